@@ -1,0 +1,168 @@
+"""Kuramoto-Sivashinsky environment pieces, fp64 NumPy restatement.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED by tests/golden/ks*_hook.npz."""
+import numpy as np
+
+from .julia_compat import julia_float_range, circshift
+
+
+class KSConfig:
+    """Globals of scripts/KS/setup/KSSetup.jl:20-77 + the experiment script
+    (e.g. scripts/KS/KS22/KS22.jl:2-21)."""
+
+    def __init__(self, nx, Lx, sensor_positions, actuator_positions=None, actuators_to_sensors=None,
+                 sigma_sensors=1.0, sigma_actuators=1.0, mu=0.0, dt=0.1, oversampling=30,
+                 max_value=30.0, agent_power=7.5, action_punish=0.002, delta_action_punish=0.002,
+                 window_size=1, te=5.0, mono=False, disturbance_in_step=True):
+        self.nx, self.Lx = int(nx), float(Lx)
+        self.dx = self.Lx / self.nx                                   # KSSetup.jl:34
+        self.sensor_positions = np.asarray(sensor_positions, dtype=np.int64)      # 1-based cells
+        self.actuator_positions = (self.sensor_positions if actuator_positions is None
+                                   else np.asarray(actuator_positions, dtype=np.int64))
+        n_act = len(self.actuator_positions)
+        self.actuators_to_sensors = (np.arange(1, n_act + 1) if actuators_to_sensors is None
+                                     else np.asarray(actuators_to_sensors, dtype=np.int64))  # 1-based
+        self.sigma_sensors, self.sigma_actuators = sigma_sensors, sigma_actuators
+        self.mu, self.dt, self.oversampling = mu, dt, int(oversampling)
+        self.max_value, self.agent_power = max_value, agent_power
+        self.action_punish, self.delta_action_punish = action_punish, delta_action_punish
+        self.window_size, self.te, self.mono = window_size, te, mono
+        self.disturbance_in_step = disturbance_in_step                # absent in KSglobalSetup.jl:167
+        self.xx = self.dx * np.arange(1, self.nx + 1)                 # collect(dx:dx:Lx), KSSetup.jl:36
+        self.gaussians = prepare_gaussians(self, sigma_sensors, 1, self.sensor_positions)
+        if mono:   # KSglobalSetup.jl:99-102,125: actuator kernels at actuator_positions, no re-indexing
+            self.gaussians_actuators = prepare_gaussians(self, sigma_actuators, 2, self.actuator_positions)
+        else:      # KSSetup.jl:112-113
+            ga = prepare_gaussians(self, sigma_actuators, 2, self.sensor_positions)
+            self.gaussians_actuators = ga[self.actuators_to_sensors - 1]
+
+
+def prepare_gaussians(cfg, sigma, norm_mode, positions):
+    """scripts/KS/setup/KSSetup.jl:82-109.  Note the reference's operator precedence:
+    exp(-((t-pos*dx)^2 / 2 * sigma^2)) (MULTIPLIED by sigma^2) and 1/sqrt(2*pi*sigma)."""
+    dx, nx, Lx = cfg.dx, cfg.nx, cfg.Lx
+    extra = 50
+    t = julia_float_range(dx - extra * dx, dx, Lx + extra * dx)              # :87
+    out = []
+    for position in positions:
+        p = (1.0 / np.sqrt(2 * np.pi * sigma)) * np.exp(-(((t - position * dx) * 1) ** 2 / 2 * sigma ** 2))  # :90
+        if norm_mode == 1:
+            p = p / p.sum()                                                   # :93
+        else:
+            p = p / p.max()                                                   # :95
+        pleft = p[:extra]                                                     # :98
+        pright = p[extra + nx:]                                               # :99
+        q = p[extra:extra + nx].copy()                                        # :100
+        q[nx - len(pleft):] += pleft                                          # :101
+        q[:len(pright)] += pright                                             # :102
+        out.append(q)
+    return np.array(out)
+
+
+def ks_operators(cfg, K=None):
+    """scripts/KS/setup/KSSetup.jl:115-123,131-135."""
+    nx, Lx = cfg.nx, cfg.Lx
+    K = cfg.oversampling if K is None else K
+    kx = np.concatenate([np.arange(0, nx // 2), [0], np.arange(-nx // 2 + 1, 0)]).astype(np.float64)  # :115
+    alpha = 2 * np.pi * kx / Lx                                               # :116
+    D = 1j * alpha                                                            # :117
+    L = alpha ** 2 - alpha ** 4                                               # :118
+    G = -0.5 * D                                                              # :119
+    h = cfg.dt / K                                                            # :131
+    dt2, dt32 = h / 2, 3 * h / 2                                              # :132-133
+    A_inv = (np.ones(nx) - dt2 * L) ** (-1)                                   # :134
+    B = np.ones(nx) + dt2 * L                                                 # :135
+    return dict(kx=kx, alpha=alpha, L=L, G=G, h=h, dt2=dt2, dt32=dt32, A_inv=A_inv, B=B)
+
+
+def do_step(cfg, y, p, ctype=np.complex128):
+    """KS CNAB2 control step, scripts/KS/setup/KSSetup.jl:130-160 (twin
+    KSglobalSetup.jl:142-172 without the disturbance term).  `ctype=np.complex64` runs the
+    same arithmetic in single precision (used to set the fp32 tolerance)."""
+    op = ks_operators(cfg)
+    rtype = np.float32 if ctype == np.complex64 else np.float64
+    G = op["G"].astype(ctype)
+    A_inv, B = op["A_inv"].astype(rtype), op["B"].astype(rtype)
+    dt2, dt32, h = rtype(op["dt2"]), rtype(op["dt32"]), rtype(op["h"])
+    fft = lambda a: np.fft.fft(a).astype(ctype)
+    ifft = lambda a: np.fft.ifft(a).astype(ctype)
+    u = np.asarray(y).astype(ctype)                                           # :137-138
+    Nn = G * fft(u ** 2)                                                      # :140
+    Nn1 = Nn.copy()                                                           # :141
+    u = fft(u)                                                                # :142
+    P = fft(np.asarray(p).astype(ctype))
+    if cfg.disturbance_in_step:
+        Dist = h * fft((cfg.mu * np.cos((2 + np.pi + cfg.xx / (cfg.Lx / 2)))).astype(ctype))
+    else:
+        Dist = 0
+    for _ in range(cfg.oversampling):                                         # :144
+        Nn1 = Nn                                                              # :145
+        w = ifft(u)                                                           # :146-148
+        Nn = G * fft(w * w)                                                   # :149-152
+        u = A_inv * (B * u + dt32 * Nn - dt2 * Nn1 + h * P) + Dist            # :155
+    return np.real(ifft(u)).astype(rtype)                                     # :158-159
+
+
+def sensor_dots(cfg, y):
+    return cfg.gaussians @ np.asarray(y, dtype=np.float64)
+
+
+def reward_function(cfg, y, action, delta_action):
+    """scripts/KS/setup/KSSetup.jl:162-178; mono variant KSglobalSetup.jl:175-199."""
+    y6 = np.asarray(y, dtype=np.float64) * 6                                  # :163
+    a2s = cfg.actuators_to_sensors - 1
+    sensors = np.abs(cfg.gaussians[a2s] @ y6) ** 1.3 / (cfg.max_value * 3)    # :169
+    sensor_rewards = -np.abs(sensors)                                         # :171
+    a = np.asarray(action, dtype=np.float64).reshape(-1)[:len(a2s)] if cfg.mono else np.asarray(action)[0, :]
+    da = np.asarray(delta_action, dtype=np.float64).reshape(-1)[:len(a2s)] if cfg.mono else np.asarray(delta_action)[0, :]
+    r = sensor_rewards - cfg.action_punish * a ** 2 - cfg.delta_action_punish * da ** 2   # :178
+    if cfg.mono:
+        return np.array([r.mean()])                                           # KSglobalSetup.jl:199
+    return r
+
+
+def featurize(cfg, y):
+    """scripts/KS/setup/KSSetup.jl:190-229 with temporal_steps=1, memory_size=0 (all shipped
+    KS experiments); mono variant KSglobalSetup.jl:211-249 returns the [S,1] column."""
+    sensors = sensor_dots(cfg, y) / cfg.max_value                             # :201
+    if cfg.mono:
+        return sensors.reshape(-1, 1)                                         # KSglobalSetup.jl:225-227
+    w = int(np.floor(cfg.window_size / 2))                                    # :204
+    rows = [circshift(sensors, i) for i in range(-w, w + 1)]                  # :205
+    result = np.stack(rows)
+    return result[:, cfg.actuators_to_sensors - 1]                            # :207
+
+
+def prepare_action(cfg, action):
+    """scripts/KS/setup/KSSetup.jl:231-245."""
+    a = np.asarray(action, dtype=np.float64)
+    a = a.reshape(-1) if cfg.mono else a[0, :]
+    p = np.zeros(cfg.nx)
+    for i in range(len(cfg.actuator_positions)):
+        p = p + cfg.agent_power * a[i] * cfg.gaussians_actuators[i]           # :241
+    return p
+
+
+def generate_random_init(cfg, rng):
+    """scripts/KS/setup/KSSetup.jl:288-298 (rng: numpy Generator; the reference draws from
+    Julia's global RNG, so only the distribution is reproduced)."""
+    number_sin = 8
+    a_i = rng.uniform(-1, 1, number_sin)
+    a_i = a_i / np.linalg.norm(a_i)
+    y0 = np.zeros(cfg.nx)
+    for i in range(1, number_sin + 1):
+        y0 += a_i[i - 1] * np.sin(i * cfg.xx / (2 * np.pi))
+    return y0 * 30 / np.linalg.norm(y0)
+
+
+def env_step(cfg, y, action_prev, action, time):
+    """(env::PDEenv)(action), src/PDEenv.jl:195-241, with the KS closures."""
+    action = np.asarray(action, dtype=np.float64)
+    delta_action = action - np.asarray(action_prev, dtype=np.float64)         # :196
+    p = prepare_action(cfg, action)                                           # :199
+    y_new = do_step(cfg, y, p)                                                # :217
+    reward = reward_function(cfg, y_new, action, delta_action)                # :220
+    state = featurize(cfg, y_new)                                             # :222
+    time = time + cfg.dt                                                      # :225
+    done = bool(time >= cfg.te or np.max(np.abs(y_new)) > cfg.max_value)      # :227
+    return dict(y=y_new, p=p, reward=reward, state=state, done=done, time=time,
+                delta_action=delta_action)

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Extract golden vectors from the reference's saved .jld2 artifacts into small .npz
+fixtures (DATA only: inputs and expected outputs logged by the reference's own PDEhook,
+src/PDEhook.jl:54-62, plus saved network weights).  Run ONCE in the build container:
+
+    python tests/golden/make_golden.py            # needs /root/reference
+
+The GPU box has no /root/reference; tests read only the committed .npz files.
+Attribution: data derived from janstenner/DistributedConvRL-PDE-Control (GPL-3.0).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from jld2_reader import JLD2File  # noqa: E402
+
+REF = os.environ.get("PDEC_REFERENCE", "/root/reference")
+
+
+def hook_traj(path):
+    """bestDF columns (action, p, y, reward) in file order, each a list of per-step arrays."""
+    f = JLD2File(path)
+    refs = [o for o in f.ref_arrays() if o.dims and o.dims[0] > 5]
+    n = refs[0].dims[0]
+    refs = [o for o in refs if o.dims[0] == n][:4]
+    cols = []
+    for o in refs:
+        rows = [f.array(f.deref(r)) for r in f.array(o)]
+        cols.append(np.stack(rows).astype(np.float64))
+    f32 = [f.array(o) for o in f.numeric(1, 4) if o.dims]
+    rewards = [f.array(o) for o in f.numeric(1, 8) if o.dims and len(o.dims) == 1]
+    return cols, f32, rewards, f
+
+
+def save(name, **kw):
+    out = os.path.join(HERE, name)
+    np.savez_compressed(out, **kw)
+    print(f"{name}: " + ", ".join(f"{k}{tuple(np.shape(v))}" for k, v in kw.items()),
+          f"-> {os.path.getsize(out)} B")
+
+
+def weights_dict(f32, prefix_names=("best", "current")):
+    """Float32 arrays in file order = bestNNA then currentNNA Dense W,b,W,b..."""
+    half = len(f32) // 2
+    d = {}
+    for pi, pref in enumerate(prefix_names):
+        chunk = f32[pi * half:(pi + 1) * half]
+        for li in range(len(chunk) // 2):
+            d[f"{pref}_W{li+1}"] = np.ascontiguousarray(chunk[2 * li])
+            d[f"{pref}_b{li+1}"] = np.ascontiguousarray(chunk[2 * li + 1])
+    return d
+
+
+def ks(name, rel, nx, Lx, stride, sigma, mu=0.0, extra=None):
+    (action, p, y, reward), f32, rew, f = hook_traj(os.path.join(REF, rel))
+    episode_rewards = max((r for r in rew if r.ndim == 1 and r.size not in (action.shape[1], nx)),
+                          key=lambda r: r.size, default=np.zeros(0))
+    kw = dict(action=action, p=p, y=y, reward=reward, nx=nx, Lx=Lx, sensor_stride=stride,
+              sigma=sigma, mu=mu, dt=0.1, oversampling=30, episode_rewards=episode_rewards)
+    kw.update(weights_dict(f32))
+    if extra:
+        kw.update(extra)
+    save(name, **kw)
+
+
+def main():
+    ks("ks22_hook.npz", "scripts/KS/KS22/saves/hook.jld2", 192, 22.0, 24, 0.7)
+    ks("ks200_hook.npz", "scripts/KS/KS200/saves/hook.jld2", 240, 200.0, 3, 1.0)
+    fy = JLD2File(os.path.join(REF, "scripts/KS/KS22_global-agent/y0.jld2"))
+    y0 = [fy.array(o) for o in fy.numeric(1, 8) if o.dims][0]
+    ks("ks22_global_hook.npz", "scripts/KS/KS22_global-agent/saves/hook.jld2", 192, 22.0, 24, 0.7,
+       extra=dict(y0=y0))
+
+    # Keller-Segel: 1334 logged steps; keep every 11th consecutive PAIR (t, t+1) -> ~120 pairs
+    (action, p, y, reward), f32, rew, f = hook_traj(
+        os.path.join(REF, "scripts/Keller-Segel/Keller-Segel10_16/saves/hook.jld2"))
+    idx = np.arange(0, action.shape[0] - 1, 11)
+    kw = dict(idx=idx, action_t=action[idx], action_t1=action[idx + 1], p_t1=p[idx + 1],
+              y_t=y[idx], y_t1=y[idx + 1], reward_t1=reward[idx + 1], nx=100, Lx=10.0, dt=0.006)
+    kw.update(weights_dict(f32))
+    save("kseg_hook.npz", **kw)
+
+    # Fluid: only actor weights and episode rewards are stored (collect_bestDF=false)
+    for k in (8, 16, 32):
+        fl = JLD2File(os.path.join(REF, f"scripts/Fluid/Fluid_{k}/saves/hook.jld2"))
+        f32 = [fl.array(o) for o in fl.numeric(1, 4) if o.dims]
+        rew = [fl.array(o) for o in fl.numeric(1, 8) if o.dims and len(o.dims) == 1]
+        kw = weights_dict(f32)
+        kw["episode_rewards"] = max(rew, key=lambda r: r.size) if rew else np.zeros(0)
+        save(f"fluid{k}_hook.npz", **kw)
+
+    # agent.jld2 (KS22): 4 nets, replay-buffer head (first 4096 transitions), ADAM constants
+    fa = JLD2File(os.path.join(REF, "scripts/KS/KS22/saves/agent.jld2"))
+    f32 = [(o, fa.array(o)) for o in fa.numeric(1, 4) if o.dims]
+    small = [a for o, a in f32 if a.size < 2000]
+    big = [a for o, a in f32 if a.size >= 2000]
+    kw = {}
+    for i, a in enumerate(small):
+        kw[f"f32_{i:02d}"] = np.ascontiguousarray(a)
+    for i, a in enumerate(big):
+        a2 = a.reshape(a.shape[0], -1) if a.ndim == 2 else a.reshape(1, -1)
+        kw[f"buf_{i}_shape"] = np.array(a.shape)
+        kw[f"buf_{i}_head"] = np.ascontiguousarray(a2[:, :4096])
+    bools = [fa.array(o) for o in fa.objs.values() if o.cls == 0 and o.size == 1 and o.dims and o.data_off]
+    for i, b in enumerate(bools):
+        kw[f"terminal_{i}_shape"] = np.array(b.shape)
+        kw[f"terminal_{i}_head"] = np.ascontiguousarray(b.reshape(-1)[:4096])
+    # ADAM hyper-parameters: byte search for [eta, 0.9, 0.999, 1e-8] Float64 quadruples
+    pat = np.array([0.9, 0.999, 1e-8]).tobytes()
+    etas, pos = [], 0
+    while True:
+        pos = fa.buf.find(pat, pos)
+        if pos < 0:
+            break
+        etas.append(np.frombuffer(fa.buf[pos - 8:pos], "<f8")[0])
+        pos += 8
+    kw["adam_eta"] = np.array(etas)
+    kw["adam_beta_eps"] = np.array([0.9, 0.999, 1e-8])
+    save("ks22_agent.npz", **kw)
+
+
+if __name__ == "__main__":
+    main()
