@@ -1,0 +1,11 @@
+"""distributedconvrl-pde-control_amd -- MI355X-native hot path of
+janstenner/DistributedConvRL-PDE-Control behind the reference's PDEenv / PDEagent / PDEhook
+operator surface.  Compute lives in libpdeconv.so (hand-written HIP for gfx950, C ABI in
+include/pdeconv.h); this package is the host-side mirror of the reference's interface.
+Import as:  pkg = importlib.import_module("distributedconvrl-pde-control_amd")"""
+from . import _lib  # noqa: F401
+from ._lib import PdecError  # noqa: F401
+from .setups import KSSetup, KellerSegelSetup  # noqa: F401
+from .env import PDEenv  # noqa: F401
+from .nna import (HipMLP, ADAM, CustomNeuralNetworkApproximator, create_NNA, create_chain,  # noqa: F401
+                  glorot_uniform, layer_spec)

@@ -1,0 +1,131 @@
+"""ctypes binding of libpdeconv.so (the C ABI declared in include/pdeconv.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails,
+an exception is raised.  Nothing here imports oracle/."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdeconv.so")
+
+PDEC_F32, PDEC_F64 = 0, 1
+PDE_KS_CNAB2, PDE_KSEG_RK4, PDE_KS_RK4_FD, PDE_FLUID_RK4 = 0, 1, 2, 3
+ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
+
+Handle = C.c_uint64
+
+
+class PdecError(RuntimeError):
+    pass
+
+
+class EnvCfg(C.Structure):
+    """mirror of `struct pdec_env_cfg` (include/pdeconv.h)"""
+    _fields_ = [
+        ("pde_kind", C.c_int), ("dtype", C.c_int), ("B", C.c_int), ("N", C.c_int),
+        ("n_species", C.c_int), ("S", C.c_int), ("A", C.c_int), ("window", C.c_int),
+        ("temporal_steps", C.c_int), ("mono", C.c_int), ("K", C.c_int), ("check_max_value", C.c_int),
+        ("Lx", C.c_double), ("dt", C.c_double), ("mu", C.c_double), ("max_value", C.c_double),
+        ("sensor_scale", C.c_double), ("agent_power", C.c_double), ("reward_in_scale", C.c_double),
+        ("reward_offset", C.c_double), ("reward_power", C.c_double), ("reward_denom", C.c_double),
+        ("action_punish", C.c_double), ("delta_action_punish", C.c_double),
+    ]
+
+
+_vp, _i, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint64
+_pi32 = C.POINTER(C.c_int32)
+_pd = C.POINTER(C.c_double)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "pdec_init": [_i], "pdec_shutdown": [], "pdec_version": [], "pdec_device_count": [C.POINTER(_i)],
+    "pdec_malloc": [C.POINTER(_vp), _sz], "pdec_free": [_vp],
+    "pdec_memcpy_h2d": [_vp, _vp, _sz], "pdec_memcpy_d2h": [_vp, _vp, _sz], "pdec_memset": [_vp, _i, _sz],
+    "pdec_set_stream": [Handle, _vp], "pdec_sync": [Handle], "pdec_destroy": [Handle],
+    "pdec_prof_enable": [Handle, _i], "pdec_prof_reset": [Handle],
+    "pdec_prof_get": [Handle, C.c_char_p, _pd, C.POINTER(_i)],
+    "pdec_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _pd, _pd, _pi32],
+    "pdec_actuate": [Handle, _vp, _vp],
+    "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
+    "pdec_featurize": [Handle, _vp, _vp, _vp],
+    "pdec_reward": [Handle, _vp, _vp, _vp, _vp],
+    "pdec_env_step": [Handle] + [_vp] * 9,
+    "pdec_rhs_eval": [Handle, _vp, _vp, _vp],
+    "pdec_pde_step_host": [Handle, _vp, _vp, _vp, _vp],
+    "pdec_env_step_host": [Handle] + [_vp] * 9,
+    "pdec_mlp_create": [C.POINTER(Handle), _i, _i, _pi32, _pi32, _vp, _i],
+    "pdec_mlp_num_params": [Handle, C.POINTER(_i)],
+    "pdec_mlp_set_params": [Handle, _vp], "pdec_mlp_get_params": [Handle, _vp],
+    "pdec_mlp_copy": [Handle, Handle],
+    "pdec_mlp_forward": [Handle, _vp, _i, _vp],
+    "pdec_mlp_backward": [Handle, _vp, _vp, _i, _vp, _vp],
+    "pdec_mlp_grad_buffer": [Handle, C.POINTER(_vp), C.POINTER(_i)],
+    "pdec_adam_step": [Handle, _d, _d, _d, _d],
+    "pdec_adam_get_state": [Handle, _vp, _vp, _pd], "pdec_adam_set_state": [Handle, _vp, _vp, _pd],
+    "pdec_polyak": [Handle, Handle, _d],
+    "pdec_policy_act": [Handle, _vp, _vp, _i, _d, _d, _vp],
+    "pdec_randn": [Handle, _vp, _sz, _i, _u64, _u64],
+    "pdec_ddpg_critic_grads": [Handle] * 4 + [_vp] * 5 + [_i, _d, _i, _d, _vp],
+    "pdec_ddpg_actor_grads": [Handle, Handle, _vp, _i, _d, _vp],
+    "pdec_ddpg_update": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _pd, _pd],
+    "pdec_comm_unique_id": [_vp], "pdec_comm_create": [C.POINTER(Handle), _i, _i, _vp],
+    "pdec_allreduce_grads": [Handle, Handle], "pdec_allreduce": [Handle, _vp, _sz, _i, _vp],
+}
+_RESTYPES = {"pdec_last_error": C.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load libpdeconv.so (once).  Raises PdecError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PdecError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C distributedconvrl-pde-control_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.pdec_last_error.argtypes = []
+    lib.pdec_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PdecError(f"libpdeconv error {rc}: {load().pdec_last_error().decode(errors='replace')}")
+
+
+_inited = set()
+
+
+def init(device=0):
+    lib = load()
+    if device not in _inited:
+        check(lib.pdec_init(int(device)))
+        _inited.add(device)
+    return lib
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return PDEC_F32
+    if torch_dtype == torch.float64:
+        return PDEC_F64
+    raise PdecError(f"unsupported dtype {torch_dtype}")
+
+
+def ptr(t):
+    """device (or host) address of a torch tensor / numpy array / None"""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        assert t.is_contiguous(), "libpdeconv needs contiguous tensors"
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)

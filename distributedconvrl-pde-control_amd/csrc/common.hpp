@@ -1,0 +1,116 @@
+// common.hpp -- handle registry, error plumbing, per-kernel event timing for libpdeconv.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pdeconv.h"
+
+namespace pdec {
+
+void set_error(const char* fmt, ...);
+
+#define PDEC_HIP(call)                                                                  \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      pdec::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                      __LINE__);                                                        \
+      return PDEC_E_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+#define PDEC_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      pdec::set_error(__VA_ARGS__);    \
+      return PDEC_E_INVALID;           \
+    }                                  \
+  } while (0)
+
+enum class Kind { Env, Mlp, Comm };
+
+struct ProfEntry {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+
+struct Object {
+  Kind kind;
+  hipStream_t stream = nullptr;
+  bool prof = false;
+  std::map<std::string, ProfEntry> profs;
+  explicit Object(Kind k) : kind(k) {}
+  virtual ~Object();
+};
+
+// RAII launch timer: records events around a launch when profiling is on
+struct ProfScope {
+  Object* o;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const char* name;
+  ProfScope(Object* obj, const char* nm) : o(obj), name(nm) {
+    if (o->prof) {
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, o->stream);
+    }
+  }
+  ~ProfScope() {
+    if (o->prof) {
+      (void)hipEventRecord(e1, o->stream);
+      o->profs[name].ev.emplace_back(e0, e1);
+    }
+  }
+};
+
+pdec_handle register_object(std::unique_ptr<Object> o);
+Object* lookup(pdec_handle h);
+template <class T>
+T* lookup_as(pdec_handle h, Kind k) {
+  Object* o = lookup(h);
+  if (!o || o->kind != k) return nullptr;
+  return static_cast<T*>(o);
+}
+
+inline size_t dtype_size(int dt) { return dt == PDEC_F64 ? 8 : 4; }
+
+// device buffer with RAII
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+    o.p = nullptr;
+    o.bytes = 0;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t alloc(size_t n) {
+    release();
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+// upload a host double array converted to dtype
+int upload_converted(DevBuf& dst, const double* src, size_t n, int dtype);
+
+}  // namespace pdec

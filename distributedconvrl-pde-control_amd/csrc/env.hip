@@ -1,0 +1,829 @@
+// env.hip -- batched PDE environment step for gfx950: actuator synthesis, time integration,
+// sensor read-out, reward, im2col featurize and blow-up flag fused in one launch.
+//
+// Restates (from scratch, batched over independent trajectories):
+//   (env::PDEenv)(action)              src/PDEenv.jl:195-241
+//   KS do_step (CNAB2, spectral)       scripts/KS/setup/KSSetup.jl:115-160
+//   Keller-Segel f + RK4               scripts/Keller-Segel/setup/KellerSegelSetup.jl:213-239
+//   featurize / prepare_action / reward_function   KSSetup.jl:162-245, KellerSegelSetup.jl:241-332
+//
+// KS kernel design: one workgroup integrates TWO trajectories packed as the real and
+// imaginary part of one complex sequence z = u_a + i u_b.  Every operator of the CNAB2
+// scheme is either a real diagonal in wave space (A_inv, B), multiplication by the purely
+// imaginary diagonal G = -i alpha/2 (linear, so it acts on the packed spectrum directly) or
+// the pointwise square in physical space, which acts on Re and Im separately -- so the pair
+// never has to be separated and one complex FFT serves two trajectories.  All 2K+3 FFTs of
+// a control step run out of LDS (mixed-radix Stockham); per-mode state lives in registers;
+// HBM sees only the compulsory traffic (y, action in; y, state, reward, done out).
+#include "common.hpp"
+#include "fft_lds.hpp"
+
+namespace pdec {
+
+template <class T>
+struct EnvDev {
+  int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species;
+  T sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
+  T dx, hstep;           // K-S: cell size, RK4 sub-step
+  const T* Gt;           // [N][S]  sensor kernels, transposed (coalesced over sensors)
+  const T* Ga;           // [A][N]  actuator kernels
+  const T* gsum;         // [S]     sum of each sensor kernel (reward offset term)
+  const int* a2s;        // [A]
+  // KS CNAB2 per-mode constants
+  const T *c1, *c2, *c3, *c4, *g;
+  const C2<T>* dhat;     // h * fft(mu cos(...))
+  const C2<T>* tw;       // exp(-2 pi i k/N)
+  FftPlan fft;
+};
+
+struct Env : Object {
+  pdec_env_cfg cfg;
+  DevBuf Gt, Ga, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
+  DevBuf stage;  // staging for the _host wrappers
+  FftPlan fft;
+  int nthreads = 64;
+  size_t lds_bytes = 0;
+  Env() : Object(Kind::Env) {}
+};
+
+// ------------------------------------------------------------------ shared device pieces
+
+// dots[r][s] = sum_n Gt[n][s] * y_r[n] for r in {0,1}; yf(r,n) reads LDS.  Threads are
+// split into groups that each cover a slice of n; partials are combined through `part`.
+template <class T, class YF>
+__device__ __forceinline__ void sense_dots(const EnvDev<T>& e, YF yf, T* dots, T* part, int tid, int nt) {
+  const int S = e.S, N = e.N;
+  int ng = nt / S;
+  if (ng < 1) ng = 1;
+  if (ng > 8) ng = 8;
+  const int chunk = (N + ng - 1) / ng;
+  for (int idx = tid; idx < ng * S; idx += nt) {
+    const int grp = idx / S, s = idx - grp * S;
+    int n0 = grp * chunk, n1 = n0 + chunk;
+    if (n1 > N) n1 = N;
+    T a0 = 0, a1 = 0;
+    for (int n = n0; n < n1; ++n) {
+      const T gk = e.Gt[(size_t)n * S + s];
+      a0 += gk * yf(0, n);
+      a1 += gk * yf(1, n);
+    }
+    part[(grp * 2 + 0) * S + s] = a0;
+    part[(grp * 2 + 1) * S + s] = a1;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 2 * S; idx += nt) {
+    T acc = 0;
+    for (int grp = 0; grp < ng; ++grp) acc += part[grp * 2 * S + idx];
+    dots[idx] = acc;
+  }
+  __syncthreads();
+}
+
+template <class T>
+__device__ __forceinline__ T pow_abs(T d, T p) {
+  d = d < 0 ? -d : d;
+  if (p == (T)2) return d * d;
+  if (p == (T)1) return d;
+  return d == 0 ? (T)0 : (T)pow((double)d, (double)p);
+}
+template <>
+__device__ __forceinline__ float pow_abs<float>(float d, float p) {
+  d = fabsf(d);
+  if (p == 2.0f) return d * d;
+  if (p == 1.0f) return d;
+  return d == 0.0f ? 0.0f : powf(d, p);
+}
+
+// reward_function for one trajectory: dots = <y, g_s> of the species the reward looks at
+template <class T>
+__device__ __forceinline__ void reward_traj(const EnvDev<T>& e, const T* dots, const T* act, const T* actp,
+                                            T* r_out, int tid, int nt) {
+  if (!e.mono) {
+    for (int a = tid; a < e.A; a += nt) {
+      const int s = e.a2s[a];
+      const T d = e.r_in_scale * (dots[s] + e.r_offset * e.gsum[s]);
+      const T da = act[a] - actp[a];
+      r_out[a] = -pow_abs<T>(d, e.r_power) / e.r_denom - e.a_pun * act[a] * act[a] - e.da_pun * da * da;
+    }
+  } else if (tid == 0) {
+    T acc = 0;
+    for (int a = 0; a < e.A; ++a) {
+      const int s = e.a2s[a];
+      const T d = e.r_in_scale * (dots[s] + e.r_offset * e.gsum[s]);
+      const T da = act[a] - actp[a];
+      acc += -pow_abs<T>(d, e.r_power) / e.r_denom - e.a_pun * act[a] * act[a] - e.da_pun * da * da;
+    }
+    r_out[0] = acc / (T)e.A;
+  }
+}
+
+// featurize for one trajectory.  dots: [n_species][S]; state/prev: [A][ns] (or [1][S] mono)
+template <class T>
+__device__ __forceinline__ void featurize_traj(const EnvDev<T>& e, const T* dots, const T* prev, T* state,
+                                               int tid, int nt) {
+  if (e.mono) {
+    for (int s = tid; s < e.S; s += nt) state[s] = dots[s] * e.sensor_scale;
+    return;
+  }
+  const int w = e.window / 2;
+  const int fresh = e.window * e.n_species;
+  for (int idx = tid; idx < e.A * e.ns; idx += nt) {
+    const int a = idx / e.ns, rr = idx - a * e.ns;
+    T v;
+    if (rr < fresh || prev == nullptr) {
+      const int r0 = rr % fresh;
+      const int sp = r0 / e.window, i = (r0 - sp * e.window) - w;
+      int s = (e.a2s[a] - i) % e.S;
+      if (s < 0) s += e.S;
+      v = dots[sp * e.S + s] * e.sensor_scale;
+    } else {
+      v = prev[a * e.ns + (rr - fresh)];
+    }
+    state[idx] = v;
+  }
+}
+
+// p[n] = agent_power * sum_a act[a] * Ga[a][n]
+template <class T>
+__device__ __forceinline__ T actuate_cell(const EnvDev<T>& e, const T* act, int n) {
+  T acc = 0;
+  for (int a = 0; a < e.A; ++a) acc += act[a] * e.Ga[(size_t)a * e.N + n];
+  return acc * e.agent_power;
+}
+
+template <class T>
+__device__ __forceinline__ T block_max(T v, T* red, int tid, int nt) {
+  for (int off = 32; off > 0; off >>= 1) {
+    T o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  T r = red[0];
+  for (int i = 1; i < (nt + 63) / 64; ++i) r = red[i] > r ? red[i] : r;
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------ KS CNAB2 kernel
+#define KS_MPT 4  // modes / cells owned per thread: k = tid + j*nt
+
+template <class T, bool FUSED>
+__global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
+                                   const T* __restrict__ action, const T* __restrict__ action_prev,
+                                   const T* __restrict__ state_prev, T* __restrict__ y_out,
+                                   T* __restrict__ p_out, T* __restrict__ state_out,
+                                   T* __restrict__ reward_out, int32_t* __restrict__ done) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = e.N, tid = threadIdx.x, nt = blockDim.x;
+  C2<T>* X = reinterpret_cast<C2<T>*>(smem_raw);
+  C2<T>* Y = X + N;
+  C2<T>* tw = Y + N;
+  T* act = reinterpret_cast<T*>(tw + N);  // [2][A] current, then [2][A] previous
+  T* actp = act + 2 * e.A;
+  T* dots = actp + 2 * e.A;               // [2][S]
+  T* part = dots + 2 * e.S;               // [8][2][S]
+  T* red = part + 16 * e.S;               // [16]
+
+  const int b0 = 2 * blockIdx.x, b1 = b0 + 1;
+  const bool has1 = b1 < e.B;
+  const size_t o0 = (size_t)b0 * N, o1 = (size_t)b1 * N;
+
+  for (int k = tid; k < N; k += nt) tw[k] = e.tw[k];
+  if (FUSED) {
+    for (int a = tid; a < e.A; a += nt) {
+      act[a] = action[(size_t)b0 * e.A + a];
+      act[e.A + a] = has1 ? action[(size_t)b1 * e.A + a] : (T)0;
+      actp[a] = action_prev[(size_t)b0 * e.A + a];
+      actp[e.A + a] = has1 ? action_prev[(size_t)b1 * e.A + a] : (T)0;
+    }
+  }
+  __syncthreads();
+
+  // forcing p (packed) -> X
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {
+    const int n = tid + j * nt;
+    if (n < N) {
+      T pa, pb;
+      if (FUSED) {
+        pa = actuate_cell<T>(e, act, n);
+        pb = has1 ? actuate_cell<T>(e, act + e.A, n) : (T)0;
+        if (p_out) {
+          p_out[o0 + n] = pa;
+          if (has1) p_out[o1 + n] = pb;
+        }
+      } else {
+        pa = p_in[o0 + n];
+        pb = has1 ? p_in[o1 + n] : (T)0;
+      }
+      X[n] = mk<T>(pa, pb);
+    }
+  }
+  C2<T> U[KS_MPT], Nn[KS_MPT], Ck[KS_MPT];
+  T kc1[KS_MPT], kc2[KS_MPT], kc3[KS_MPT], kg[KS_MPT];
+  {
+    C2<T>* R = fft_lds<-1, T>(X, Y, tw, e.fft, tid, nt);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) {
+        const C2<T> d = e.dhat[k];
+        const T c4 = e.c4[k];
+        // (1+i)*dhat: the same real disturbance enters both packed trajectories
+        Ck[j] = mk<T>(c4 * R[k].x + (d.x - d.y), c4 * R[k].y + (d.x + d.y));
+        kc1[j] = e.c1[k];
+        kc2[j] = e.c2[k];
+        kc3[j] = e.c3[k];
+        kg[j] = e.g[k];
+      }
+    }
+    __syncthreads();
+  }
+  // Nn = G * fft(u^2)
+  C2<T> yv[KS_MPT];
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {
+    const int n = tid + j * nt;
+    if (n < N) {
+      yv[j] = mk<T>(y_in[o0 + n], has1 ? y_in[o1 + n] : (T)0);
+      X[n] = mk<T>(yv[j].x * yv[j].x, yv[j].y * yv[j].y);
+    }
+  }
+  {
+    C2<T>* R = fft_lds<-1, T>(X, Y, tw, e.fft, tid, nt);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) Nn[j] = cscale(mul_i<+1, T>(R[k]), kg[j]);  // G = i * (-alpha/2)
+    }
+    __syncthreads();
+  }
+  // u_hat = fft(u)
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {
+    const int n = tid + j * nt;
+    if (n < N) X[n] = yv[j];
+  }
+  {
+    C2<T>* R = fft_lds<-1, T>(X, Y, tw, e.fft, tid, nt);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) U[j] = R[k];
+    }
+    __syncthreads();
+  }
+  const T invN = (T)1 / (T)N;
+  for (int it = 0; it < e.K; ++it) {
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) X[k] = U[j];
+    }
+    C2<T>* R = fft_lds<+1, T>(X, Y, tw, e.fft, tid, nt);
+    C2<T>* O = (R == X) ? Y : X;  // write squares into the other buffer
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int n = tid + j * nt;
+      if (n < N) {
+        const T wr = R[n].x * invN, wi = R[n].y * invN;
+        O[n] = mk<T>(wr * wr, wi * wi);
+      }
+    }
+    C2<T>* R2 = fft_lds<-1, T>(O, R, tw, e.fft, tid, nt);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) {
+        const C2<T> nn1 = Nn[j];
+        Nn[j] = cscale(mul_i<+1, T>(R2[k]), kg[j]);
+        U[j] = mk<T>(kc1[j] * U[j].x + kc2[j] * Nn[j].x - kc3[j] * nn1.x + Ck[j].x,
+                     kc1[j] * U[j].y + kc2[j] * Nn[j].y - kc3[j] * nn1.y + Ck[j].y);
+      }
+    }
+    __syncthreads();
+  }
+  // y+ = real(ifft(u_hat))
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {
+    const int k = tid + j * nt;
+    if (k < N) X[k] = U[j];
+  }
+  C2<T>* R = fft_lds<+1, T>(X, Y, tw, e.fft, tid, nt);
+  T mx0 = 0, mx1 = 0;
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {
+    const int n = tid + j * nt;
+    if (n < N) {
+      const T ya = R[n].x * invN, yb = R[n].y * invN;
+      R[n] = mk<T>(ya, yb);
+      y_out[o0 + n] = ya;
+      if (has1) y_out[o1 + n] = yb;
+      // blow-up test max|y| > max_value (src/PDEenv.jl:227); a NaN also raises the flag
+      // (deliberate deviation: Julia's `NaN > max_value` is false and the run would go on)
+      if (!(fabs(ya) <= e.max_value)) mx0 = 1;
+      if (!(fabs(yb) <= e.max_value)) mx1 = 1;
+    }
+  }
+  if (done) {
+    mx0 = block_max<T>(mx0, red, tid, nt);
+    mx1 = block_max<T>(mx1, red, tid, nt);
+    if (tid == 0) {
+      const bool chk = e.check_max == 1;
+      done[b0] = (chk && mx0 > 0) ? 1 : 0;
+      if (has1) done[b1] = (chk && mx1 > 0) ? 1 : 0;
+    }
+  }
+  if (!FUSED) return;
+  __syncthreads();
+  const T* Rt = reinterpret_cast<const T*>(R);
+  sense_dots<T>(e, [&](int r, int n) { return Rt[2 * n + r]; }, dots, part, tid, nt);
+  const int rw = e.mono ? 1 : e.A;             // reward entries per trajectory
+  const int sw = e.mono ? e.S : e.A * e.ns;    // state entries per trajectory
+  reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b0 * rw, tid, nt);
+  featurize_traj<T>(e, dots, state_prev ? state_prev + (size_t)b0 * sw : nullptr, state_out + (size_t)b0 * sw, tid, nt);
+  if (has1) {
+    reward_traj<T>(e, dots + e.S, act + e.A, actp + e.A, reward_out + (size_t)b1 * rw, tid, nt);
+    featurize_traj<T>(e, dots + e.S, state_prev ? state_prev + (size_t)b1 * sw : nullptr,
+                      state_out + (size_t)b1 * sw, tid, nt);
+  }
+  if (done && e.check_max == 2) {
+    // check_max_value == "reward" (src/PDEenv.jl:232-237): flag on max|reward|
+    __syncthreads();
+    if (tid == 0) {
+      for (int t = 0; t < (has1 ? 2 : 1); ++t) {
+        T m = 0;
+        const T* r = reward_out + (size_t)(b0 + t) * rw;
+        for (int a = 0; a < rw; ++a)
+          if (!(fabs(r[a]) <= e.max_value)) m = 1;
+        done[b0 + t] = m > 0 ? 1 : 0;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Keller-Segel RK4 kernel
+// One workgroup per trajectory, one cell per thread; u,v in registers, neighbours through
+// LDS with the reference's zero-flux edge fix-up (KellerSegelSetup.jl:220-223).
+template <class T>
+__device__ __forceinline__ void kseg_rhs(T u, T v, T p, T* su, T* sv, int n, int N, T idx, T idx2, bool live,
+                                         T& du, T& dv) {
+  __syncthreads();
+  if (live) {
+    su[n + 1] = u;
+    sv[n + 1] = v;
+    if (n == 0) {
+      su[0] = u;
+      sv[0] = v;
+    }
+    if (n == N - 1) {
+      su[N + 1] = u;
+      sv[N + 1] = v;
+    }
+  }
+  __syncthreads();
+  if (live) {
+    const T um = su[n], up = su[n + 2], vm = sv[n], vp = sv[n + 2];
+    const T ux = (T)0.5 * idx * (up - um);
+    const T uxx = idx2 * um - (T)2 * idx2 * u + idx2 * up;
+    const T vx = (T)0.5 * idx * (vp - vm);
+    const T vxx = idx2 * vm - (T)2 * idx2 * v + idx2 * vp;
+    dv = vxx - v + u + p;
+    du = uxx + u - (T)5.6 * ux * vx - (T)5.6 * u * vxx - u * u;
+  }
+}
+
+template <class T, int MODE>  // MODE 0: fused env step, 1: integrate only, 2: rhs only
+__global__ void kseg_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
+                                     const T* __restrict__ action, const T* __restrict__ action_prev,
+                                     const T* __restrict__ state_prev, T* __restrict__ y_out,
+                                     T* __restrict__ p_out, T* __restrict__ state_out,
+                                     T* __restrict__ reward_out, int32_t* __restrict__ done) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = e.N, tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+  T* su = reinterpret_cast<T*>(smem_raw);  // [N+2]
+  T* sv = su + N + 2;                      // [N+2]
+  T* act = sv + N + 2;                     // [A]
+  T* actp = act + e.A;                     // [A]
+  T* dots = actp + e.A;                    // [2][S]
+  T* part = dots + 2 * e.S;                // [8][2][S]
+  T* red = part + 16 * e.S;                // [16]
+  const int n = tid;
+  const bool live = n < N;
+  // y[2, nx] Julia column-major: element (species, cell) at cell*2 + species
+  const size_t yo = (size_t)b * 2 * N;
+  T u = live ? y_in[yo + 2 * n] : (T)0, v = live ? y_in[yo + 2 * n + 1] : (T)0;
+  T p = 0;
+  if (MODE == 0) {
+    for (int a = tid; a < e.A; a += nt) {
+      act[a] = action[(size_t)b * e.A + a];
+      actp[a] = action_prev[(size_t)b * e.A + a];
+    }
+    __syncthreads();
+    if (live) {
+      p = actuate_cell<T>(e, act, n);
+      if (p_out) p_out[(size_t)b * N + n] = p;
+    }
+  } else if (live) {
+    p = p_in[(size_t)b * N + n];
+  }
+  const T idx = (T)1 / e.dx, idx2 = (T)1 / (e.dx * e.dx);
+  if (MODE == 2) {
+    T du = 0, dv = 0;
+    kseg_rhs<T>(u, v, p, su, sv, n, N, idx, idx2, live, du, dv);
+    if (live) {
+      y_out[yo + 2 * n] = du;
+      y_out[yo + 2 * n + 1] = dv;
+    }
+    return;
+  }
+  const T h = e.hstep;
+  for (int it = 0; it < e.K; ++it) {
+    T k1u = 0, k1v = 0, k2u = 0, k2v = 0, k3u = 0, k3v = 0, k4u = 0, k4v = 0;
+    kseg_rhs<T>(u, v, p, su, sv, n, N, idx, idx2, live, k1u, k1v);
+    kseg_rhs<T>(u + (T)0.5 * h * k1u, v + (T)0.5 * h * k1v, p, su, sv, n, N, idx, idx2, live, k2u, k2v);
+    kseg_rhs<T>(u + (T)0.5 * h * k2u, v + (T)0.5 * h * k2v, p, su, sv, n, N, idx, idx2, live, k3u, k3v);
+    kseg_rhs<T>(u + h * k3u, v + h * k3v, p, su, sv, n, N, idx, idx2, live, k4u, k4v);
+    u = u + h / (T)6 * (k1u + (T)2 * (k2u + k3u) + k4u);
+    v = v + h / (T)6 * (k1v + (T)2 * (k2v + k3v) + k4v);
+  }
+  if (live) {
+    y_out[yo + 2 * n] = u;
+    y_out[yo + 2 * n + 1] = v;
+  }
+  if (done) {
+    T m = (live && !(fabs(u) <= e.max_value && fabs(v) <= e.max_value)) ? (T)1 : (T)0;
+    m = block_max<T>(m, red, tid, nt);
+    if (tid == 0) done[b] = (e.check_max == 1 && m > 0) ? 1 : 0;
+  }
+  if (MODE != 0) return;
+  __syncthreads();
+  if (live) {
+    su[n] = u;
+    sv[n] = v;
+  }
+  __syncthreads();
+  sense_dots<T>(e, [&](int r, int nn) { return r == 0 ? su[nn] : sv[nn]; }, dots, part, tid, nt);
+  reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b * e.A, tid, nt);
+  const size_t sw = (size_t)e.A * e.ns;
+  featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, state_out + b * sw, tid, nt);
+  if (done && e.check_max == 2) {
+    __syncthreads();
+    if (tid == 0) {
+      T m = 0;
+      for (int a = 0; a < e.A; ++a)
+        if (!(fabs(reward_out[(size_t)b * e.A + a]) <= e.max_value)) m = 1;
+      done[b] = m > 0 ? 1 : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stand-alone closures
+// MODE 0: prepare_action, 1: featurize, 2: reward
+template <class T, int MODE>
+__global__ void sense_kernel(EnvDev<T> e, const T* __restrict__ y, const T* __restrict__ action,
+                             const T* __restrict__ action_prev, const T* __restrict__ state_prev,
+                             T* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = e.N, tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+  T* sy = reinterpret_cast<T*>(smem_raw);  // [2][N]
+  T* act = sy + 2 * N;
+  T* actp = act + e.A;
+  T* dots = actp + e.A;
+  T* part = dots + 2 * e.S;
+  if (MODE == 0 || MODE == 2) {
+    for (int a = tid; a < e.A; a += nt) {
+      act[a] = action[(size_t)b * e.A + a];
+      actp[a] = MODE == 2 ? action_prev[(size_t)b * e.A + a] : (T)0;
+    }
+    __syncthreads();
+  }
+  if (MODE == 0) {
+    for (int n = tid; n < N; n += nt) out[(size_t)b * N + n] = actuate_cell<T>(e, act, n);
+    return;
+  }
+  const int sp = e.n_species;
+  for (int i = tid; i < sp * N; i += nt) {
+    // y[sp, N] column-major: (species, cell) at cell*sp + species
+    const int n = i / sp, r = i - n * sp;
+    sy[r * N + n] = y[(size_t)b * sp * N + i];
+  }
+  if (sp == 1)
+    for (int n = tid; n < N; n += nt) sy[N + n] = 0;
+  __syncthreads();
+  sense_dots<T>(e, [&](int r, int n) { return sy[r * N + n]; }, dots, part, tid, nt);
+  if (MODE == 1) {
+    const size_t sw = e.mono ? (size_t)e.S : (size_t)e.A * e.ns;
+    featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, out + b * sw, tid, nt);
+  } else {
+    const int rw = e.mono ? 1 : e.A;
+    reward_traj<T>(e, dots, act, actp, out + (size_t)b * rw, tid, nt);
+  }
+}
+
+// ------------------------------------------------------------------ host side
+template <class T>
+static EnvDev<T> make_dev(const Env& E) {
+  const pdec_env_cfg& c = E.cfg;
+  EnvDev<T> e;
+  e.B = c.B; e.N = c.N; e.S = c.S; e.A = c.A; e.window = c.window; e.temporal = c.temporal_steps;
+  e.mono = c.mono; e.K = c.K; e.check_max = c.check_max_value; e.n_species = c.n_species;
+  e.ns = c.mono ? c.S : c.window * c.n_species * c.temporal_steps;
+  e.sensor_scale = (T)c.sensor_scale; e.agent_power = (T)c.agent_power;
+  e.r_in_scale = (T)c.reward_in_scale; e.r_offset = (T)c.reward_offset; e.r_power = (T)c.reward_power;
+  e.r_denom = (T)c.reward_denom; e.a_pun = (T)c.action_punish; e.da_pun = (T)c.delta_action_punish;
+  e.max_value = (T)c.max_value;
+  e.dx = (T)(c.Lx / c.N);
+  e.hstep = (T)(c.dt / c.K);
+  e.Gt = E.Gt.as<T>(); e.Ga = E.Ga.as<T>(); e.gsum = E.gsum.as<T>(); e.a2s = E.a2s.as<int>();
+  e.c1 = E.c1.as<T>(); e.c2 = E.c2.as<T>(); e.c3 = E.c3.as<T>(); e.c4 = E.c4.as<T>(); e.g = E.g.as<T>();
+  e.dhat = E.dhat.as<C2<T>>(); e.tw = E.tw.as<C2<T>>();
+  e.fft = E.fft;
+  return e;
+}
+
+static size_t ks_lds_bytes(const pdec_env_cfg& c) {
+  const size_t ts = dtype_size(c.dtype);
+  return 3 * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
+}
+static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
+  const size_t ts = dtype_size(c.dtype);
+  return (2 * ((size_t)c.N + 2) + 2 * c.A + 2 * c.S + 16 * c.S + 16) * ts;
+}
+static size_t sense_lds_bytes(const pdec_env_cfg& c) {
+  const size_t ts = dtype_size(c.dtype);
+  return (2 * (size_t)c.N + 2 * c.A + 2 * c.S + 16 * c.S) * ts;
+}
+
+template <class T>
+static int launch_step(Env& E, bool fused, int mode, const void* y_in, const void* p, const void* action,
+                       const void* action_prev, const void* state_prev, void* y_out, void* p_out,
+                       void* state_out, void* reward_out, int32_t* done) {
+  EnvDev<T> e = make_dev<T>(E);
+  const pdec_env_cfg& c = E.cfg;
+  if (c.pde_kind == PDEC_PDE_KS_CNAB2) {
+    dim3 grid((c.B + 1) / 2), block(E.nthreads);
+    ProfScope ps(&E, fused ? "ks_env_step" : "ks_pde_step");
+    if (fused)
+      hipLaunchKernelGGL((ks_env_step_kernel<T, true>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,
+                         (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,
+                         (T*)p_out, (T*)state_out, (T*)reward_out, done);
+    else
+      hipLaunchKernelGGL((ks_env_step_kernel<T, false>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,
+                         (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,
+                         (T*)p_out, (T*)state_out, (T*)reward_out, done);
+  } else if (c.pde_kind == PDEC_PDE_KSEG_RK4) {
+    dim3 grid(c.B), block(E.nthreads);
+    ProfScope ps(&E, mode == 0 ? "kseg_env_step" : (mode == 1 ? "kseg_pde_step" : "kseg_rhs"));
+#define KSEG_LAUNCH(M)                                                                                        \
+  hipLaunchKernelGGL((kseg_env_step_kernel<T, M>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,      \
+                     (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,   \
+                     (T*)p_out, (T*)state_out, (T*)reward_out, done)
+    if (mode == 0) KSEG_LAUNCH(0);
+    else if (mode == 1) KSEG_LAUNCH(1);
+    else KSEG_LAUNCH(2);
+#undef KSEG_LAUNCH
+  } else {
+    set_error("pde_kind %d not implemented", c.pde_kind);
+    return PDEC_E_INVALID;
+  }
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+template <class T>
+static int launch_sense(Env& E, int mode, const void* y, const void* action, const void* action_prev,
+                        const void* state_prev, void* out) {
+  EnvDev<T> e = make_dev<T>(E);
+  dim3 grid(E.cfg.B), block(128);
+  const size_t lds = sense_lds_bytes(E.cfg);
+  ProfScope ps(&E, mode == 0 ? "actuate" : (mode == 1 ? "featurize" : "reward"));
+#define SENSE_LAUNCH(M)                                                                                 \
+  hipLaunchKernelGGL((sense_kernel<T, M>), grid, block, lds, E.stream, e, (const T*)y, (const T*)action, \
+                     (const T*)action_prev, (const T*)state_prev, (T*)out)
+  if (mode == 0) SENSE_LAUNCH(0);
+  else if (mode == 1) SENSE_LAUNCH(1);
+  else SENSE_LAUNCH(2);
+#undef SENSE_LAUNCH
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+}  // namespace pdec
+
+using namespace pdec;
+
+extern "C" {
+
+int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* sensor_kernels,
+                    const double* actuator_kernels, const int32_t* a2s) {
+  PDEC_REQUIRE(h && cfg && sensor_kernels && actuator_kernels && a2s, "pdec_env_create: null argument");
+  const pdec_env_cfg& c = *cfg;
+  PDEC_REQUIRE(c.dtype == PDEC_F32 || c.dtype == PDEC_F64, "pdec_env_create: bad dtype %d", c.dtype);
+  PDEC_REQUIRE(c.B >= 1 && c.N >= 4 && c.S >= 1 && c.A >= 1 && c.K >= 1, "pdec_env_create: bad sizes B=%d N=%d S=%d A=%d K=%d",
+               c.B, c.N, c.S, c.A, c.K);
+  PDEC_REQUIRE(c.window >= 1 && (c.window & 1) && c.temporal_steps >= 1, "pdec_env_create: window must be odd >= 1");
+  PDEC_REQUIRE(c.window <= c.S || c.mono, "pdec_env_create: window %d larger than sensor count %d", c.window, c.S);
+  PDEC_REQUIRE(c.Lx > 0 && c.dt > 0, "pdec_env_create: Lx and dt must be positive");
+  for (int a = 0; a < c.A && !c.mono; ++a)
+    PDEC_REQUIRE(a2s[a] >= 0 && a2s[a] < c.S, "pdec_env_create: a2s[%d]=%d out of range", a, a2s[a]);
+  auto E = std::make_unique<Env>();
+  E->cfg = c;
+  const int N = c.N;
+  std::vector<int32_t> a2s_h(a2s, a2s + c.A);
+  if (c.mono)
+    for (int a = 0; a < c.A; ++a) PDEC_REQUIRE(a2s_h[a] >= 0 && a2s_h[a] < c.S, "pdec_env_create: a2s out of range");
+  if (c.pde_kind == PDEC_PDE_KS_CNAB2) {
+    PDEC_REQUIRE(c.n_species == 1, "KS has one species");
+    PDEC_REQUIRE(N % 2 == 0, "KS CNAB2 needs even N (Nyquist slot, KSSetup.jl:115)");
+    PDEC_REQUIRE(make_fft_plan(N, E->fft), "N=%d has a prime factor other than 2,3,5", N);
+    int nt = ((N + KS_MPT - 1) / KS_MPT + 63) / 64 * 64;
+    PDEC_REQUIRE(nt <= 1024, "N=%d too large for the in-LDS KS kernel (max 4096)", N);
+    E->nthreads = nt;
+    E->lds_bytes = ks_lds_bytes(c);
+    PDEC_REQUIRE(E->lds_bytes <= 160 * 1024, "KS kernel needs %zu B of LDS (> 160 KiB)", E->lds_bytes);
+    // per-mode constants, scripts/KS/setup/KSSetup.jl:115-123,131-135
+    std::vector<double> c1(N), c2(N), c3(N), c4(N), g(N), dh(2 * N), tw(2 * N), dist(N);
+    const double hh = c.dt / c.K, dt2 = hh / 2, dt32 = 3 * hh / 2, dx = c.Lx / N;
+    for (int k = 0; k < N; ++k) {
+      double kx = k < N / 2 ? k : (k == N / 2 ? 0 : k - N);
+      double al = 2 * M_PI * kx / c.Lx;
+      double L = al * al - al * al * al * al;
+      double Ainv = 1.0 / (1.0 - dt2 * L), Bc = 1.0 + dt2 * L;
+      c1[k] = Ainv * Bc; c2[k] = Ainv * dt32; c3[k] = Ainv * dt2; c4[k] = Ainv * hh; g[k] = -0.5 * al;
+      tw[2 * k] = cos(2 * M_PI * k / N);
+      tw[2 * k + 1] = -sin(2 * M_PI * k / N);
+      dist[k] = c.mu * cos(2 + M_PI + (dx * (k + 1)) / (c.Lx / 2));  // KSSetup.jl:155
+    }
+    for (int k = 0; k < N; ++k) {  // O(N^2) host DFT, setup time only
+      double re = 0, im = 0;
+      if (c.mu != 0.0)
+        for (int n = 0; n < N; ++n) {
+          long long ph = ((long long)k * n) % N;
+          re += dist[n] * tw[2 * ph];
+          im += dist[n] * tw[2 * ph + 1];
+        }
+      dh[2 * k] = hh * re;
+      dh[2 * k + 1] = hh * im;
+    }
+    int rc;
+    if ((rc = upload_converted(E->c1, c1.data(), N, c.dtype))) return rc;
+    if ((rc = upload_converted(E->c2, c2.data(), N, c.dtype))) return rc;
+    if ((rc = upload_converted(E->c3, c3.data(), N, c.dtype))) return rc;
+    if ((rc = upload_converted(E->c4, c4.data(), N, c.dtype))) return rc;
+    if ((rc = upload_converted(E->g, g.data(), N, c.dtype))) return rc;
+    if ((rc = upload_converted(E->dhat, dh.data(), 2 * N, c.dtype))) return rc;
+    if ((rc = upload_converted(E->tw, tw.data(), 2 * N, c.dtype))) return rc;
+  } else if (c.pde_kind == PDEC_PDE_KSEG_RK4) {
+    PDEC_REQUIRE(c.n_species == 2, "Keller-Segel has two species");
+    PDEC_REQUIRE(!c.mono, "Keller-Segel has no mono variant");
+    int nt = (N + 63) / 64 * 64;
+    PDEC_REQUIRE(nt <= 1024, "N=%d too large for the one-cell-per-thread K-S kernel (max 1024)", N);
+    E->nthreads = nt;
+    E->lds_bytes = kseg_lds_bytes(c);
+  } else {
+    set_error("pdec_env_create: pde_kind %d not implemented", c.pde_kind);
+    return PDEC_E_INVALID;
+  }
+  PDEC_REQUIRE(sense_lds_bytes(c) <= 160 * 1024, "sensor kernels need too much LDS");
+  // tables
+  std::vector<double> Gt((size_t)N * c.S), gs(c.S, 0.0);
+  for (int s = 0; s < c.S; ++s)
+    for (int n = 0; n < N; ++n) {
+      Gt[(size_t)n * c.S + s] = sensor_kernels[(size_t)s * N + n];
+      gs[s] += sensor_kernels[(size_t)s * N + n];
+    }
+  int rc;
+  if ((rc = upload_converted(E->Gt, Gt.data(), Gt.size(), c.dtype))) return rc;
+  if ((rc = upload_converted(E->gsum, gs.data(), gs.size(), c.dtype))) return rc;
+  if ((rc = upload_converted(E->Ga, actuator_kernels, (size_t)c.A * N, c.dtype))) return rc;
+  PDEC_HIP(E->a2s.alloc(sizeof(int32_t) * c.A));
+  PDEC_HIP(hipMemcpy(E->a2s.p, a2s_h.data(), sizeof(int32_t) * c.A, hipMemcpyHostToDevice));
+  *h = register_object(std::move(E));
+  return PDEC_OK;
+}
+
+#define GET_ENV(E, h)                              \
+  Env* E = lookup_as<Env>(h, Kind::Env);           \
+  if (!E) {                                        \
+    set_error("%s: not an env handle", __func__);  \
+    return PDEC_E_HANDLE;                          \
+  }
+
+int pdec_actuate(pdec_handle h, const void* action, void* p_out) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(action && p_out, "pdec_actuate: null");
+  return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 0, nullptr, action, nullptr, nullptr, p_out)
+                                  : launch_sense<float>(*E, 0, nullptr, action, nullptr, nullptr, p_out);
+}
+
+int pdec_featurize(pdec_handle h, const void* y, const void* prev_state, void* state_out) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(y && state_out, "pdec_featurize: null");
+  PDEC_REQUIRE(prev_state != state_out, "pdec_featurize: state_out must not alias prev_state");
+  return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 1, y, nullptr, nullptr, prev_state, state_out)
+                                  : launch_sense<float>(*E, 1, y, nullptr, nullptr, prev_state, state_out);
+}
+
+int pdec_reward(pdec_handle h, const void* y, const void* action, const void* action_prev, void* r_out) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(y && action && action_prev && r_out, "pdec_reward: null");
+  return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 2, y, action, action_prev, nullptr, r_out)
+                                  : launch_sense<float>(*E, 2, y, action, action_prev, nullptr, r_out);
+}
+
+int pdec_pde_step(pdec_handle h, const void* y_in, const void* p, void* y_out, int32_t* done) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(y_in && p && y_out, "pdec_pde_step: null");
+  return E->cfg.dtype == PDEC_F64
+             ? launch_step<double>(*E, false, 1, y_in, p, nullptr, nullptr, nullptr, y_out, nullptr, nullptr, nullptr, done)
+             : launch_step<float>(*E, false, 1, y_in, p, nullptr, nullptr, nullptr, y_out, nullptr, nullptr, nullptr, done);
+}
+
+int pdec_rhs_eval(pdec_handle h, const void* y, const void* p, void* out) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(y && p && out, "pdec_rhs_eval: null");
+  PDEC_REQUIRE(E->cfg.pde_kind == PDEC_PDE_KSEG_RK4, "pdec_rhs_eval: only RK4-type PDE kinds expose an RHS");
+  return E->cfg.dtype == PDEC_F64
+             ? launch_step<double>(*E, false, 2, y, p, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr)
+             : launch_step<float>(*E, false, 2, y, p, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr);
+}
+
+int pdec_env_step(pdec_handle h, const void* y_in, const void* action, const void* action_prev,
+                  const void* state_prev, void* y_out, void* p_out, void* state_out, void* reward_out,
+                  int32_t* done) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(y_in && action && action_prev && y_out && state_out && reward_out, "pdec_env_step: null");
+  PDEC_REQUIRE(!(E->cfg.temporal_steps > 1 && state_prev == state_out),
+               "pdec_env_step: state_out must not alias state_prev when temporal_steps > 1");
+  return E->cfg.dtype == PDEC_F64
+             ? launch_step<double>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done)
+             : launch_step<float>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
+}
+
+// ---- host-pointer wrappers: stage through one plan-owned device arena, synchronous
+static int env_stage(Env* E, size_t bytes) {
+  if (E->stage.bytes < bytes) PDEC_HIP(E->stage.alloc(bytes));
+  return PDEC_OK;
+}
+
+int pdec_pde_step_host(pdec_handle h, const void* y_in, const void* p, void* y_out, int32_t* done) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(y_in && p && y_out, "pdec_pde_step_host: null");
+  const pdec_env_cfg& c = E->cfg;
+  const size_t ts = dtype_size(c.dtype), ny = (size_t)c.B * c.n_species * c.N * ts, np = (size_t)c.B * c.N * ts;
+  int rc = env_stage(E, 2 * ny + np + c.B * sizeof(int32_t) + 64);
+  if (rc) return rc;
+  char* base = E->stage.as<char>();
+  char *dy = base, *dp = base + ny, *dyo = dp + np, *dd = dyo + ny;
+  PDEC_HIP(hipMemcpyAsync(dy, y_in, ny, hipMemcpyHostToDevice, E->stream));
+  PDEC_HIP(hipMemcpyAsync(dp, p, np, hipMemcpyHostToDevice, E->stream));
+  rc = pdec_pde_step(h, dy, dp, dyo, (int32_t*)dd);
+  if (rc) return rc;
+  PDEC_HIP(hipMemcpyAsync(y_out, dyo, ny, hipMemcpyDeviceToHost, E->stream));
+  if (done) PDEC_HIP(hipMemcpyAsync(done, dd, c.B * sizeof(int32_t), hipMemcpyDeviceToHost, E->stream));
+  PDEC_HIP(hipStreamSynchronize(E->stream));
+  return PDEC_OK;
+}
+
+int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, const void* action_prev,
+                       const void* state_prev, void* y_out, void* p_out, void* state_out, void* reward_out,
+                       int32_t* done) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(y_in && action && action_prev && y_out && state_out && reward_out, "pdec_env_step_host: null");
+  const pdec_env_cfg& c = E->cfg;
+  const size_t ts = dtype_size(c.dtype);
+  const int ns = c.mono ? c.S : c.window * c.n_species * c.temporal_steps;
+  const size_t ny = (size_t)c.B * c.n_species * c.N * ts, np = (size_t)c.B * c.N * ts, na = (size_t)c.B * c.A * ts;
+  const size_t nst = (size_t)c.B * (c.mono ? c.S : c.A * ns) * ts, nr = (size_t)c.B * (c.mono ? 1 : c.A) * ts;
+  auto al = [](size_t x) { return (x + 63) / 64 * 64; };
+  int rc = env_stage(E, 2 * al(ny) + al(np) + 2 * al(na) + 2 * al(nst) + al(nr) + al(c.B * sizeof(int32_t)));
+  if (rc) return rc;
+  char* q = E->stage.as<char>();
+  char* dy = q; q += al(ny);
+  char* dyo = q; q += al(ny);
+  char* dp = q; q += al(np);
+  char* da = q; q += al(na);
+  char* dap = q; q += al(na);
+  char* dsp = q; q += al(nst);
+  char* dso = q; q += al(nst);
+  char* dr = q; q += al(nr);
+  char* dd = q;
+  PDEC_HIP(hipMemcpyAsync(dy, y_in, ny, hipMemcpyHostToDevice, E->stream));
+  PDEC_HIP(hipMemcpyAsync(da, action, na, hipMemcpyHostToDevice, E->stream));
+  PDEC_HIP(hipMemcpyAsync(dap, action_prev, na, hipMemcpyHostToDevice, E->stream));
+  if (state_prev) PDEC_HIP(hipMemcpyAsync(dsp, state_prev, nst, hipMemcpyHostToDevice, E->stream));
+  rc = pdec_env_step(h, dy, da, dap, state_prev ? dsp : nullptr, dyo, dp, dso, dr, (int32_t*)dd);
+  if (rc) return rc;
+  PDEC_HIP(hipMemcpyAsync(y_out, dyo, ny, hipMemcpyDeviceToHost, E->stream));
+  if (p_out) PDEC_HIP(hipMemcpyAsync(p_out, dp, np, hipMemcpyDeviceToHost, E->stream));
+  PDEC_HIP(hipMemcpyAsync(state_out, dso, nst, hipMemcpyDeviceToHost, E->stream));
+  PDEC_HIP(hipMemcpyAsync(reward_out, dr, nr, hipMemcpyDeviceToHost, E->stream));
+  if (done) PDEC_HIP(hipMemcpyAsync(done, dd, c.B * sizeof(int32_t), hipMemcpyDeviceToHost, E->stream));
+  PDEC_HIP(hipStreamSynchronize(E->stream));
+  return PDEC_OK;
+}
+
+}  // extern "C"

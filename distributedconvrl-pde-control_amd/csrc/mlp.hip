@@ -1,0 +1,827 @@
+// mlp.hip -- weight-shared ("convolutional") actor/critic MLPs on gfx950: forward,
+// backward, Flux-ADAM, Polyak, policy act and the DDPG update.
+//
+// Restates (from scratch):
+//   create_NNA / Chain(Dense...)            src/PDEagent.jl:14-56
+//   CustomNeuralNetworkApproximator         src/custom_nna.jl:7-27
+//   (policy::CustomDDPGPolicy)(env)         src/PDEagent.jl:175-209
+//   RLBase.update!(policy, batch)           src/PDEagent.jl:363-418
+//
+// A Dense layer applied to the im2col state matrix [features, columns] is a 1-D/2-D
+// convolution with circular padding expressed as a GEMM over columns.  Activations are
+// kept feature-major H[f][col] (columns contiguous -> coalesced, one column per lane).
+// This file holds the GENERIC path (any widths, fp32 and fp64): LDS-tiled VALU GEMMs with
+// fused bias/activation and activation-derivative epilogues, split-K weight gradients with
+// a deterministic slab reduction (so data-parallel replicas stay bit-identical).  The
+// fp32 MFMA fast path for the wide critic lives in mlp_mfma.hip.
+#include "common.hpp"
+#include "mlp.hpp"
+
+namespace pdec {
+
+// ------------------------------------------------------------------ tiled GEMM
+#define GB_M 64
+#define GB_N 64
+#define GB_K 16
+
+enum { EPI_STORE = 0, EPI_BIAS_ACT = 1, EPI_MUL_DACT = 2 };
+
+template <class T>
+struct GemmArgs {
+  int M, N, K, kchunk;
+  const T* A; long sam, sak;
+  const T* B; long sbk, sbn;
+  T* C; long scm, scn, scz;       // scz: slab stride for split-K (blockIdx.z)
+  int epi, act;
+  const T* bias;                  // EPI_BIAS_ACT: bias[m]
+  const T* aux; long sauxm, sauxn;  // EPI_MUL_DACT: activation values at (m,n)
+};
+
+template <class T>
+__device__ __forceinline__ T apply_act(T z, int act) {
+  if (act == PDEC_ACT_RELU) return z > 0 ? z : (T)0;
+  if (act == PDEC_ACT_TANH) return (T)tanh((double)z);
+  return z;
+}
+template <>
+__device__ __forceinline__ float apply_act<float>(float z, int act) {
+  if (act == PDEC_ACT_RELU) return z > 0 ? z : 0.0f;
+  if (act == PDEC_ACT_TANH) return tanhf(z);
+  return z;
+}
+// derivative expressed through the activation VALUE a = act(z)
+template <class T>
+__device__ __forceinline__ T dact_from_value(T a, int act) {
+  if (act == PDEC_ACT_RELU) return a > 0 ? (T)1 : (T)0;
+  if (act == PDEC_ACT_TANH) return (T)1 - a * a;
+  return (T)1;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs<T> g) {
+  __shared__ T As[GB_K][GB_M + 1];
+  __shared__ T Bs[GB_K][GB_N + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+  const int kbeg = blockIdx.z * g.kchunk;
+  int kend = kbeg + g.kchunk;
+  if (kend > g.K) kend = g.K;
+  T acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      int m, k;
+      if (g.sak == 1) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k][m] = (gm < g.M && gk < kend) ? g.A[gm * g.sam + gk * g.sak] : (T)0;
+      int n, kb;
+      if (g.sbn == 1) { n = idx & 63; kb = idx >> 6; } else { kb = idx & 15; n = idx >> 4; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      Bs[kb][n] = (gn < g.N && gkb < kend) ? g.B[gkb * g.sbk + gn * g.sbn] : (T)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GB_K; ++k) {
+      T a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][ty + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+  T* C = g.C + (size_t)blockIdx.z * g.scz;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty + 16 * i;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx + 16 * j;
+      if (n >= g.N) continue;
+      T v = acc[i][j];
+      if (g.epi == EPI_BIAS_ACT) v = apply_act<T>(v + g.bias[m], g.act);
+      else if (g.epi == EPI_MUL_DACT) v *= dact_from_value<T>(g.aux[m * g.sauxm + n * g.sauxn], g.act);
+      C[m * g.scm + n * g.scn] = v;
+    }
+  }
+}
+
+// grad[i] = scale * sum_z slab[z][i]
+template <class T>
+__global__ void reduce_slabs_kernel(const T* __restrict__ slabs, T* __restrict__ grad, int n, int nz, size_t zstride,
+                                    T scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T acc = 0;
+  for (int z = 0; z < nz; ++z) acc += slabs[(size_t)z * zstride + i];
+  grad[i] = acc * scale;
+}
+
+// db[m] = scale * sum_c dz[m][c]   (one block per row)
+template <class T>
+__global__ void rowsum_kernel(const T* __restrict__ dz, T* __restrict__ db, int cols, T scale) {
+  __shared__ T red[256];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  T acc = 0;
+  for (int c = tid; c < cols; c += 256) acc += dz[(size_t)m * cols + c];
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) db[m] = red[0] * scale;
+}
+
+// X0[f][c] from up to two sources; layout flag 0: [cols][n] (Julia [n,cols]), 1: feature-major [n][cols]
+template <class T>
+__global__ void pack_kernel(T* __restrict__ X0, int cols, const T* __restrict__ s1, int n1, int l1,
+                            const T* __restrict__ s2, int n2, int l2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int f = 0; f < n1; ++f) X0[(size_t)f * cols + c] = l1 ? s1[(size_t)f * cols + c] : s1[(size_t)c * n1 + f];
+  for (int f = 0; f < n2; ++f)
+    X0[(size_t)(n1 + f) * cols + c] = l2 ? s2[(size_t)f * cols + c] : s2[(size_t)c * n2 + f];
+}
+
+// out[c][f] = H[f][c]
+template <class T>
+__global__ void unpack_kernel(const T* __restrict__ H, int cols, int n, T* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int f = 0; f < n; ++f) out[(size_t)c * n + f] = H[(size_t)f * cols + c];
+}
+
+// dz[f][c] = dy(f,c) * act'(a[f][c]); dy layout flag as in pack
+template <class T>
+__global__ void dz_init_kernel(T* __restrict__ dz, const T* __restrict__ dy, int ldy, const T* __restrict__ a,
+                               int n, int cols, int act) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int f = 0; f < n; ++f) {
+    const T d = ldy ? dy[(size_t)f * cols + c] : dy[(size_t)c * n + f];
+    dz[(size_t)f * cols + c] = d * dact_from_value<T>(a[(size_t)f * cols + c], act);
+  }
+}
+
+// Flux.Optimise.ADAM apply! + update!: arithmetic in Float64 (beta, eps, eta are Float64 in
+// Flux, so the broadcast promotes), stored back in T.
+template <class T>
+__global__ void adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, int n,
+                            double eta, double b1, double b2, double eps, double omb1p, double omb2p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double gi = (double)g[i];
+  const T mt = (T)(b1 * (double)m[i] + (1.0 - b1) * gi);
+  const T vt = (T)(b2 * (double)v[i] + (1.0 - b2) * gi * gi);
+  m[i] = mt;
+  v[i] = vt;
+  const T delta = (T)((double)mt / omb1p / (sqrt((double)vt / omb2p) + eps) * eta);
+  p[i] = p[i] - delta;
+}
+
+template <class T>
+__global__ void polyak_kernel(T* __restrict__ dst, const T* __restrict__ src, int n, T rho, T omr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = rho * dst[i] + omr * src[i];
+}
+
+template <class TD, class TS>
+__global__ void cast_copy_kernel(TD* __restrict__ dst, const TS* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (TD)src[i];
+}
+
+// actions[c][f] = clamp(H[f][c] + noise[c][f]*act_noise, +-lim)
+template <class T>
+__global__ void act_noise_clamp_kernel(const T* __restrict__ H, const T* __restrict__ noise, int cols, int n,
+                                       T act_noise, T lim, T* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  for (int f = 0; f < n; ++f) {
+    T v = H[(size_t)f * cols + c];
+    if (noise) v += noise[(size_t)c * n + f] * act_noise;
+    v = v < -lim ? -lim : (v > lim ? lim : v);
+    out[(size_t)c * n + f] = v;
+  }
+}
+
+// ---- counter-based normals: Philox4x32-10 + Box-Muller (replaces randn(rng), PDEagent.jl:201)
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+template <class T>
+__global__ void randn_kernel(T* __restrict__ dst, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // 4 normals per thread
+  if (q * 4 >= n) return;
+  const uint64_t ctr = offset + q;
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const double s = 1.0 / 4294967296.0;
+  for (int h = 0; h < 2; ++h) {
+    const double u1 = ((double)c[2 * h] + 0.5) * s, u2 = ((double)c[2 * h + 1] + 0.5) * s;
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+    const size_t i = q * 4 + 2 * h;
+    if (i < n) dst[i] = (T)(rad * cos(ang));
+    if (i + 1 < n) dst[i + 1] = (T)(rad * sin(ang));
+  }
+}
+
+// ---- DDPG loss statistics (single block; deterministic)
+// stats[0..4] = mean(c), mean(c^2), mean(r), mean(r^2), mean(q) with c_i = gamma(1-t_i)qt_i - q_i
+template <class T>
+__global__ void ddpg_stats_kernel(const T* __restrict__ q, const T* __restrict__ qt, const T* __restrict__ r,
+                                  const T* __restrict__ t, int n, T gamma, T* __restrict__ stats) {
+  __shared__ double red[5][256];
+  const int tid = threadIdx.x;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int i = tid; i < n; i += 256) {
+    const T qi = q[i];
+    a[4] += (double)qi;
+    if (qt) {
+      const T c = gamma * ((T)1 - t[i]) * qt[i] - qi;
+      a[0] += (double)c;
+      a[1] += (double)c * (double)c;
+      a[2] += (double)r[i];
+      a[3] += (double)r[i] * (double)r[i];
+    }
+  }
+  for (int k = 0; k < 5; ++k) red[k][tid] = a[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s)
+      for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + s];
+    __syncthreads();
+  }
+  if (tid < 5) stats[tid] = (T)(red[tid][0] / n);
+}
+
+// critic: dq_i = -(2/Bu)(rr + c_i) * scale with rr = mean(r) (quirk) or r_i; writes dz of the
+// (identity) output layer directly; loss -> *loss_out
+template <class T>
+__global__ void ddpg_critic_dq_kernel(const T* __restrict__ q, const T* __restrict__ qt, const T* __restrict__ r,
+                                      const T* __restrict__ t, int n, T gamma, int quirk, const T* __restrict__ stats,
+                                      T* __restrict__ dq, T* __restrict__ loss_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && loss_out) {
+    // quirk: mean_ij (r_j + c_i)^2 = mean(c^2) + 2 mean(c) mean(r) + mean(r^2)
+    *loss_out = quirk ? stats[1] + (T)2 * stats[0] * stats[2] + stats[3] : stats[5];
+  }
+  if (i >= n) return;
+  const T c = gamma * ((T)1 - t[i]) * qt[i] - q[i];
+  const T rr = quirk ? stats[2] : r[i];
+  dq[i] = -((T)2 / (T)n) * (rr + c);
+}
+// diagonal loss needs mean((r_i + c_i)^2): stats[5]
+template <class T>
+__global__ void ddpg_diag_loss_kernel(const T* __restrict__ q, const T* __restrict__ qt, const T* __restrict__ r,
+                                      const T* __restrict__ t, int n, T gamma, T* __restrict__ stats) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  double a = 0;
+  for (int i = tid; i < n; i += 256) {
+    const T e = r[i] + gamma * ((T)1 - t[i]) * qt[i] - q[i];
+    a += (double)e * (double)e;
+  }
+  red[tid] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) stats[5] = (T)(red[0] / n);
+}
+template <class T>
+__global__ void fill_kernel(T* __restrict__ p, int n, T v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+template <class T>
+__global__ void neg_copy_kernel(T* __restrict__ dst, const T* __restrict__ src) { *dst = -*src; }
+
+// ------------------------------------------------------------------ Mlp methods
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+template <class T>
+static int launch_gemm(Mlp& M, const char* label, GemmArgs<T> g, int nz) {
+  dim3 grid(cdiv(g.N, GB_N), cdiv(g.M, GB_M), nz), block(256);
+  ProfScope ps(&M, label);
+  hipLaunchKernelGGL((gemm_kernel<T>), grid, block, 0, M.stream, g);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int Mlp::init(int dtype_, int L_, const int32_t* dims_, const int32_t* acts_, int max_cols_) {
+  dtype = dtype_;
+  L = L_;
+  max_cols = max_cols_;
+  dims.assign(dims_, dims_ + L + 1);
+  acts.assign(acts_, acts_ + L);
+  w_off.resize(L);
+  b_off.resize(L);
+  size_t off = 0, maxw = 0;
+  int maxd = 0;
+  for (int l = 0; l < L; ++l) {
+    w_off[l] = off;
+    off += (size_t)dims[l] * dims[l + 1];
+    b_off[l] = off;
+    off += dims[l + 1];
+    maxw = std::max(maxw, (size_t)dims[l] * dims[l + 1]);
+  }
+  for (int l = 0; l <= L; ++l) maxd = std::max(maxd, dims[l]);
+  nparams = (int)off;
+  const size_t ts = dtype_size(dtype);
+  PDEC_HIP(params.alloc(off * ts));
+  PDEC_HIP(grads.alloc(off * ts));
+  PDEC_HIP(m.alloc(off * ts));
+  PDEC_HIP(v.alloc(off * ts));
+  PDEC_HIP(hipMemset(params.p, 0, off * ts));
+  PDEC_HIP(hipMemset(grads.p, 0, off * ts));
+  PDEC_HIP(hipMemset(m.p, 0, off * ts));
+  PDEC_HIP(hipMemset(v.p, 0, off * ts));
+  H.resize(L + 1);
+  for (int l = 0; l <= L; ++l) PDEC_HIP(H[l].alloc((size_t)dims[l] * max_cols * ts));
+  PDEC_HIP(dz[0].alloc((size_t)maxd * max_cols * ts));
+  PDEC_HIP(dz[1].alloc((size_t)maxd * max_cols * ts));
+  kchunk = 512;
+  nsplit_max = cdiv(max_cols, kchunk);
+  PDEC_HIP(slabs.alloc((size_t)nsplit_max * maxw * ts));
+  PDEC_HIP(dy.alloc((size_t)dims[L] * max_cols * ts));
+  PDEC_HIP(scratch.alloc(64 * 8));
+  bp[0] = bp[1] = -1.0;  // beta powers initialised on the first adam step (Flux: Float64[beta1, beta2])
+  return PDEC_OK;
+}
+
+template <class T>
+int Mlp::pack(const void* s1, int n1, int l1, const void* s2, int n2, int l2, int cols) {
+  PDEC_REQUIRE(n1 + n2 == dims[0], "mlp: input rows %d+%d != %d", n1, n2, dims[0]);
+  PDEC_REQUIRE(cols >= 1 && cols <= max_cols, "mlp: cols %d exceeds max_cols %d", cols, max_cols);
+  ProfScope ps(this, "mlp_pack");
+  hipLaunchKernelGGL((pack_kernel<T>), dim3(cdiv(cols, 256)), dim3(256), 0, stream, H[0].as<T>(), cols, (const T*)s1, n1, l1,
+                     (const T*)s2, n2, l2);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+template <class T>
+int Mlp::forward(int cols) {
+  for (int l = 0; l < L; ++l) {
+    GemmArgs<T> g{};
+    g.M = dims[l + 1]; g.N = cols; g.K = dims[l]; g.kchunk = g.K;
+    g.A = params.as<T>() + w_off[l]; g.sam = dims[l]; g.sak = 1;
+    g.B = H[l].as<T>(); g.sbk = cols; g.sbn = 1;
+    g.C = H[l + 1].as<T>(); g.scm = cols; g.scn = 1; g.scz = 0;
+    g.epi = EPI_BIAS_ACT; g.act = acts[l]; g.bias = params.as<T>() + b_off[l];
+    int rc = launch_gemm<T>(*this, "mlp_fwd_gemm", g, 1);
+    if (rc) return rc;
+  }
+  return PDEC_OK;
+}
+
+// dy: [out][cols] feature-major (ldy=1) or [cols][out] (ldy=0).  Leaves dX0 (w.r.t. the
+// packed input, feature-major [in][cols]) in dx_ptr() when want_dx.
+template <class T>
+int Mlp::backward(const void* dy, int ldy, int cols, bool want_dw, bool want_dx, double grad_scale) {
+  int cur = 0;
+  {
+    ProfScope ps(this, "mlp_dz_init");
+    hipLaunchKernelGGL((dz_init_kernel<T>), dim3(cdiv(cols, 256)), dim3(256), 0, stream, dz[cur].as<T>(), (const T*)dy, ldy,
+                       H[L].as<T>(), dims[L], cols, acts[L - 1]);
+    PDEC_HIP(hipGetLastError());
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const int out = dims[l + 1], in = dims[l];
+    if (want_dw) {
+      const int nz = cdiv(cols, kchunk);
+      GemmArgs<T> g{};
+      g.M = out; g.N = in; g.K = cols; g.kchunk = kchunk;
+      g.A = dz[cur].as<T>(); g.sam = cols; g.sak = 1;
+      g.B = H[l].as<T>(); g.sbk = 1; g.sbn = cols;
+      g.C = slabs.as<T>(); g.scm = in; g.scn = 1; g.scz = (long)out * in;
+      g.epi = EPI_STORE;
+      int rc = launch_gemm<T>(*this, "mlp_dw_gemm", g, nz);
+      if (rc) return rc;
+      ProfScope ps(this, "mlp_dw_reduce");
+      hipLaunchKernelGGL((reduce_slabs_kernel<T>), dim3(cdiv(out * in, 256)), dim3(256), 0, stream, slabs.as<T>(),
+                         grads.as<T>() + w_off[l], out * in, nz, (size_t)out * in, (T)grad_scale);
+      hipLaunchKernelGGL((rowsum_kernel<T>), dim3(out), dim3(256), 0, stream, dz[cur].as<T>(), grads.as<T>() + b_off[l], cols,
+                         (T)grad_scale);
+      PDEC_HIP(hipGetLastError());
+    }
+    if (l > 0 || want_dx) {
+      GemmArgs<T> g{};
+      g.M = in; g.N = cols; g.K = out; g.kchunk = out;
+      g.A = params.as<T>() + w_off[l]; g.sam = 1; g.sak = in;   // W^T
+      g.B = dz[cur].as<T>(); g.sbk = cols; g.sbn = 1;
+      g.C = dz[cur ^ 1].as<T>(); g.scm = cols; g.scn = 1; g.scz = 0;
+      if (l > 0) {
+        g.epi = EPI_MUL_DACT; g.act = acts[l - 1]; g.aux = H[l].as<T>(); g.sauxm = cols; g.sauxn = 1;
+      } else {
+        g.epi = EPI_STORE;
+      }
+      int rc = launch_gemm<T>(*this, "mlp_dx_gemm", g, 1);
+      if (rc) return rc;
+      cur ^= 1;
+    }
+  }
+  dx_index = cur;
+  return PDEC_OK;
+}
+
+}  // namespace pdec
+
+using namespace pdec;
+
+#define GET_MLP(M, h)                               \
+  Mlp* M = lookup_as<Mlp>(h, Kind::Mlp);            \
+  if (!M) {                                         \
+    set_error("%s: not an mlp handle", __func__);   \
+    return PDEC_E_HANDLE;                           \
+  }
+
+#define DISPATCH(M, expr_f, expr_d) ((M)->dtype == PDEC_F64 ? (expr_d) : (expr_f))
+
+// host conversion between the Julia layout (W column-major [out,in]) and the internal one
+template <class T>
+static void julia_to_internal(const Mlp& M, const T* src, T* dst) {
+  size_t so = 0;
+  for (int l = 0; l < M.L; ++l) {
+    const int in = M.dims[l], out = M.dims[l + 1];
+    for (int o = 0; o < out; ++o)
+      for (int i = 0; i < in; ++i) dst[M.w_off[l] + (size_t)o * in + i] = src[so + (size_t)i * out + o];
+    so += (size_t)in * out;
+    for (int o = 0; o < out; ++o) dst[M.b_off[l] + o] = src[so + o];
+    so += out;
+  }
+}
+template <class T>
+static void internal_to_julia(const Mlp& M, const T* src, T* dst) {
+  size_t so = 0;
+  for (int l = 0; l < M.L; ++l) {
+    const int in = M.dims[l], out = M.dims[l + 1];
+    for (int o = 0; o < out; ++o)
+      for (int i = 0; i < in; ++i) dst[so + (size_t)i * out + o] = src[M.w_off[l] + (size_t)o * in + i];
+    so += (size_t)in * out;
+    for (int o = 0; o < out; ++o) dst[so + o] = src[M.b_off[l] + o];
+    so += out;
+  }
+}
+
+static int set_flat(Mlp* M, DevBuf& buf, const void* host) {
+  const size_t ts = dtype_size(M->dtype), n = M->nparams;
+  std::vector<unsigned char> tmp(n * ts);
+  if (M->dtype == PDEC_F64) julia_to_internal<double>(*M, (const double*)host, (double*)tmp.data());
+  else julia_to_internal<float>(*M, (const float*)host, (float*)tmp.data());
+  PDEC_HIP(hipMemcpyAsync(buf.p, tmp.data(), n * ts, hipMemcpyHostToDevice, M->stream));
+  PDEC_HIP(hipStreamSynchronize(M->stream));
+  return PDEC_OK;
+}
+static int get_flat(Mlp* M, const DevBuf& buf, void* host) {
+  const size_t ts = dtype_size(M->dtype), n = M->nparams;
+  std::vector<unsigned char> tmp(n * ts);
+  PDEC_HIP(hipMemcpyAsync(tmp.data(), buf.p, n * ts, hipMemcpyDeviceToHost, M->stream));
+  PDEC_HIP(hipStreamSynchronize(M->stream));
+  if (M->dtype == PDEC_F64) internal_to_julia<double>(*M, (const double*)tmp.data(), (double*)host);
+  else internal_to_julia<float>(*M, (const float*)tmp.data(), (float*)host);
+  return PDEC_OK;
+}
+
+extern "C" {
+
+int pdec_mlp_create(pdec_handle* h, int dtype, int n_layers, const int32_t* dims, const int32_t* acts,
+                    const void* params_host, int max_cols) {
+  PDEC_REQUIRE(h && dims && acts, "pdec_mlp_create: null");
+  PDEC_REQUIRE(dtype == PDEC_F32 || dtype == PDEC_F64, "pdec_mlp_create: bad dtype");
+  PDEC_REQUIRE(n_layers >= 1 && n_layers <= 8, "pdec_mlp_create: n_layers %d out of [1,8]", n_layers);
+  PDEC_REQUIRE(max_cols >= 1, "pdec_mlp_create: max_cols must be >= 1");
+  for (int l = 0; l <= n_layers; ++l) PDEC_REQUIRE(dims[l] >= 1 && dims[l] <= 4096, "pdec_mlp_create: dims[%d]=%d", l, dims[l]);
+  for (int l = 0; l < n_layers; ++l) PDEC_REQUIRE(acts[l] >= 0 && acts[l] <= 2, "pdec_mlp_create: acts[%d]=%d", l, acts[l]);
+  auto M = std::make_unique<Mlp>();
+  int rc = M->init(dtype, n_layers, dims, acts, max_cols);
+  if (rc) return rc;
+  if (params_host && (rc = set_flat(M.get(), M->params, params_host))) return rc;
+  *h = register_object(std::move(M));
+  return PDEC_OK;
+}
+
+int pdec_mlp_num_params(pdec_handle h, int* n) {
+  GET_MLP(M, h);
+  PDEC_REQUIRE(n, "null");
+  *n = M->nparams;
+  return PDEC_OK;
+}
+
+int pdec_mlp_set_params(pdec_handle h, const void* params_host) {
+  GET_MLP(M, h);
+  PDEC_REQUIRE(params_host, "pdec_mlp_set_params: null");
+  return set_flat(M, M->params, params_host);
+}
+
+int pdec_mlp_get_params(pdec_handle h, void* params_host) {
+  GET_MLP(M, h);
+  PDEC_REQUIRE(params_host, "pdec_mlp_get_params: null");
+  return get_flat(M, M->params, params_host);
+}
+
+int pdec_mlp_copy(pdec_handle dst, pdec_handle src) {
+  GET_MLP(D, dst);
+  Mlp* S = lookup_as<Mlp>(src, Kind::Mlp);
+  if (!S) { set_error("pdec_mlp_copy: bad src"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(D->dims == S->dims, "pdec_mlp_copy: shape mismatch");
+  const int n = D->nparams;
+  dim3 grid(cdiv(n, 256)), block(256);
+  // order the copy after both handles' streams' prior work: use dst's stream after syncing src's
+  if (S->stream != D->stream) PDEC_HIP(hipStreamSynchronize(S->stream));
+  if (D->dtype == S->dtype) {
+    PDEC_HIP(hipMemcpyAsync(D->params.p, S->params.p, n * dtype_size(D->dtype), hipMemcpyDeviceToDevice, D->stream));
+  } else if (D->dtype == PDEC_F64) {
+    hipLaunchKernelGGL((cast_copy_kernel<double, float>), grid, block, 0, D->stream, D->params.as<double>(), S->params.as<float>(), n);
+  } else {
+    hipLaunchKernelGGL((cast_copy_kernel<float, double>), grid, block, 0, D->stream, D->params.as<float>(), S->params.as<double>(), n);
+  }
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int pdec_mlp_forward(pdec_handle h, const void* x, int cols, void* y_out) {
+  GET_MLP(M, h);
+  PDEC_REQUIRE(x && y_out, "pdec_mlp_forward: null");
+  int rc = DISPATCH(M, M->pack<float>(x, M->dims[0], 0, nullptr, 0, 0, cols), M->pack<double>(x, M->dims[0], 0, nullptr, 0, 0, cols));
+  if (rc) return rc;
+  rc = DISPATCH(M, M->forward<float>(cols), M->forward<double>(cols));
+  if (rc) return rc;
+  const int no = M->dims[M->L];
+  dim3 grid(cdiv(cols, 256)), block(256);
+  if (M->dtype == PDEC_F64)
+    hipLaunchKernelGGL((unpack_kernel<double>), grid, block, 0, M->stream, M->H[M->L].as<double>(), cols, no, (double*)y_out);
+  else
+    hipLaunchKernelGGL((unpack_kernel<float>), grid, block, 0, M->stream, M->H[M->L].as<float>(), cols, no, (float*)y_out);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int pdec_mlp_backward(pdec_handle h, const void* x, const void* dy, int cols, void* dx_out, void* grads_out) {
+  GET_MLP(M, h);
+  PDEC_REQUIRE(x && dy, "pdec_mlp_backward: null");
+  int rc = DISPATCH(M, M->pack<float>(x, M->dims[0], 0, nullptr, 0, 0, cols), M->pack<double>(x, M->dims[0], 0, nullptr, 0, 0, cols));
+  if (rc) return rc;
+  rc = DISPATCH(M, M->forward<float>(cols), M->forward<double>(cols));
+  if (rc) return rc;
+  rc = DISPATCH(M, M->backward<float>(dy, 0, cols, true, dx_out != nullptr, 1.0),
+                M->backward<double>(dy, 0, cols, true, dx_out != nullptr, 1.0));
+  if (rc) return rc;
+  dim3 grid(cdiv(cols, 256)), block(256);
+  if (dx_out) {
+    if (M->dtype == PDEC_F64)
+      hipLaunchKernelGGL((unpack_kernel<double>), grid, block, 0, M->stream, M->dz[M->dx_index].as<double>(), cols, M->dims[0], (double*)dx_out);
+    else
+      hipLaunchKernelGGL((unpack_kernel<float>), grid, block, 0, M->stream, M->dz[M->dx_index].as<float>(), cols, M->dims[0], (float*)dx_out);
+    PDEC_HIP(hipGetLastError());
+  }
+  if (grads_out) {
+    // grads_out is a DEVICE buffer in the Julia layout: convert through the host (setup/test path)
+    const size_t ts = dtype_size(M->dtype);
+    std::vector<unsigned char> tmp((size_t)M->nparams * ts);
+    rc = get_flat(M, M->grads, tmp.data());
+    if (rc) return rc;
+    PDEC_HIP(hipMemcpy(grads_out, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+  }
+  return PDEC_OK;
+}
+
+int pdec_mlp_grad_buffer(pdec_handle h, void** dptr, int* n) {
+  GET_MLP(M, h);
+  PDEC_REQUIRE(dptr && n, "null");
+  *dptr = M->grads.p;
+  *n = M->nparams;
+  return PDEC_OK;
+}
+
+int pdec_adam_step(pdec_handle h, double eta, double beta1, double beta2, double eps) {
+  GET_MLP(M, h);
+  if (M->bp[0] < 0) { M->bp[0] = beta1; M->bp[1] = beta2; }
+  const int n = M->nparams;
+  dim3 grid(cdiv(n, 256)), block(256);
+  {
+    ProfScope ps(M, "adam");
+    if (M->dtype == PDEC_F64)
+      hipLaunchKernelGGL((adam_kernel<double>), grid, block, 0, M->stream, M->params.as<double>(), M->grads.as<double>(),
+                         M->m.as<double>(), M->v.as<double>(), n, eta, beta1, beta2, eps, 1.0 - M->bp[0], 1.0 - M->bp[1]);
+    else
+      hipLaunchKernelGGL((adam_kernel<float>), grid, block, 0, M->stream, M->params.as<float>(), M->grads.as<float>(),
+                         M->m.as<float>(), M->v.as<float>(), n, eta, beta1, beta2, eps, 1.0 - M->bp[0], 1.0 - M->bp[1]);
+  }
+  PDEC_HIP(hipGetLastError());
+  M->bp[0] *= beta1;
+  M->bp[1] *= beta2;
+  return PDEC_OK;
+}
+
+int pdec_adam_get_state(pdec_handle h, void* m_host, void* v_host, double* beta_pow2) {
+  GET_MLP(M, h);
+  int rc;
+  if (m_host && (rc = get_flat(M, M->m, m_host))) return rc;
+  if (v_host && (rc = get_flat(M, M->v, v_host))) return rc;
+  if (beta_pow2) { beta_pow2[0] = M->bp[0]; beta_pow2[1] = M->bp[1]; }
+  return PDEC_OK;
+}
+
+int pdec_adam_set_state(pdec_handle h, const void* m_host, const void* v_host, const double* beta_pow2) {
+  GET_MLP(M, h);
+  int rc;
+  if (m_host && (rc = set_flat(M, M->m, m_host))) return rc;
+  if (v_host && (rc = set_flat(M, M->v, v_host))) return rc;
+  if (beta_pow2) { M->bp[0] = beta_pow2[0]; M->bp[1] = beta_pow2[1]; }
+  return PDEC_OK;
+}
+
+int pdec_polyak(pdec_handle dst, pdec_handle src, double rho) {
+  GET_MLP(D, dst);
+  Mlp* S = lookup_as<Mlp>(src, Kind::Mlp);
+  if (!S) { set_error("pdec_polyak: bad src"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(D->dims == S->dims && D->dtype == S->dtype, "pdec_polyak: shape/dtype mismatch");
+  const int n = D->nparams;
+  dim3 grid(cdiv(n, 256)), block(256);
+  ProfScope ps(D, "polyak");
+  const float r = (float)rho;  // the reference holds p = 0.995f0 and computes (1 - p) in Float32
+  if (D->dtype == PDEC_F64) {
+    hipLaunchKernelGGL((polyak_kernel<double>), grid, block, 0, D->stream, D->params.as<double>(), S->params.as<double>(), n,
+                       (double)r, (double)(1.0f - r));
+  } else {
+    hipLaunchKernelGGL((polyak_kernel<float>), grid, block, 0, D->stream, D->params.as<float>(), S->params.as<float>(), n, r, 1.0f - r);
+  }
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int pdec_policy_act(pdec_handle actor, const void* state, const void* noise, int cols, double act_noise,
+                    double act_limit, void* actions_out) {
+  GET_MLP(M, actor);
+  PDEC_REQUIRE(state && actions_out, "pdec_policy_act: null");
+  int rc = DISPATCH(M, M->pack<float>(state, M->dims[0], 0, nullptr, 0, 0, cols), M->pack<double>(state, M->dims[0], 0, nullptr, 0, 0, cols));
+  if (rc) return rc;
+  rc = DISPATCH(M, M->forward<float>(cols), M->forward<double>(cols));
+  if (rc) return rc;
+  const int no = M->dims[M->L];
+  dim3 grid(cdiv(cols, 256)), block(256);
+  ProfScope ps(M, "act_noise_clamp");
+  if (M->dtype == PDEC_F64)
+    hipLaunchKernelGGL((act_noise_clamp_kernel<double>), grid, block, 0, M->stream, M->H[M->L].as<double>(), (const double*)noise,
+                       cols, no, act_noise, act_limit, (double*)actions_out);
+  else
+    hipLaunchKernelGGL((act_noise_clamp_kernel<float>), grid, block, 0, M->stream, M->H[M->L].as<float>(), (const float*)noise, cols,
+                       no, (float)act_noise, (float)act_limit, (float*)actions_out);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int pdec_randn(pdec_handle any_handle, void* dst, size_t n, int dtype, uint64_t seed, uint64_t offset) {
+  Object* o = lookup(any_handle);
+  if (!o) { set_error("pdec_randn: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(dst, "pdec_randn: null");
+  if (n == 0) return PDEC_OK;
+  dim3 grid(cdiv((long)((n + 3) / 4), 256)), block(256);
+  if (dtype == PDEC_F64) hipLaunchKernelGGL((randn_kernel<double>), grid, block, 0, o->stream, (double*)dst, n, seed, offset);
+  else hipLaunchKernelGGL((randn_kernel<float>), grid, block, 0, o->stream, (float*)dst, n, seed, offset);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ DDPG
+template <class T>
+static int critic_grads_t(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
+                          const void* snext, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev) {
+  const int ns = At->dims[0], na = At->dims[At->L];
+  PDEC_REQUIRE(C->dims[0] == ns + na && Ct->dims[0] == ns + na && C->dims[C->L] == 1 && Ct->dims[Ct->L] == 1,
+               "ddpg: critic must map ns+na -> 1");
+  int rc;
+  // a' = At(s')                                              src/PDEagent.jl:385
+  if ((rc = At->pack<T>(snext, ns, 0, nullptr, 0, 0, Bu))) return rc;
+  if ((rc = At->forward<T>(Bu))) return rc;
+  // qt = Ct(vcat(s', a'))                                    :386
+  if (At->stream != Ct->stream) PDEC_HIP(hipStreamSynchronize(At->stream));
+  if ((rc = Ct->pack<T>(snext, ns, 0, At->H[At->L].p, na, 1, Bu))) return rc;
+  if ((rc = Ct->forward<T>(Bu))) return rc;
+  // q = C(vcat(s, a))                                        :392
+  if (Ct->stream != C->stream) PDEC_HIP(hipStreamSynchronize(Ct->stream));
+  if ((rc = C->pack<T>(s, ns, 0, a, na, 0, Bu))) return rc;
+  if ((rc = C->forward<T>(Bu))) return rc;
+  T* stats = C->scratch.as<T>();
+  const T* q = C->H[C->L].as<T>();
+  const T* qt = Ct->H[Ct->L].as<T>();
+  // gamma is Float32 in the reference (y = 0.99f0, KSSetup.jl:64)
+  const T gm = (T)(float)gamma;
+  {
+    ProfScope ps(C, "ddpg_loss");
+    hipLaunchKernelGGL((ddpg_stats_kernel<T>), dim3(1), dim3(256), 0, C->stream, q, qt, (const T*)r, (const T*)t, Bu, gm, stats);
+    if (!quirk)
+      hipLaunchKernelGGL((ddpg_diag_loss_kernel<T>), dim3(1), dim3(256), 0, C->stream, q, qt, (const T*)r, (const T*)t, Bu, gm, stats);
+    // dq goes straight into dz of the identity output layer (feature-major [1][Bu])
+    hipLaunchKernelGGL((ddpg_critic_dq_kernel<T>), dim3(cdiv(Bu, 256)), dim3(256), 0, C->stream, q, qt, (const T*)r, (const T*)t, Bu,
+                       gm, quirk, stats, C->dy_buf<T>(Bu), (T*)loss_dev);
+    PDEC_HIP(hipGetLastError());
+  }
+  return C->backward<T>(C->dy_buf<T>(Bu), 1, Bu, true, false, grad_scale);
+}
+
+template <class T>
+static int actor_grads_t(Mlp* A, Mlp* C, const void* s, int Bu, double grad_scale, void* loss_dev) {
+  const int ns = A->dims[0], na = A->dims[A->L];
+  int rc;
+  if ((rc = A->pack<T>(s, ns, 0, nullptr, 0, 0, Bu))) return rc;
+  if ((rc = A->forward<T>(Bu))) return rc;
+  if (A->stream != C->stream) PDEC_HIP(hipStreamSynchronize(A->stream));
+  if ((rc = C->pack<T>(s, ns, 0, A->H[A->L].p, na, 1, Bu))) return rc;
+  if ((rc = C->forward<T>(Bu))) return rc;
+  T* stats = C->scratch.as<T>();
+  {
+    ProfScope ps(C, "ddpg_loss");
+    hipLaunchKernelGGL((ddpg_stats_kernel<T>), dim3(1), dim3(256), 0, C->stream, C->H[C->L].as<T>(), (const T*)nullptr,
+                       (const T*)nullptr, (const T*)nullptr, Bu, (T)0, stats);
+    if (loss_dev) hipLaunchKernelGGL((neg_copy_kernel<T>), dim3(1), dim3(1), 0, C->stream, (T*)loss_dev, stats + 4);
+    hipLaunchKernelGGL((fill_kernel<T>), dim3(cdiv(Bu, 256)), dim3(256), 0, C->stream, C->dy_buf<T>(Bu), Bu, (T)(-1.0 / Bu));
+    PDEC_HIP(hipGetLastError());
+  }
+  // d(-mean q)/d[s;a] through the critic, no critic weight gradients   :402-409
+  if ((rc = C->backward<T>(C->dy_buf<T>(Bu), 1, Bu, false, true, 1.0))) return rc;
+  if (A->stream != C->stream) PDEC_HIP(hipStreamSynchronize(C->stream));
+  const T* dA = C->dz[C->dx_index].as<T>() + (size_t)ns * Bu;  // rows ns.. of dX0 = gradient w.r.t. A(s)
+  return A->backward<T>(dA, 1, Bu, true, false, grad_scale);
+}
+
+extern "C" {
+
+int pdec_ddpg_critic_grads(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* s,
+                           const void* a, const void* r, const void* t, const void* snext, int Bu, double gamma,
+                           int quirk, double grad_scale, void* critic_loss_dev) {
+  GET_MLP(A, hA);
+  GET_MLP(C, hC);
+  GET_MLP(At, hAt);
+  GET_MLP(Ct, hCt);
+  PDEC_REQUIRE(s && a && r && t && snext && Bu >= 1, "pdec_ddpg_critic_grads: null/empty batch");
+  PDEC_REQUIRE(A->dtype == C->dtype && At->dtype == C->dtype && Ct->dtype == C->dtype, "ddpg: dtype mismatch");
+  return C->dtype == PDEC_F64
+             ? critic_grads_t<double>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev)
+             : critic_grads_t<float>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev);
+}
+
+int pdec_ddpg_actor_grads(pdec_handle hA, pdec_handle hC, const void* s, int Bu, double grad_scale, void* actor_loss_dev) {
+  GET_MLP(A, hA);
+  GET_MLP(C, hC);
+  PDEC_REQUIRE(s && Bu >= 1, "pdec_ddpg_actor_grads: null/empty batch");
+  PDEC_REQUIRE(A->dtype == C->dtype, "ddpg: dtype mismatch");
+  return C->dtype == PDEC_F64 ? actor_grads_t<double>(A, C, s, Bu, grad_scale, actor_loss_dev)
+                              : actor_grads_t<float>(A, C, s, Bu, grad_scale, actor_loss_dev);
+}
+
+int pdec_ddpg_update(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* s, const void* a,
+                     const void* r, const void* t, const void* snext, int Bu, double gamma, double rho, int quirk,
+                     double eta_actor, double eta_critic, double* actor_loss, double* critic_loss) {
+  GET_MLP(C, hC);
+  GET_MLP(A, hA);
+  const size_t ts = dtype_size(C->dtype);
+  char* losses = C->scratch.as<char>() + 16 * ts;  // two device scalars behind the stats
+  int rc = pdec_ddpg_critic_grads(hA, hC, hAt, hCt, s, a, r, t, snext, Bu, gamma, quirk, 1.0, losses);
+  if (rc) return rc;
+  if ((rc = pdec_adam_step(hC, eta_critic, 0.9, 0.999, 1e-8))) return rc;           // :400
+  if ((rc = pdec_ddpg_actor_grads(hA, hC, s, Bu, 1.0, losses + ts))) return rc;
+  if (A->stream != C->stream) PDEC_HIP(hipStreamSynchronize(C->stream));
+  if ((rc = pdec_adam_step(hA, eta_actor, 0.9, 0.999, 1e-8))) return rc;            // :412
+  if ((rc = pdec_polyak(hAt, hA, rho))) return rc;                                  // :415-417
+  if ((rc = pdec_polyak(hCt, hC, rho))) return rc;
+  if (actor_loss || critic_loss) {
+    unsigned char buf[16];
+    PDEC_HIP(hipStreamSynchronize(A->stream));
+    PDEC_HIP(hipMemcpyAsync(buf, losses, 2 * ts, hipMemcpyDeviceToHost, C->stream));
+    PDEC_HIP(hipStreamSynchronize(C->stream));
+    if (C->dtype == PDEC_F64) {
+      if (critic_loss) *critic_loss = ((double*)buf)[0];
+      if (actor_loss) *actor_loss = ((double*)buf)[1];
+    } else {
+      if (critic_loss) *critic_loss = ((float*)buf)[0];
+      if (actor_loss) *actor_loss = ((float*)buf)[1];
+    }
+  }
+  return PDEC_OK;
+}
+
+}  // extern "C"

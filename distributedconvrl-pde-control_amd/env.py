@@ -1,0 +1,195 @@
+"""PDEenv -- batched, device-resident mirror of the reference's `PDEenv` (src/PDEenv.jl:26-241).
+
+Same field names and step semantics; the build's addition is the leading batch dimension B
+(the reference has B = 1).  Tensors are torch CUDA tensors whose MEMORY matches
+`[B][Julia column-major array]`, i.e. shapes are the Julia shapes reversed behind B:
+    y      [B, nx]  (KS)   or [B, nx, 2]  (Keller-Segel; Julia y[2, nx])
+    state  [B, A, ns]      (Julia state[ns, A])
+    action [B, A, 1]       (Julia action[1, A])
+    reward [B, A]  (mono: [B, 1]),  p [B, nx],  done [B] bool
+`*_julia()` helpers return numpy copies in the Julia shapes for B = 1 (what PDEhook logs).
+The whole `(env)(action)` body -- delta_action, prepare_action, integrator, reward, featurize,
+blow-up test (src/PDEenv.jl:195-241) -- is ONE HIP launch (pdec_env_step)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return C.c_void_p(stream.cuda_stream)
+
+
+class PDEenv:
+    def __init__(self, setup, B=1, dtype=torch.float32, device="cuda:0", y0=None, action0=None, stream=None):
+        self.setup = setup
+        self.B = int(B)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PdecError("PDEenv runs on the GPU only (no CPU fallback); pass device='cuda:N'")
+        self.lib = _lib.init(self.device.index or 0)
+        self.te, self.t0, self.dt = setup.te, setup.t0, setup.dt
+        self.oversampling = setup.oversampling
+        self.max_value, self.check_max_value = setup.max_value, setup.check_max_value
+        cfg = setup.env_cfg(self.B, _lib.dtype_code(dtype))
+        G, Ga, a2s = setup.tables()
+        self._h = _lib.Handle()
+        _lib.check(self.lib.pdec_env_create(
+            C.byref(self._h), C.byref(cfg), G.ctypes.data_as(C.POINTER(C.c_double)),
+            Ga.ctypes.data_as(C.POINTER(C.c_double)), a2s.ctypes.data_as(C.POINTER(C.c_int32))))
+        self.stream = stream
+        if stream is not None:
+            _lib.check(self.lib.pdec_set_stream(self._h, _stream_ptr(stream)))
+        ns, A = setup.state_shape
+        self._yshape = (self.B,) + tuple(reversed(setup.y_shape))
+        self._sshape = (self.B, A, ns)
+        self._ashape = (self.B,) + tuple(reversed(setup.action_shape))
+        kw = dict(dtype=dtype, device=self.device)
+        if y0 is None:
+            y0 = np.broadcast_to(self._to_mem(setup.y0_standard()), self._yshape[1:])
+        self.y0 = self._as_batch(y0, self._yshape)
+        self.action0 = (torch.zeros(self._ashape, **kw) if action0 is None else self._as_batch(action0, self._ashape))
+        self.y = self.y0.clone()
+        self._y_next = torch.empty_like(self.y)
+        self.state = torch.empty(self._sshape, **kw)
+        self._state_next = torch.empty_like(self.state)
+        self.action = self.action0.clone()
+        self._action_prev = self.action0.clone()
+        self.p = torch.zeros((self.B, setup.nx), **kw)
+        self.reward = torch.zeros((self.B, setup.reward_len), **kw)
+        self._done_flags = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.done = torch.zeros(self.B, dtype=torch.bool, device=self.device)
+        self.steps, self.time = 0, 0.0
+        self.reset()
+
+    # ---- helpers
+    def _to_mem(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        return a.T if a.ndim == 2 else a
+
+    def _as_batch(self, a, shape):
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=self.dtype)
+        else:
+            t = torch.as_tensor(np.array(a, copy=True), dtype=self.dtype, device=self.device)
+        if t.dim() == len(shape) - 1:
+            t = t.unsqueeze(0).expand(shape)
+        if tuple(t.shape) != tuple(shape):
+            raise _lib.PdecError(f"expected shape {shape} (or without the batch axis), got {tuple(t.shape)}")
+        return t.contiguous().clone()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def delta_action(self):
+        return self.action - self._action_prev
+
+    # ---- RLBase surface (src/PDEenv.jl:172-181)
+    def state_space_size(self):
+        return self.setup.state_shape
+
+    def action_space_size(self):
+        return self.setup.action_shape
+
+    def is_terminated(self):
+        """Episode end.  Time-out is common to the lock-stepped batch; a blown-up trajectory
+        (done[b]) ends the episode only when B == 1 (the reference's case)."""
+        if self.time >= self.te:
+            return True
+        return bool(self.done.all().item()) if self.B > 1 else bool(self.done[0].item())
+
+    # ---- stand-alone closures (each one launch)
+    def featurize(self, y=None, prev_state=None):
+        y = self.y if y is None else y
+        out = torch.empty(self._sshape, dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(y), _lib.ptr(prev_state), _lib.ptr(out)))
+        return out
+
+    def prepare_action(self, action=None):
+        action = self.action if action is None else action
+        out = torch.empty((self.B, self.setup.nx), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.pdec_actuate(self._h, _lib.ptr(action), _lib.ptr(out)))
+        return out
+
+    def reward_function(self, y=None, action=None, action_prev=None):
+        y = self.y if y is None else y
+        action = self.action if action is None else action
+        action_prev = self._action_prev if action_prev is None else action_prev
+        out = torch.empty((self.B, self.setup.reward_len), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.pdec_reward(self._h, _lib.ptr(y), _lib.ptr(action), _lib.ptr(action_prev), _lib.ptr(out)))
+        return out
+
+    def do_step(self, y=None, p=None):
+        """do_step(env): integrator only (KSSetup.jl:130-160 / KellerSegelSetup.jl:234-239)"""
+        y = self.y if y is None else y
+        p = self.p if p is None else p
+        out = torch.empty_like(y)
+        flags = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pdec_pde_step(self._h, _lib.ptr(y), _lib.ptr(p), _lib.ptr(out), _lib.ptr(flags)))
+        return out, flags
+
+    def rhs(self, y, p):
+        out = torch.empty_like(y)
+        _lib.check(self.lib.pdec_rhs_eval(self._h, _lib.ptr(y), _lib.ptr(p), _lib.ptr(out)))
+        return out
+
+    # ---- reset!(env), src/PDEenv.jl:183-193
+    def reset(self):
+        self.y.copy_(self.y0)
+        self.state = self.featurize(self.y, None)
+        self._state_next = torch.empty_like(self.state)
+        self.action.copy_(self.action0)
+        self._action_prev.copy_(self.action0)
+        self.p = self.prepare_action(self.action0)
+        self.steps, self.time = 0, 0.0
+        self.reward.zero_()
+        self.done.zero_()
+
+    # ---- (env::PDEenv)(action), src/PDEenv.jl:195-241
+    def __call__(self, action):
+        if action.dtype != self.dtype or not action.is_contiguous() or tuple(action.shape) != self._ashape:
+            action = action.to(self.dtype).reshape(self._ashape).contiguous()
+        self._action_prev, self.action = self.action, self._action_prev
+        self.action.copy_(action)
+        _lib.check(self.lib.pdec_env_step(
+            self._h, _lib.ptr(self.y), _lib.ptr(self.action), _lib.ptr(self._action_prev), _lib.ptr(self.state),
+            _lib.ptr(self._y_next), _lib.ptr(self.p), _lib.ptr(self._state_next), _lib.ptr(self.reward),
+            _lib.ptr(self._done_flags)))
+        self.y, self._y_next = self._y_next, self.y
+        self.state, self._state_next = self._state_next, self.state
+        self.steps += 1
+        self.time += self.dt
+        if self.time >= self.te:
+            self.done.fill_(True)
+        else:
+            torch.ne(self._done_flags, 0, out=self.done)
+
+    # ---- Julia-shaped host views for B == 1 (what PDEhook logs, src/PDEhook.jl:54-62)
+    def y_julia(self, b=0):
+        a = self.y[b].detach().cpu().numpy().astype(np.float64)
+        return a.T if a.ndim == 2 else a
+
+    def state_julia(self, b=0):
+        return self.state[b].detach().cpu().numpy().astype(np.float64).T
+
+    def action_julia(self, b=0):
+        a = self.action[b].detach().cpu().numpy().astype(np.float64)
+        return a.T if a.ndim == 2 else a
+
+    def close(self):
+        if self._h is not None:
+            self.lib.pdec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

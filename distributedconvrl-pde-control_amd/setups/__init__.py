@@ -1,0 +1,2 @@
+from .ks import KSSetup  # noqa: F401
+from .keller_segel import KellerSegelSetup  # noqa: F401

@@ -1,0 +1,106 @@
+"""Keller-Segel experiment configuration: scripts/Keller-Segel/setup/KellerSegelSetup.jl:26-84
+and Keller-Segel10_16.jl:8-14 turned into libpdeconv tables (setup-time host code)."""
+import numpy as np
+
+from .. import _lib
+
+
+def prepare_rectangles(nx, positions, half_window_size=2):
+    """KellerSegelSetup.jl:112-126"""
+    out = np.zeros((len(positions), nx))
+    for i, position in enumerate(positions):
+        out[i, position - half_window_size - 1: position + half_window_size] = 1.0
+    return out
+
+
+class KellerSegelSetup:
+    def __init__(self, nx=100, Lx=10.0, sensor_positions=None, actuators_to_sensors=None, te=8.0, t0=0.0,
+                 dt=0.006, substeps=32, max_value=20.0, check_max_value="y", agent_power=10.0,
+                 action_punish=0.0, delta_action_punish=0.0, window_size=3, temporal_steps=2,
+                 nna_scale=2.0, nna_scale_critic=17.0, drop_middle_layer=True, gamma=0.99, rho=0.995,
+                 batch_size=3, start_steps=-1, update_after=1, update_freq=1, update_loops=20,
+                 learning_rate=0.0005, learning_rate_critic=0.001, act_limit=1.0, act_noise=1.2,
+                 trajectory_length=100_000):
+        self.nx, self.Lx = int(nx), float(Lx)
+        self.dx = self.Lx / self.nx
+        self.sensor_positions = (np.arange(3, nx + 1, 5) if sensor_positions is None
+                                 else np.asarray(sensor_positions, dtype=np.int64))
+        self.actuators_to_sensors = (np.arange(3, 19) if actuators_to_sensors is None
+                                     else np.asarray(actuators_to_sensors, dtype=np.int64))
+        self.actuator_positions = self.sensor_positions[self.actuators_to_sensors - 1]
+        self.te, self.t0, self.dt = te, t0, dt
+        # the reference integrates adaptively (OrdinaryDiffEq RK4(), tol 1e-8, :234-239); the
+        # fixed-step equivalent needs 32 sub-steps to reach that tolerance
+        self.oversampling = int(substeps)
+        self.max_value, self.check_max_value, self.agent_power = max_value, check_max_value, agent_power
+        self.action_punish, self.delta_action_punish = action_punish, delta_action_punish
+        self.window_size, self.temporal_steps, self.memory_size, self.mono, self.n_species = \
+            window_size, temporal_steps, 0, False, 2
+        self.nna_scale, self.nna_scale_critic, self.drop_middle_layer = nna_scale, nna_scale_critic, drop_middle_layer
+        self.gamma, self.rho, self.batch_size = gamma, rho, batch_size
+        self.start_steps, self.update_after, self.update_freq, self.update_loops = \
+            start_steps, update_after, update_freq, update_loops
+        self.learning_rate, self.learning_rate_critic = learning_rate, learning_rate_critic
+        self.act_limit, self.act_noise, self.trajectory_length = act_limit, act_noise, trajectory_length
+        self.gaussians = prepare_rectangles(self.nx, self.sensor_positions, 2)          # :128
+        self.gaussians_actuators = self.gaussians[self.actuators_to_sensors - 1]         # :129
+
+    @property
+    def n_actuators(self):
+        return len(self.actuator_positions)
+
+    @property
+    def n_sensors(self):
+        return len(self.sensor_positions)
+
+    @property
+    def state_shape(self):
+        return (self.window_size * 2 * self.temporal_steps, self.n_actuators)
+
+    @property
+    def action_shape(self):
+        return (1, self.n_actuators)
+
+    @property
+    def reward_len(self):
+        return self.n_actuators
+
+    @property
+    def y_shape(self):
+        return (2, self.nx)
+
+    def y0_standard(self):
+        """y0_2D_standard, KellerSegelSetup.jl:60-61: u = 1, v = 1.01 (Julia [2, nx])"""
+        return np.stack([np.ones(self.nx), 1.01 * np.ones(self.nx)])
+
+    def generate_random_init(self, rng, B=1):
+        """KellerSegelSetup.jl:373-384, batched -> [B, 2, nx]"""
+        number_sin = int(np.ceil(self.Lx / 3))
+        xx = self.dx * np.arange(1, self.nx + 1)
+        a = rng.uniform(-1, 1, (B, 2 * number_sin))
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        y0 = np.ones((B, 2, self.nx))
+        for i in range(1, number_sin + 1):
+            s = np.sin(i * xx / (2 * np.pi * (self.Lx / 22)))[None, :]
+            y0[:, 0] += a[:, i - 1:i] * s
+            y0[:, 1] += a[:, i - 1 + number_sin:i + number_sin] * s
+        return y0
+
+    def env_cfg(self, B, dtype_code):
+        c = _lib.EnvCfg()
+        c.pde_kind, c.dtype, c.B, c.N, c.n_species = _lib.PDE_KSEG_RK4, dtype_code, B, self.nx, 2
+        c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, self.temporal_steps, 0
+        c.K = self.oversampling
+        c.check_max_value = {"y": 1, "reward": 2}.get(self.check_max_value, 0)
+        c.Lx, c.dt, c.mu, c.max_value = self.Lx, self.dt, 0.0, self.max_value
+        c.sensor_scale = 0.25                                      # KellerSegelSetup.jl:276
+        c.agent_power = self.agent_power
+        c.reward_in_scale, c.reward_offset = 1.0, -1.0             # :248  <y[1,:] - 1, g>
+        c.reward_power, c.reward_denom = 2.0, 800.0
+        c.action_punish, c.delta_action_punish = self.action_punish, self.delta_action_punish
+        return c
+
+    def tables(self):
+        return (np.ascontiguousarray(self.gaussians, dtype=np.float64),
+                np.ascontiguousarray(self.gaussians_actuators, dtype=np.float64),
+                np.ascontiguousarray(self.actuators_to_sensors - 1, dtype=np.int32))

@@ -1,0 +1,212 @@
+/* pdeconv.h -- C ABI of libpdeconv.so: MI355X (gfx950) hot path of
+ * janstenner/DistributedConvRL-PDE-Control, hand-written HIP behind plain C.
+ *
+ * The reference has NO FFI (pure Julia); the seam this library replaces is the set of
+ * Julia callables that `PDEenv` / `CustomDDPGPolicy` invoke.  Each entry
+ * point below cites the reference callable (file:line, relative to the reference repo) it
+ * stands in for.  The Julia `ccall` bindings a maintainer would add are in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns int: 0 = OK, <0 = error (PDEC_E_*); text via pdec_last_error()
+ *    (thread-local).  No exceptions cross the boundary.  Blow-up of the PDE is NOT an error:
+ *    it sets the per-trajectory `done` flag (src/PDEenv.jl:226-237).
+ *  - handles are opaque uint64_t created/destroyed in pairs; a handle is not re-entrant,
+ *    distinct handles may be used from distinct threads.
+ *  - array arguments of compute calls are DEVICE pointers (pdec_malloc, or any HIP
+ *    allocation such as a torch tensor's data_ptr); calls are asynchronous on the handle's
+ *    stream (pdec_set_stream; default = the null stream).  The `_host` wrappers take HOST
+ *    pointers, stage through plan-owned buffers and return after completion -- these are
+ *    what a Julia `do_step(env)` closure binds.
+ *  - arrays are dense, batch-major `[B][...Julia column-major...]`: a Julia matrix
+ *    `state[ns, A]` of trajectory b starts at `state + b*ns*A` and element (r,a) is at
+ *    `a*ns + r`.  dtype (PDEC_F32 / PDEC_F64) is fixed at plan creation; setup-time tables
+ *    (sensor kernels, weights in set/get) are passed as documented per call.
+ */
+#ifndef PDECONV_H
+#define PDECONV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t pdec_handle;
+
+enum { PDEC_F32 = 0, PDEC_F64 = 1 };
+
+enum {
+  PDEC_OK = 0,
+  PDEC_E_INVALID = -1,   /* bad argument / unsupported size */
+  PDEC_E_HIP = -2,       /* HIP runtime error */
+  PDEC_E_HANDLE = -3,    /* unknown / wrong-kind handle */
+  PDEC_E_NOGPU = -4,     /* no usable gfx950 device */
+  PDEC_E_COMM = -5       /* RCCL error */
+};
+
+/* PDE right-hand side / integrator kinds */
+enum {
+  PDEC_PDE_KS_CNAB2 = 0,     /* scripts/KS/setup/KSSetup.jl:130-160 (what the reference runs) */
+  PDEC_PDE_KSEG_RK4 = 1,     /* scripts/Keller-Segel/setup/KellerSegelSetup.jl:213-239 with fixed RK4 */
+  PDEC_PDE_KS_RK4_FD = 2,    /* north-star variant: RK4 + periodic 5-point FD (KSSetup.jl:55-59 table) */
+  PDEC_PDE_FLUID_RK4 = 3     /* src/fluid_rk4.jl:122-190 + scripts/Fluid/setup/FluidSetup.jl:163-172 */
+};
+
+enum { PDEC_ACT_IDENTITY = 0, PDEC_ACT_RELU = 1, PDEC_ACT_TANH = 2 };
+
+/* ---------------------------------------------------------------- runtime ------------ */
+int pdec_init(int device_ordinal);            /* selects the device, checks gfx950 */
+int pdec_shutdown(void);                      /* destroys every live handle */
+const char* pdec_last_error(void);
+int pdec_version(void);
+int pdec_device_count(int* n);
+
+int pdec_malloc(void** dptr, size_t bytes);
+int pdec_free(void* dptr);
+int pdec_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int pdec_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int pdec_memset(void* dptr, int value, size_t bytes);
+int pdec_set_stream(pdec_handle h, void* hip_stream);   /* hipStream_t; NULL = null stream */
+int pdec_sync(pdec_handle h);                           /* hipStreamSynchronize of h's stream */
+int pdec_destroy(pdec_handle h);                        /* any handle kind */
+
+/* Per-kernel timing with HIP events on the handle's stream (for bench.py's roofline):
+ * when enabled every launch of the handle's kernels is bracketed by events. */
+int pdec_prof_enable(pdec_handle h, int on);
+int pdec_prof_reset(pdec_handle h);
+/* name: kernel label, e.g. "ks_env_step", "ddpg_critic"; returns mean ms and launch count */
+int pdec_prof_get(pdec_handle h, const char* name, double* mean_ms, int* count);
+
+/* ---------------------------------------------------------------- environment -------- */
+/* Configuration of one batched PDE environment = the globals of a reference setup file
+ * (scripts/KS/setup/KSSetup.jl:20-77, scripts/Keller-Segel/setup/KellerSegelSetup.jl:26-84)
+ * plus the build's batch size. */
+typedef struct pdec_env_cfg {
+  int pde_kind;            /* PDEC_PDE_* */
+  int dtype;               /* PDEC_F32 / PDEC_F64 */
+  int B;                   /* trajectories in the batch (reference: 1) */
+  int N;                   /* nx: cells per species */
+  int n_species;           /* 1 (KS) or 2 (Keller-Segel: rows u,v of y[2,nx]) */
+  int S;                   /* number of sensors */
+  int A;                   /* number of actuators (columns of state/action) */
+  int window;              /* window_size (odd; rows per species = window) */
+  int temporal_steps;      /* KellerSegelSetup.jl:48 */
+  int mono;                /* 1: global agent (KSglobalSetup.jl): state [S,1], reward [1] */
+  int K;                   /* oversampling: CNAB2 sub-steps / fixed RK4 sub-steps per control step */
+  int check_max_value;     /* 0 none, 1 "y", 2 "reward" (src/PDEenv.jl:226-240) */
+  double Lx;               /* domain length */
+  double dt;               /* control interval */
+  double mu;               /* KS disturbance amplitude (KSSetup.jl:155); 0 for mono */
+  double max_value;        /* blow-up threshold */
+  double sensor_scale;     /* sensors = <y,g> * sensor_scale  (1/max_value KS; 1/4 K-S) */
+  double agent_power;      /* p = sum_i agent_power * action[i] * kernel_i */
+  double reward_in_scale;  /* d = reward_in_scale * (<y,g> + reward_offset*sum(g)) */
+  double reward_offset;    /* KS 0; K-S -1 (y-1) */
+  double reward_power;     /* r = -|d|^reward_power / reward_denom - ... */
+  double reward_denom;
+  double action_punish;
+  double delta_action_punish;
+} pdec_env_cfg;
+
+/* sensor_kernels [S][N], actuator_kernels [A][N] (host, double, row = one kernel: the
+ * `gaussians` / `gaussians_actuators` arrays, KSSetup.jl:111-113); a2s [A] 0-based index
+ * of the sensor under each actuator (`actuators_to_sensors`).  Replaces the closures built
+ * in KSSetup.jl:82-245 / KellerSegelSetup.jl:112-332. */
+int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* sensor_kernels,
+                    const double* actuator_kernels, const int32_t* a2s);
+
+/* prepare_action(; env): p[B][N] from action[B][A]      (KSSetup.jl:231-245) */
+int pdec_actuate(pdec_handle h, const void* action, void* p_out);
+/* do_step(env): y_out[B][n_species*N] from y_in, p[B][N]; done[B] int32 (bit0 = blow-up,
+ * only when check_max_value==1)                           (KSSetup.jl:130-160, PDEenv.jl:216-228) */
+int pdec_pde_step(pdec_handle h, const void* y_in, const void* p, void* y_out, int32_t* done);
+/* featurize(; env): state_out[B][A][ns] from y and the previous state (temporal_steps>1;
+ * may be NULL = constructor/reset form, KSSetup.jl:190-229, KellerSegelSetup.jl:265-316) */
+int pdec_featurize(pdec_handle h, const void* y, const void* prev_state, void* state_out);
+/* reward_function(env): r_out[B][A] (or [B][1] mono)      (KSSetup.jl:162-178) */
+int pdec_reward(pdec_handle h, const void* y, const void* action, const void* action_prev,
+                void* r_out);
+/* (env::PDEenv)(action), src/PDEenv.jl:195-241, in ONE launch: delta_action, prepare_action,
+ * integrator, reward, featurize, blow-up flag.  y_out may alias y_in; state_out must not
+ * alias state_prev when temporal_steps>1.  p_out may be NULL. */
+int pdec_env_step(pdec_handle h, const void* y_in, const void* action, const void* action_prev,
+                  const void* state_prev, void* y_out, void* p_out, void* state_out,
+                  void* reward_out, int32_t* done);
+/* RHS evaluation for known-answer tests: out = f(y, p)    (KellerSegelSetup.jl:213-232) */
+int pdec_rhs_eval(pdec_handle h, const void* y, const void* p, void* out);
+
+/* Host-pointer forms (synchronous) -- what Julia's do_step/featurize closures bind. */
+int pdec_pde_step_host(pdec_handle h, const void* y_in, const void* p, void* y_out, int32_t* done);
+int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, const void* action_prev,
+                       const void* state_prev, void* y_out, void* p_out, void* state_out,
+                       void* reward_out, int32_t* done);
+
+/* ---------------------------------------------------------------- networks ----------- */
+/* Chain(Dense...) with weights shared across columns (src/PDEagent.jl:14-56).
+ * dims[n_layers+1], acts[n_layers].  params_host: Flux.params order W1,b1,W2,b2,... each W
+ * in Julia column-major [out,in] (element (o,i) at i*out+o), dtype = the plan's dtype; NULL
+ * = zeros.  max_cols = largest number of columns any later call will pass. */
+int pdec_mlp_create(pdec_handle* h, int dtype, int n_layers, const int32_t* dims,
+                    const int32_t* acts, const void* params_host, int max_cols);
+int pdec_mlp_num_params(pdec_handle h, int* n);
+int pdec_mlp_set_params(pdec_handle h, const void* params_host);   /* Flux.loadparams!  (custom_nna.jl:26-27) */
+int pdec_mlp_get_params(pdec_handle h, void* params_host);         /* Flux.params -> host (checkpoint)      */
+int pdec_mlp_copy(pdec_handle dst, pdec_handle src);               /* copyto!(dst, src)  (custom_nna.jl:26)  */
+/* app(x): x [cols][in] (= Julia [in, cols]), y_out [cols][out]    (custom_nna.jl:13) */
+int pdec_mlp_forward(pdec_handle h, const void* x, int cols, void* y_out);
+/* forward + backward of sum(dy .* app(x)): grads_out (device, layout of get_params, may be
+ * NULL -> only the internal gradient buffer is filled), dx_out [cols][in] may be NULL */
+int pdec_mlp_backward(pdec_handle h, const void* x, const void* dy, int cols, void* dx_out,
+                      void* grads_out);
+/* device pointer + length of the internal flat gradient buffer (for an external all-reduce) */
+int pdec_mlp_grad_buffer(pdec_handle h, void** dptr, int* n);
+/* update!(app, gs) with Flux.Optimise.ADAM semantics (custom_nna.jl:23-24); uses the
+ * internal gradient buffer */
+int pdec_adam_step(pdec_handle h, double eta, double beta1, double beta2, double eps);
+int pdec_adam_get_state(pdec_handle h, void* m_host, void* v_host, double* beta_pow2);
+int pdec_adam_set_state(pdec_handle h, const void* m_host, const void* v_host, const double* beta_pow2);
+/* dest .= rho .* dest .+ (1-rho) .* src                          (src/PDEagent.jl:415-417) */
+int pdec_polyak(pdec_handle dst, pdec_handle src, double rho);
+
+/* policy act: actions[cols][na] = clamp(actor(state) + noise*act_noise, +-act_limit)
+ * (src/PDEagent.jl:183-207).  noise [cols][na] device standard normals or NULL (-> no noise,
+ * `learning=false`). */
+int pdec_policy_act(pdec_handle actor, const void* state, const void* noise, int cols,
+                    double act_noise, double act_limit, void* actions_out);
+/* fill dst[n] with standard normals from a counter-based generator (replaces randn(rng),
+ * src/PDEagent.jl:201) */
+int pdec_randn(pdec_handle any_handle, void* dst, size_t n, int dtype, uint64_t seed, uint64_t offset);
+
+/* DDPG update (src/PDEagent.jl:363-418) split at the points where a data-parallel run
+ * all-reduces gradients.  s,snext [Bu][ns]; a [Bu][na]; r [Bu]; t [Bu] (same dtype; 0/1).
+ * quirk=1 reproduces the reference's (1xBu).+(Bu) broadcast of the reward,
+ * quirk=0 is the diagonal TD target.  grad_scale multiplies the gradients (1/world_size for
+ * a data-parallel mean).  Losses are written to device scalars (dtype of the plan). */
+int pdec_ddpg_critic_grads(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
+                           const void* s, const void* a, const void* r, const void* t,
+                           const void* snext, int Bu, double gamma, int quirk, double grad_scale,
+                           void* critic_loss_dev);
+int pdec_ddpg_actor_grads(pdec_handle A, pdec_handle C, const void* s, int Bu, double grad_scale,
+                          void* actor_loss_dev);
+/* whole update on one device: critic grads, ADAM(C), actor grads, ADAM(A), Polyak x2;
+ * losses returned to host (synchronises). */
+int pdec_ddpg_update(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
+                     const void* s, const void* a, const void* r, const void* t, const void* snext,
+                     int Bu, double gamma, double rho, int quirk, double eta_actor, double eta_critic,
+                     double* actor_loss, double* critic_loss);
+
+/* ---------------------------------------------------------------- multi-GPU ---------- */
+/* One RCCL communicator per process (one process per GPU).  unique_id: 128 bytes from
+ * pdec_comm_unique_id on rank 0, broadcast by the host (the reference has no collective;
+ * this is the build's data-parallel addition). */
+int pdec_comm_unique_id(void* id128);
+int pdec_comm_create(pdec_handle* c, int nranks, int rank, const void* id128);
+/* sum-all-reduce the internal gradient buffer of an MLP in place (fp32/fp64) */
+int pdec_allreduce_grads(pdec_handle comm, pdec_handle mlp);
+int pdec_allreduce(pdec_handle comm, void* dptr, size_t n, int dtype, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDECONV_H */

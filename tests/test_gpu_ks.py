@@ -1,0 +1,131 @@
+"""GPU parity of the KS environment path against the reference's golden trajectories and the
+oracle (through the C ABI).  Tolerances: fp64 <= 1e-12 abs per teacher-forced
+control step vs the golden; fp32 <= 2e-5 abs (a complex64 CPU run measures 3.5e-6..7.6e-6)."""
+import numpy as np
+import pytest
+
+from util import ks_pair, to_dev
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+TOL = {"f64": 1e-12, "f32": 2e-5}
+
+
+@pytest.mark.parametrize("name", ["ks22", "ks200", "ks22_global"])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_do_step_matches_reference_golden(pkg, name, prec):
+    """y[t+1] = do_step(y[t], p[t+1]) for all 50 logged pairs, batched as B = 50 trajectories."""
+    setup, cfg, g = ks_pair(pkg, name)
+    dt = torch.float64 if prec == "f64" else torch.float32
+    y, p = g["y"], g["p"]
+    env = pkg.PDEenv(setup, B=50, dtype=dt)
+    out, flags = env.do_step(to_dev(y[:50], dt), to_dev(p[1:51], dt))
+    err = np.abs(out.cpu().numpy().astype(np.float64) - y[1:51]).max()
+    assert err <= TOL[prec], err
+    assert int(flags.sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["ks22", "ks200", "ks22_global"])
+def test_env_step_fused_matches_golden_and_oracle(pkg, name):
+    """Fused (env)(action): p, y, reward against the golden rows; state against the oracle."""
+    from oracle import ks
+    setup, cfg, g = ks_pair(pkg, name)
+    dt = torch.float64
+    y, p, a, r = g["y"], g["p"], g["action"], g["reward"]
+    B = 49
+    env = pkg.PDEenv(setup, B=B, dtype=dt)
+    env.y.copy_(to_dev(y[1:50], dt))
+    prev = to_dev(a[1:50], dt).reshape(env._ashape)
+    env.action.copy_(prev)
+    env(to_dev(a[2:51], dt).reshape(env._ashape))
+    assert np.abs(env.p.cpu().numpy() - p[2:51]).max() <= 1e-12
+    assert np.abs(env.y.cpu().numpy() - y[2:51]).max() <= 1e-12
+    assert np.abs(env.reward.cpu().numpy() - r[2:51]).max() <= 1e-12
+    for b in (0, 17, 48):
+        st = ks.featurize(cfg, y[2 + b])
+        got = env.state[b].cpu().numpy().T if not setup.mono else env.state[b].cpu().numpy().reshape(-1, 1)
+        assert np.abs(got - st).max() <= 1e-13
+    assert not bool(env.done.any())
+
+
+def test_fp32_env_step_and_odd_batch(pkg):
+    """fp32, odd B (the last workgroup integrates a single trajectory), bench geometry C2."""
+    from oracle import ks
+    setup = pkg.KSSetup.bench_C2(256)
+    cfg = ks.KSConfig(256, setup.Lx, setup.sensor_positions, sigma_sensors=1.0, sigma_actuators=1.0, window_size=3)
+    rng = np.random.default_rng(0)
+    B = 5
+    y0 = setup.generate_random_init(rng, B) * 0.15
+    act_prev = rng.uniform(-1, 1, (B, 64))
+    act = rng.uniform(-1, 1, (B, 64))
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float32)
+    env.y.copy_(to_dev(y0, torch.float32))
+    env.action.copy_(to_dev(act_prev, torch.float32).reshape(env._ashape))
+    env(to_dev(act, torch.float32).reshape(env._ashape))
+    for b in range(B):
+        o = ks.env_step(cfg, y0[b], act_prev[b][None], act[b][None], 0.0)
+        assert np.abs(env.y[b].cpu().numpy() - o["y"]).max() <= 2e-5
+        assert np.abs(env.p[b].cpu().numpy() - o["p"]).max() <= 1e-5
+        assert np.abs(env.reward[b].cpu().numpy() - o["reward"]).max() <= 1e-5
+        assert np.abs(env.state[b].cpu().numpy().T - o["state"]).max() <= 1e-5
+
+
+def test_standalone_closures_match_oracle(pkg):
+    from oracle import ks
+    setup, cfg, g = ks_pair(pkg, "ks200")
+    dt = torch.float64
+    env = pkg.PDEenv(setup, B=3, dtype=dt)
+    y, a = g["y"][5:8], g["action"]
+    st = env.featurize(to_dev(y, dt)).cpu().numpy()
+    pp = env.prepare_action(to_dev(a[5:8], dt).reshape(env._ashape)).cpu().numpy()
+    rr = env.reward_function(to_dev(y, dt), to_dev(a[5:8], dt).reshape(env._ashape),
+                             to_dev(a[4:7], dt).reshape(env._ashape)).cpu().numpy()
+    for b in range(3):
+        assert np.abs(st[b].T - ks.featurize(cfg, y[b])).max() <= 1e-13
+        assert np.abs(pp[b] - ks.prepare_action(cfg, a[5 + b][None])).max() <= 1e-12
+        assert np.abs(rr[b] - ks.reward_function(cfg, y[b], a[5 + b][None], (a[5 + b] - a[4 + b])[None])).max() <= 1e-13
+
+
+def test_mass_conservation_and_blowup_flag(pkg):
+    """Size-independent properties at the bench size: with p = 0 the CNAB2 step conserves
+    sum(y) (mode 0 has L = G = 0); a state beyond max_value raises the done flag."""
+    setup = pkg.KSSetup.bench_C2(256)
+    B = 512
+    rng = np.random.default_rng(1)
+    y0 = setup.generate_random_init(rng, B) * 0.1
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float64)
+    yd = to_dev(y0, torch.float64)
+    out, flags = env.do_step(yd, torch.zeros_like(yd))
+    assert torch.allclose(out.sum(1), yd.sum(1), atol=1e-10)
+    assert int(flags.sum()) == 0
+    yd[3] += 40.0   # mean mode is conserved, so |y| stays > max_value = 30 but finite
+    out, flags = env.do_step(yd, torch.zeros_like(yd))
+    f = flags.cpu().numpy()
+    assert f[3] == 1 and f.sum() == 1
+
+
+def test_disturbance_term(pkg):
+    """mu != 0 (KS200_disturbed.jl:16): the inhomogeneous term added outside A_inv (KSSetup.jl:155)."""
+    from oracle import ks
+    g_setup, cfg, g = ks_pair(pkg, "ks200")
+    pos = np.arange(1, 241, 3)
+    setup = pkg.KSSetup(240, 200.0, pos, mu=0.02)
+    cfg = ks.KSConfig(240, 200.0, pos, mu=0.02)
+    env = pkg.PDEenv(setup, B=2, dtype=torch.float64)
+    y, p = g["y"][10:12], g["p"][11:13]
+    out, _ = env.do_step(to_dev(y, torch.float64), to_dev(p, torch.float64))
+    for b in range(2):
+        assert np.abs(out[b].cpu().numpy() - ks.do_step(cfg, y[b], p[b])).max() <= 1e-12
+
+
+def test_host_pointer_wrapper(pkg):
+    """pdec_pde_step_host: the form a Julia do_step(env) closure binds (host arrays in/out)."""
+    import ctypes as C
+    setup, cfg, g = ks_pair(pkg, "ks22")
+    env = pkg.PDEenv(setup, B=1, dtype=torch.float64)
+    y = np.ascontiguousarray(g["y"][3]); p = np.ascontiguousarray(g["p"][4])
+    out = np.empty_like(y); done = np.zeros(1, dtype=np.int32)
+    lib = pkg._lib.load()
+    pkg._lib.check(lib.pdec_pde_step_host(env.handle, y.ctypes.data, p.ctypes.data, out.ctypes.data, done.ctypes.data))
+    assert np.abs(out - g["y"][4]).max() <= 1e-12 and done[0] == 0

@@ -1,0 +1,158 @@
+"""GPU parity of the weight-shared MLP path (forward, backward, ADAM, Polyak, DDPG update)
+against the fp64/fp32 oracle, through the C ABI.  Tolerances: fp32 forward
+<= 1e-5 rel, gradients <= 1e-4 rel vs the fp64 restatement; fp64 <= 1e-11 rel."""
+import numpy as np
+import pytest
+
+from util import to_dev
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def relerr(a, b):
+    return np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max() / max(1e-30, np.abs(b).max())
+
+
+def make_net(pkg, rng, dims, acts, dtype, max_cols):
+    from oracle import nn
+    P = nn.glorot_uniform(rng, dims, np.float64)
+    for i in range(1, len(P), 2):
+        P[i] = rng.standard_normal(P[i].shape) * 0.1
+    code = {nn.RELU: "relu", nn.TANH: "tanh", nn.IDENT: None}
+    net = pkg.HipMLP(dims, [code[a] for a in acts], P, dtype=dtype, max_cols=max_cols)
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    return net, [p.astype(npdt) for p in P]
+
+
+SHAPES = [
+    ("ks_actor_2l", 1, 1, 0.6, True, True),       # Dense(1,6,relu)->Dense(6,1,tanh)   KSSetup.jl:40-46
+    ("ks_critic_2l", 1, 1, 7.0, False, True),     # 2->140->1
+    ("c2_actor_3l", 3, 1, 1.6, True, False),      # 3->16->16->1
+    ("c2_critic_3l", 3, 1, 7.0, False, False),    # 4->140->140->1
+    ("kseg_critic", 12, 1, 17.0, False, True),    # 13->340->1
+    ("global_actor", 8, 8, 4.8, True, True),      # 8->48->8
+]
+
+
+@pytest.mark.parametrize("name,ns,na,scale,is_actor,drop", SHAPES)
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_forward_backward(pkg, name, ns, na, scale, is_actor, drop, prec):
+    from oracle import nn
+    rng = np.random.default_rng(hash(name) % 1000)
+    dims, acts = nn.layer_sizes(ns, na, scale, is_actor, drop)
+    dtype = torch.float64 if prec == "f64" else torch.float32
+    cols = 777
+    net, P = make_net(pkg, rng, dims, acts, dtype, cols)
+    P64 = [p.astype(np.float64) for p in P]
+    x = rng.standard_normal((dims[0], cols))
+    dy = rng.standard_normal((dims[-1], cols))
+    y, zs, as_ = nn.forward(P64, acts, x, keep=True)
+    g, dx = nn.backward(P64, acts, zs, as_, dy)
+    xd = to_dev(x.T, dtype)
+    yd = net(xd).cpu().numpy().T
+    gg, dxd = net.backward(xd, to_dev(dy.T, dtype))
+    tol_f, tol_g = (1e-11, 1e-10) if prec == "f64" else (1e-5, 1e-4)
+    assert relerr(yd, y) <= tol_f
+    assert relerr(dxd.cpu().numpy().T, dx) <= tol_g
+    for a, b in zip(gg, g):
+        assert relerr(a, b) <= tol_g, name
+    # params round-trip (checkpoint / copyto!)
+    for a, b in zip(net.params(), P):
+        assert np.array_equal(a, b)
+
+
+def test_adam_polyak_match_flux_semantics(pkg):
+    from oracle import nn
+    rng = np.random.default_rng(3)
+    dims, acts = nn.layer_sizes(3, 1, 1.6, True, False)
+    net, P = make_net(pkg, rng, dims, acts, torch.float32, 64)
+    tgt, PT = make_net(pkg, rng, dims, acts, torch.float32, 64)
+    opt = nn.Adam(P, 5e-4)
+    app = pkg.CustomNeuralNetworkApproximator(net, pkg.ADAM(5e-4))
+    x = rng.standard_normal((3, 64)).astype(np.float32)
+    dy = rng.standard_normal((1, 64)).astype(np.float32)
+    for it in range(3):
+        y, zs, as_ = nn.forward(P, acts, x, keep=True)
+        g, _ = nn.backward(P, acts, zs, as_, dy)
+        P = opt.step(P, [gi.astype(np.float32) for gi in g])
+        net.backward(to_dev(x.T, torch.float32), to_dev(dy.T, torch.float32), want_dx=False)
+        app.update()
+    for a, b in zip(net.params(), P):
+        assert relerr(a, b) <= 2e-5
+    pkg._lib.check(net.lib.pdec_polyak(tgt.handle, net.handle, 0.995))
+    PT = nn.polyak(PT, P, np.float32(0.995))
+    for a, b in zip(tgt.params(), PT):
+        assert relerr(a, b) <= 2e-6
+
+
+@pytest.mark.parametrize("quirk", [1, 0])
+@pytest.mark.parametrize("prec,Bu", [("f64", 300), ("f32", 4096)])
+def test_ddpg_update_matches_oracle(pkg, quirk, prec, Bu):
+    """Whole update (src/PDEagent.jl:363-418): losses, all four networks after one and two
+    updates.  quirk=1 is the reference's (1xBu).+(Bu) reward broadcast."""
+    import ctypes as C
+    from oracle import nn
+    rng = np.random.default_rng(11 + quirk)
+    ns, na = 3, 1
+    da, aa = nn.layer_sizes(ns, na, 1.6, True, False)
+    dc, ac = nn.layer_sizes(ns, na, 7.0, False, False)
+    dtype = torch.float64 if prec == "f64" else torch.float32
+    npdt = np.float64 if prec == "f64" else np.float32
+    A, PA = make_net(pkg, rng, da, aa, dtype, Bu)
+    Cn, PC = make_net(pkg, rng, dc, ac, dtype, Bu)
+    At, PAt = make_net(pkg, rng, da, aa, dtype, Bu)
+    Ct, PCt = make_net(pkg, rng, dc, ac, dtype, Bu)
+    optA, optC = nn.Adam(PA, 5e-4), nn.Adam(PC, 1e-3)
+    lib = A.lib
+    tol = 1e-9 if prec == "f64" else 2e-4
+    for it in range(2):
+        s = rng.standard_normal((ns, Bu)).astype(npdt)
+        sn = rng.standard_normal((ns, Bu)).astype(npdt)
+        a = rng.uniform(-1, 1, (na, Bu)).astype(npdt)
+        r = -rng.uniform(0, 1, Bu).astype(npdt)
+        t = (rng.uniform(0, 1, Bu) < 0.1).astype(npdt)
+        out = nn.ddpg_update(PA, PC, PAt, PCt, optA, optC, aa, ac, s, a, r, t, sn, npdt(np.float32(0.99)), np.float32(0.995), bool(quirk))
+        al, cl = C.c_double(), C.c_double()
+        ds, da_, dr, dt_, dsn = (to_dev(s.T, dtype), to_dev(a.T, dtype), to_dev(r, dtype), to_dev(t, dtype),
+                                 to_dev(sn.T, dtype))   # keep alive across the call
+        pkg._lib.check(lib.pdec_ddpg_update(
+            A.handle, Cn.handle, At.handle, Ct.handle, pkg._lib.ptr(ds), pkg._lib.ptr(da_), pkg._lib.ptr(dr),
+            pkg._lib.ptr(dt_), pkg._lib.ptr(dsn), Bu, 0.99, 0.995, quirk, 5e-4, 1e-3, C.byref(al), C.byref(cl)))
+        assert abs(cl.value - out["critic_loss"]) <= tol * max(1.0, abs(out["critic_loss"]))
+        assert abs(al.value - out["actor_loss"]) <= tol * max(1.0, abs(out["actor_loss"]))
+        for net, P in ((A, PA), (Cn, PC), (At, PAt), (Ct, PCt)):
+            for x, y in zip(net.params(), P):
+                assert relerr(x, y) <= tol
+
+
+def test_policy_act_noise_clamp(pkg):
+    from oracle import nn
+    rng = np.random.default_rng(5)
+    dims, acts = nn.layer_sizes(3, 1, 1.6, True, False)
+    net, P = make_net(pkg, rng, dims, acts, torch.float64, 512)
+    state = rng.standard_normal((3, 512))
+    noise = rng.standard_normal((1, 512))
+    ref = nn.policy_act(P, acts, state, noise, 1.2, 1.0)
+    out = torch.empty((512, 1), dtype=torch.float64, device="cuda:0")
+    dstate, dnoise = to_dev(state.T, torch.float64), to_dev(noise.T, torch.float64)
+    pkg._lib.check(net.lib.pdec_policy_act(net.handle, pkg._lib.ptr(dstate), pkg._lib.ptr(dnoise), 512, 1.2, 1.0,
+                                           pkg._lib.ptr(out)))
+    assert np.abs(out.cpu().numpy().T - ref).max() <= 1e-12
+    assert np.abs(ref).max() <= 1.0
+
+
+def test_randn_moments_and_determinism(pkg):
+    rng = np.random.default_rng(0)
+    dims = [1, 1]
+    net = pkg.HipMLP(dims, [None], None, max_cols=1)
+    n = 1 << 20
+    a = torch.empty(n, dtype=torch.float32, device="cuda:0")
+    b = torch.empty(n, dtype=torch.float32, device="cuda:0")
+    pkg._lib.check(net.lib.pdec_randn(net.handle, pkg._lib.ptr(a), n, 0, 1234, 0))
+    pkg._lib.check(net.lib.pdec_randn(net.handle, pkg._lib.ptr(b), n, 0, 1234, 0))
+    assert torch.equal(a, b)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.05
+    pkg._lib.check(net.lib.pdec_randn(net.handle, pkg._lib.ptr(b), n, 0, 1234, n // 4))
+    assert not torch.equal(a, b)
