@@ -9,3 +9,9 @@ from .setups import KSSetup, KellerSegelSetup  # noqa: F401
 from .env import PDEenv  # noqa: F401
 from .nna import (HipMLP, ADAM, CustomNeuralNetworkApproximator, create_NNA, create_chain,  # noqa: F401
                   glorot_uniform, layer_spec)
+from .agent import (Agent, CustomDDPGPolicy, CircularArraySARTTrajectory, ZeroPolicy, RandomPolicy,  # noqa: F401
+                    create_agent, PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE,
+                    POST_EPISODE_STAGE, POST_EXPERIMENT_STAGE)
+from .hook import PDEhook  # noqa: F401
+from .run import run, StopAfterEpisode, StopAfterEpisodeWithMinSteps  # noqa: F401
+from . import julia_compat, distributed  # noqa: F401

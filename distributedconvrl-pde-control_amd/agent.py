@@ -1,0 +1,262 @@
+"""PDEagent mirror: CustomDDPGPolicy, trajectory glue, create_agent, ZeroPolicy
+(src/PDEagent.jl:58-424), batched over B environments and running on libpdeconv.
+
+Columns: one env step yields B*A (state, action) columns (A = actuators sharing the policy;
+mono/global agent: one column per env).  The reference pushes A columns per step into a
+CircularArraySARTTrajectory and samples `batch_size` of them per update
+(src/PDEagent.jl:254-340); the batched run pushes B*A columns per step in [b][a] order, so
+the next-state of column i sits at i + B*A (the reference's `inds .+ number_actuators`)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .nna import create_NNA
+
+PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE, POST_EPISODE_STAGE, POST_EXPERIMENT_STAGE = range(6)
+
+
+class ZeroPolicy:
+    """src/PDEagent.jl:420-424"""
+
+    def __init__(self, action_shape):
+        self.action_shape = action_shape
+
+    def __call__(self, env):
+        return torch.zeros(env._ashape, dtype=env.dtype, device=env.device)
+
+
+class RandomPolicy:
+    """RLCore.RandomPolicy(action_space; rng): uniform in [-1, 1]"""
+
+    def __init__(self, action_shape, rng=None):
+        self.action_shape, self.rng = action_shape, rng or np.random.default_rng()
+
+    def __call__(self, env):
+        return torch.as_tensor(self.rng.uniform(-1, 1, env._ashape), dtype=env.dtype, device=env.device)
+
+
+class CircularArraySARTTrajectory:
+    """Device-resident replay with the reference's trace layout (state/action one `stride`
+    longer than reward/terminal; Float32, src/PDEagent.jl:112-117).  Unlike RLCore's buffer the
+    four traces stay aligned after wrap-around (reference quirks)."""
+
+    def __init__(self, capacity, ns, na, stride, device, reward_per_column=True):
+        self.stride = int(stride)
+        self.capacity = max(self.stride, int(capacity) // self.stride * self.stride)
+        kw = dict(dtype=torch.float32, device=device)
+        self.state = torch.zeros((self.capacity + self.stride, ns), **kw)
+        self.action = torch.zeros((self.capacity + self.stride, na), **kw)
+        self.reward = torch.zeros(self.capacity, **kw)
+        self.terminal = torch.zeros(self.capacity, **kw)
+        self.n_sa = 0        # logical entries in the state/action traces (monotone, minus pops)
+        self.n_rt = 0        # logical entries in the reward/terminal traces
+        self.device = device
+
+    def __len__(self):       # length(t) = length(t[:terminal])
+        return min(self.n_rt, self.capacity)
+
+    def _slots(self, start, n, cap):
+        return (torch.arange(start, start + n, device=self.device) % cap)
+
+    def push_sa(self, s, a):
+        n = s.shape[0]
+        idx = self._slots(self.n_sa, n, self.capacity + self.stride)
+        self.state.index_copy_(0, idx, s.to(torch.float32))
+        self.action.index_copy_(0, idx, a.to(torch.float32))
+        self.n_sa += n
+
+    def pop_sa(self, n):
+        self.n_sa -= n
+
+    def push_rt(self, r, t):
+        n = r.shape[0]
+        idx = self._slots(self.n_rt, n, self.capacity)
+        self.reward.index_copy_(0, idx, r.to(torch.float32))
+        self.terminal.index_copy_(0, idx, t.to(torch.float32))
+        self.n_rt += n
+
+    def sample(self, rng, batch_size):
+        """pde_sample / pde_fetch! (src/PDEagent.jl:317-340): inds in 1:length(t)-stride"""
+        L = len(self)
+        hi = L - self.stride
+        inds = torch.as_tensor(rng.integers(0, hi, batch_size), device=self.device)
+        base = max(0, self.n_rt - self.capacity)          # logical index of the oldest entry
+        lg = base + inds
+        i_rt = lg % self.capacity
+        i_s = lg % (self.capacity + self.stride)
+        i_sn = (lg + self.stride) % (self.capacity + self.stride)
+        return dict(state=self.state[i_s], action=self.action[i_s], reward=self.reward[i_rt],
+                    terminal=self.terminal[i_rt], next_state=self.state[i_sn])
+
+
+class CustomDDPGPolicy:
+    """src/PDEagent.jl:121-209, 342-418"""
+
+    def __init__(self, *, behavior_actor, behavior_critic, target_actor, target_critic, rng, gamma=0.99, rho=0.995,
+                 batch_size=3, start_steps=6, start_policy=None, update_after=10, update_freq=1, update_loops=1,
+                 reset_stage=POST_EPISODE_STAGE, act_limit=1.0, act_noise=1.2, memory_size=0, number_actuators=1,
+                 quirk_target_broadcast=True, noise_seed=0, reducer=None):
+        self.behavior_actor, self.behavior_critic = behavior_actor, behavior_critic
+        self.target_actor, self.target_critic = target_actor, target_critic
+        self.rng = rng
+        self.y, self.p = gamma, rho                       # the reference's field names (gamma, polyak rho)
+        self.batch_size, self.start_steps, self.start_policy = batch_size, start_steps, start_policy
+        self.update_after, self.update_freq, self.update_loops = update_after, update_freq, update_loops
+        self.reset_stage, self.act_limit, self.act_noise, self.memory_size = reset_stage, act_limit, act_noise, memory_size
+        self.number_actuators = number_actuators
+        self.quirk = quirk_target_broadcast               # (1xBu) .+ (Bu) broadcast of r
+        self.update_step = 0
+        self.actor_loss = self.critic_loss = 0.0
+        self.reducer = reducer                            # data-parallel gradient all-reduce (or None)
+        self._noise_seed, self._noise_off = int(noise_seed), 0
+        m = behavior_actor.model
+        self.lib, self.device = m.lib, m.device
+        self._losses = torch.zeros(2, dtype=m.dtype, device=m.device)
+        self._acting = {}                                 # dtype -> promoted acting copy of the actor
+        self._noise = None
+        self._actions = None
+
+    # ---- acting (src/PDEagent.jl:175-209)
+    def _actor_for(self, dtype, cols):
+        m = self.behavior_actor.model
+        if dtype == m.dtype and cols <= m.max_cols:
+            return m
+        key = (dtype, cols)
+        if key not in self._acting:
+            self._acting[key] = m.clone(dtype=dtype, max_cols=max(cols, 1))
+        else:
+            _lib.check(self.lib.pdec_mlp_copy(self._acting[key].handle, m.handle))
+        return self._acting[key]
+
+    def __call__(self, env, learning=True, test=False):
+        if learning:
+            self.update_step += 1
+        if self.update_step <= self.start_steps:
+            return self.start_policy(env)
+        s = env.state                                     # [B, A, ns] == columns [B*A, ns]
+        cols = s.shape[0] * s.shape[1]
+        actor = self._actor_for(env.dtype, cols)
+        na = actor.dims[-1]
+        if self._actions is None or self._actions.shape != (cols, na) or self._actions.dtype != env.dtype:
+            self._actions = torch.empty((cols, na), dtype=env.dtype, device=env.device)
+            self._noise = torch.empty((cols, na), dtype=env.dtype, device=env.device)
+        noise = None
+        if learning:                                      # randn(rng, ...) .* act_noise (:201)
+            n = cols * na
+            _lib.check(self.lib.pdec_randn(actor.handle, _lib.ptr(self._noise), n, _lib.dtype_code(env.dtype),
+                                           self._noise_seed, self._noise_off))
+            self._noise_off += (n + 3) // 4
+            noise = self._noise
+        _lib.check(self.lib.pdec_policy_act(actor.handle, _lib.ptr(s), _lib.ptr(noise), cols, float(self.act_noise),
+                                            float(self.act_limit), _lib.ptr(self._actions)))
+        return self._actions.view(env._ashape)
+
+    # ---- update!(policy, batch) (src/PDEagent.jl:363-418), fused on the device
+    def update(self, batch):
+        """batch: dict(state [Bu,ns], action [Bu,na], reward [Bu], terminal [Bu], next_state [Bu,ns])"""
+        A, Cn, At, Ct = (self.behavior_actor.model, self.behavior_critic.model, self.target_actor.model,
+                         self.target_critic.model)
+        dt = Cn.dtype
+        s, a, r, t, sn = (batch[k].to(dt).contiguous() for k in ("state", "action", "reward", "terminal", "next_state"))
+        Bu = s.shape[0]
+        scale = 1.0 if self.reducer is None else 1.0 / self.reducer.world_size
+        L = self._losses
+        _lib.check(self.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a),
+                                                   _lib.ptr(r), _lib.ptr(t), _lib.ptr(sn), Bu, float(self.y), int(self.quirk),
+                                                   scale, C.c_void_p(L.data_ptr())))
+        if self.reducer is not None:
+            self.reducer.all_reduce(Cn)
+        self.behavior_critic.update()                                                  # :400
+        _lib.check(self.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, _lib.ptr(s), Bu, scale,
+                                                  C.c_void_p(L.data_ptr() + L.element_size())))
+        if self.reducer is not None:
+            self.reducer.all_reduce(A)
+        self.behavior_actor.update()                                                   # :412
+        _lib.check(self.lib.pdec_polyak(At.handle, A.handle, float(self.p)))           # :415-417
+        _lib.check(self.lib.pdec_polyak(Ct.handle, Cn.handle, float(self.p)))
+        self._batch_keepalive = (s, a, r, t, sn)
+
+    def losses(self):
+        """(actor_loss, critic_loss) of the last update (synchronises)"""
+        v = self._losses.cpu().numpy()
+        self.critic_loss, self.actor_loss = float(v[0]), float(v[1])
+        return self.actor_loss, self.critic_loss
+
+
+class Agent:
+    """RLCore.Agent(policy, trajectory) with the stage methods of src/PDEagent.jl:211-361"""
+
+    def __init__(self, policy, trajectory):
+        self.policy, self.trajectory = policy, trajectory
+
+    def __call__(self, *args):
+        if len(args) == 1:                    # agent(env) -> action
+            return self.policy(args[0])
+        stage, env = args[0], args[1]
+        p, tr = self.policy, self.trajectory
+        if stage == PRE_EPISODE_STAGE:        # :237-252 pop the dummy (s, a) of the previous episode
+            if len(tr) > 0 and tr.n_sa > tr.n_rt:
+                tr.pop_sa(tr.stride)
+        elif stage == PRE_ACT_STAGE:          # :254-274 push, then :342-361 update
+            action = args[2]
+            s = env.state.reshape(-1, env.state.shape[-1])
+            tr.push_sa(s, action.reshape(s.shape[0], -1))
+            self._maybe_update()
+        elif stage == POST_ACT_STAGE:         # :276-289
+            r = env.reward.reshape(-1)
+            cols_per_env = r.shape[0] // env.B
+            t = env.done.to(torch.float32).repeat_interleave(cols_per_env)
+            tr.push_rt(r, t)
+        elif stage == POST_EPISODE_STAGE:     # :215-224, :291-314
+            if stage == p.reset_stage:
+                p.update_step = 0
+            s = env.state.reshape(-1, env.state.shape[-1])
+            tr.push_sa(s, torch.zeros((s.shape[0], tr.action.shape[1]), device=s.device))
+        elif stage == POST_EXPERIMENT_STAGE:
+            if stage == p.reset_stage:
+                p.update_step = 0
+
+    def _maybe_update(self):
+        p, tr = self.policy, self.trajectory
+        if not (len(tr) > p.update_after * tr.stride):        # :354
+            return
+        if p.update_step % p.update_freq != 0:                # :355
+            return
+        for _ in range(p.update_loops):                       # :357-360
+            p.update(tr.sample(p.rng, p.batch_size))
+
+
+def create_agent(*, setup, B=1, rng=None, dtype=torch.float32, device="cuda:0", start_policy=None, mono=None,
+                 max_update_cols=None, reducer=None, stream=None, **overrides):
+    """src/PDEagent.jl:58-119 with the setup's agent constants (KSSetup.jl:38-77)."""
+    rng = rng or np.random.default_rng(0)
+    g = lambda k: overrides.get(k, getattr(setup, k))
+    ns, cols_per_env = setup.state_shape
+    mono = setup.mono if mono is None else mono
+    na = setup.action_shape[0]
+    batch_size = g("batch_size")
+    max_cols = max(B * cols_per_env, batch_size, max_update_cols or 0)
+    mk = lambda actor, lr: create_NNA(na=na, ns=ns, is_actor=actor, init_rng=rng,
+                                      nna_scale=g("nna_scale") if actor else g("nna_scale_critic"),
+                                      drop_middle_layer=g("drop_middle_layer"), learning_rate=lr, dtype=dtype,
+                                      device=device, max_cols=max_cols, stream=stream)
+    behavior_actor = mk(True, g("learning_rate"))
+    behavior_critic = mk(False, g("learning_rate_critic"))
+    target_actor = mk(True, g("learning_rate"))
+    target_critic = mk(False, g("learning_rate_critic"))
+    behavior_actor.copyto(target_actor)            # force sync, :76-77
+    behavior_critic.copyto(target_critic)
+    stride = B * cols_per_env
+    policy = CustomDDPGPolicy(
+        behavior_actor=behavior_actor, behavior_critic=behavior_critic, target_actor=target_actor,
+        target_critic=target_critic, rng=rng, gamma=g("gamma"), rho=g("rho"), batch_size=batch_size,
+        start_steps=g("start_steps"), start_policy=start_policy or ZeroPolicy(setup.action_shape),
+        update_after=g("update_after"), update_freq=g("update_freq"), update_loops=g("update_loops"),
+        act_limit=g("act_limit"), act_noise=g("act_noise"), memory_size=setup.memory_size,
+        number_actuators=cols_per_env, reducer=reducer,
+        quirk_target_broadcast=overrides.get("quirk_target_broadcast", True),
+        noise_seed=overrides.get("noise_seed", 0))
+    trajectory = CircularArraySARTTrajectory(g("trajectory_length") * B, ns, na, stride, torch.device(device))
+    return Agent(policy, trajectory)

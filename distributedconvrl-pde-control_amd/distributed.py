@@ -1,0 +1,62 @@
+"""Data-parallel pieces (the build's addition; the reference is single-process,
+SURVEY.md §2.2/§8e): shard the batch of independent trajectories over one process per GPU and
+sum-all-reduce the flattened actor / critic gradient once per update (RCCL over xGMI via
+torch.distributed's "nccl" backend on GPUs, "gloo" in the CPU tests).  Nothing else crosses
+GPUs; identical ADAM/Polyak steps keep the replicas bit-identical."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, world_size, rank):
+    """contiguous shard [lo, hi) of `total` trajectories for `rank` (remainder to the low ranks)"""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of a library-owned device buffer"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class GradReducer:
+    """all_reduce(model): sums the model's flat gradient buffer over the process group"""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._views = {}
+
+    def _view(self, model):
+        key = int(model.handle.value)
+        if key not in self._views:
+            ptr, n = model.grad_buffer()
+            ts = "<f8" if model.dtype == torch.float64 else "<f4"
+            self._views[key] = torch.as_tensor(_DevArray(ptr, n, ts), device=model.device)
+        return self._views[key]
+
+    def all_reduce(self, model):
+        if self.world_size == 1:
+            return
+        g = self._view(model)
+        stream = model.stream
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def all_reduce_host_grads(grads, group=None):
+    """CPU/gloo form used by the world_size-2 tests: list of numpy arrays summed in place"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return grads
+    flat = torch.cat([torch.as_tensor(g).reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, o = [], 0
+    for g in grads:
+        out.append(flat[o:o + g.size].reshape(g.shape).numpy().copy())
+        o += g.size
+    return out

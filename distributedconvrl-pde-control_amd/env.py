@@ -56,13 +56,19 @@ class PDEenv:
         self.action0 = (torch.zeros(self._ashape, **kw) if action0 is None else self._as_batch(action0, self._ashape))
         self.y = self.y0.clone()
         self._y_next = torch.empty_like(self.y)
-        self.state = torch.empty(self._sshape, **kw)
-        self._state_next = torch.empty_like(self.state)
+        # rings: the previous transition (s_t, a_t, r_t, done_t, s_{t+1}) stays valid while the NEXT
+        # step is in flight, so an update on another stream can read it without a copy
+        self._state_ring = [torch.empty(self._sshape, **kw) for _ in range(3)]
+        self._reward_ring = [torch.zeros((self.B, setup.reward_len), **kw) for _ in range(2)]
+        self._flag_ring = [torch.zeros(self.B, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self._si = self._ri = 0
+        self.state = self._state_ring[0]
         self.action = self.action0.clone()
         self._action_prev = self.action0.clone()
         self.p = torch.zeros((self.B, setup.nx), **kw)
-        self.reward = torch.zeros((self.B, setup.reward_len), **kw)
-        self._done_flags = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.reward = self._reward_ring[0]
+        self._done_flags = self._flag_ring[0]
+        self.prev_state = None
         self.done = torch.zeros(self.B, dtype=torch.bool, device=self.device)
         self.steps, self.time = 0, 0.0
         self.reset()
@@ -143,8 +149,8 @@ class PDEenv:
     # ---- reset!(env), src/PDEenv.jl:183-193
     def reset(self):
         self.y.copy_(self.y0)
-        self.state = self.featurize(self.y, None)
-        self._state_next = torch.empty_like(self.state)
+        _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(self.y), None, _lib.ptr(self.state)))
+        self.prev_state = None
         self.action.copy_(self.action0)
         self._action_prev.copy_(self.action0)
         self.p = self.prepare_action(self.action0)
@@ -158,12 +164,16 @@ class PDEenv:
             action = action.to(self.dtype).reshape(self._ashape).contiguous()
         self._action_prev, self.action = self.action, self._action_prev
         self.action.copy_(action)
+        self._si = (self._si + 1) % 3
+        self._ri ^= 1
+        state_next = self._state_ring[self._si]
+        self.reward, self._done_flags = self._reward_ring[self._ri], self._flag_ring[self._ri]
         _lib.check(self.lib.pdec_env_step(
             self._h, _lib.ptr(self.y), _lib.ptr(self.action), _lib.ptr(self._action_prev), _lib.ptr(self.state),
-            _lib.ptr(self._y_next), _lib.ptr(self.p), _lib.ptr(self._state_next), _lib.ptr(self.reward),
+            _lib.ptr(self._y_next), _lib.ptr(self.p), _lib.ptr(state_next), _lib.ptr(self.reward),
             _lib.ptr(self._done_flags)))
         self.y, self._y_next = self._y_next, self.y
-        self.state, self._state_next = self._state_next, self.state
+        self.prev_state, self.state = self.state, state_next
         self.steps += 1
         self.time += self.dt
         if self.time >= self.te:

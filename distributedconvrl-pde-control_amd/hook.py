@@ -1,0 +1,66 @@
+"""PDEhook mirror (src/PDEhook.jl:8-103): reward bookkeeping, best-episode trajectory log
+(`bestDF` rows timestep/action/p/y/reward), best-actor snapshot.  For B > 1 the episode
+reward is the mean over the batch and the logged rows are those of trajectory 0."""
+import copy
+
+import numpy as np
+
+from .agent import (PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE, POST_EPISODE_STAGE,
+                    POST_EXPERIMENT_STAGE)
+
+
+class PDEhook:
+    def __init__(self, min_best_episode=0, use_random_init=False, collect_history=False, collect_NNA=True,
+                 collect_bestDF=True, is_display_on_exit=False, error_detection=None, init_rng=None):
+        self.rewards, self.rewards_compare = [], []
+        self.reward, self.ep = 0.0, 1
+        self.is_display_on_exit, self.use_random_init = is_display_on_exit, use_random_init
+        self.collect_history, self.collect_NNA, self.collect_bestDF = collect_history, collect_NNA, collect_bestDF
+        self.min_best_episode = min_best_episode
+        self.bestNNA = self.currentNNA = None
+        self.bestDF, self.currentDF = [], []
+        self.bestreward, self.bestepisode = -1000000.0, 0
+        self.history, self.errored_episodes = [], []
+        self.error_detection = error_detection or (lambda y: False)
+        self.init_rng = init_rng or np.random.default_rng(0)
+
+    def __call__(self, stage, agent, env):
+        if stage == PRE_EXPERIMENT_STAGE:                       # PDEhook.jl:35-40
+            if self.collect_NNA and self.currentNNA is None:
+                self.currentNNA = copy.deepcopy(agent.policy.behavior_actor)
+                self.bestNNA = copy.deepcopy(agent.policy.behavior_actor)
+        elif stage == PRE_EPISODE_STAGE:                        # :42-49
+            if self.use_random_init:
+                y0 = env.setup.generate_random_init(self.init_rng, env.B)
+                if y0.ndim == 3:
+                    y0 = np.swapaxes(y0, 1, 2)
+                env.y0 = env._as_batch(y0, env._yshape)
+                env.y.copy_(env.y0)
+                env.state.copy_(env.featurize(env.y, env.state if env.setup.temporal_steps > 1 else None))
+        elif stage == POST_ACT_STAGE:                           # :51-63
+            self.reward += float(env.reward.mean().item())
+            if self.collect_bestDF:
+                self.currentDF.append(dict(timestep=env.steps, action=env.action_julia().reshape(-1),
+                                           p=env.p[0].cpu().numpy().astype(np.float64), y=env.y_julia(),
+                                           reward=env.reward[0].cpu().numpy().astype(np.float64)))
+        elif stage == POST_EPISODE_STAGE:                       # :65-97
+            if env.time >= env.te and self.ep >= self.min_best_episode:
+                self.rewards_compare.append(self.reward)
+                if self.collect_NNA and self.reward >= max(self.rewards_compare):
+                    self.bestNNA.copyto(agent.policy.behavior_actor)
+                    self.bestreward, self.bestepisode = self.reward, self.ep
+                    if self.collect_bestDF:
+                        self.bestDF = list(self.currentDF)
+            if env.time < env.te and self.error_detection(env.y):
+                self.errored_episodes.append(self.ep)
+            if self.collect_history:
+                self.history.append(self.currentDF)
+            self.currentDF = []
+            self.ep += 1
+            self.rewards.append(self.reward)
+            self.reward = 0.0
+            if self.collect_NNA:
+                self.currentNNA.copyto(agent.policy.behavior_actor)
+        elif stage == POST_EXPERIMENT_STAGE:                    # :99-103
+            if self.is_display_on_exit and self.rewards:
+                print("Total reward per episode:", np.round(self.rewards, 4))

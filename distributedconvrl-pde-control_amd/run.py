@@ -1,0 +1,52 @@
+"""The RL.jl run loop the reference relies on (`run(agent, env, stop_condition, hook)`), with
+the stage order replicated in-tree by scripts/Fluid/setup/FluidSetup.jl:436-519, and the
+reference's stop conditions (src/StopCondition.jl:6-40)."""
+from .agent import (PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE, POST_EPISODE_STAGE,
+                    POST_EXPERIMENT_STAGE)
+
+
+class StopAfterEpisode:
+    def __init__(self, episode):
+        self.episode, self.cur = episode, 0
+
+    def __call__(self, agent, env):
+        if env.is_terminated():
+            self.cur += 1
+        return self.cur >= self.episode
+
+
+class StopAfterEpisodeWithMinSteps:
+    """src/StopCondition.jl:6-40: stop at the first episode end after >= `step` steps"""
+
+    def __init__(self, step):
+        self.step, self.cur = step, 1
+
+    def __call__(self, agent, env):
+        stop = self.cur >= self.step and env.is_terminated()     # :31
+        self.cur += 1
+        return stop
+
+
+def run(agent, env, stop_condition, hook):
+    hook(PRE_EXPERIMENT_STAGE, agent, env)
+    agent(PRE_EXPERIMENT_STAGE, env)
+    is_stop = False
+    while not is_stop:
+        env.reset()
+        agent(PRE_EPISODE_STAGE, env)
+        hook(PRE_EPISODE_STAGE, agent, env)
+        while not env.is_terminated():
+            action = agent(env)
+            agent(PRE_ACT_STAGE, env, action)
+            hook(PRE_ACT_STAGE, agent, env)
+            env(action)
+            agent(POST_ACT_STAGE, env)
+            hook(POST_ACT_STAGE, agent, env)
+            if stop_condition(agent, env):
+                is_stop = True
+                break
+        if env.is_terminated():
+            agent(POST_EPISODE_STAGE, env)
+            hook(POST_EPISODE_STAGE, agent, env)
+    hook(POST_EXPERIMENT_STAGE, agent, env)
+    return hook

@@ -1,0 +1,93 @@
+"""GPU tests of the host mirror driving the HIP path: policy act, fused update through
+CustomDDPGPolicy, and the RL.jl-style run loop with PDEhook (B = 1 like the reference, and a
+batched run)."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_policy_update_matches_oracle_and_losses(pkg):
+    from oracle import nn
+    setup = pkg.KSSetup.bench_C2(256)
+    B = 4
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(3))
+    pol = agent.policy
+    rng = np.random.default_rng(4)
+    Bu = 256
+    batch_np = dict(state=rng.standard_normal((Bu, 3)), action=rng.uniform(-1, 1, (Bu, 1)), reward=-rng.uniform(0, 1, Bu),
+                    terminal=(rng.uniform(0, 1, Bu) < 0.1) * 1.0, next_state=rng.standard_normal((Bu, 3)))
+    batch = {k: torch.as_tensor(v, dtype=torch.float32, device="cuda:0") for k, v in batch_np.items()}
+    P = [[p.astype(np.float32) for p in m.params()] for m in (pol.behavior_actor.model, pol.behavior_critic.model,
+                                                                pol.target_actor.model, pol.target_critic.model)]
+    for a, b in zip(P[0], P[2]):
+        assert np.array_equal(a, b)                      # create_agent force-syncs targets (PDEagent.jl:76-77)
+    da, aa = nn.layer_sizes(3, 1, 1.6, True, False)
+    dc, ac = nn.layer_sizes(3, 1, 7.0, False, False)
+    optA, optC = nn.Adam(P[0], 5e-4), nn.Adam(P[1], 1e-3)
+    f32 = lambda k: batch_np[k].astype(np.float32)
+    out = nn.ddpg_update(P[0], P[1], P[2], P[3], optA, optC, aa, ac, f32("state").T, f32("action").T, f32("reward"),
+                         f32("terminal"), f32("next_state").T, np.float32(0.99), np.float32(0.995), True)
+    pol.update(batch)
+    al, cl = pol.losses()
+    assert abs(al - out["actor_loss"]) <= 2e-4 and abs(cl - out["critic_loss"]) <= 2e-4
+    for m, Pr in zip((pol.behavior_actor.model, pol.behavior_critic.model, pol.target_actor.model, pol.target_critic.model), P):
+        for x, y in zip(m.params(), Pr):
+            assert np.abs(x - y).max() <= 2e-4 * max(1.0, np.abs(y).max())
+
+
+def test_acting_path_is_fp64_with_fp32_weights(pkg):
+    """src/PDEagent.jl:184-189: Float64 state promotes the Float32 weights"""
+    from oracle import nn
+    setup = pkg.KSSetup.KS22()
+    env = pkg.PDEenv(setup, B=1, dtype=torch.float64)
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), start_steps=-1)
+    a = agent.policy(env, learning=False)
+    P = agent.policy.behavior_actor.model.params()
+    _, acts = nn.layer_sizes(1, 1, 0.6, True, True)
+    ref = nn.policy_act(P, acts, env.state_julia(), None, 0.0, 1.0, learning=False)
+    assert a.dtype == torch.float64 and np.abs(a.cpu().numpy().reshape(-1) - ref.reshape(-1)).max() <= 1e-13
+
+
+@pytest.mark.parametrize("B", [1, 8])
+def test_run_loop_trains_and_logs(pkg, B):
+    """run(agent, env, stop, hook) with the reference's stage order; KS22 constants, short run"""
+    setup = pkg.KSSetup.KS22(te=1.0, update_loops=2, start_steps=2, update_after=2)
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float32)
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), trajectory_length=2000)
+    hook = pkg.PDEhook(min_best_episode=1, use_random_init=True)
+    before = copy.deepcopy(agent.policy.behavior_actor).params()
+    pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(25), hook)
+    assert len(hook.rewards) == 3 and all(np.isfinite(hook.rewards))
+    # 11 steps per episode: ten additions of dt=0.1 give 0.9999999999999999 < te (same in Julia;
+    # the reference's te=5.0 episodes log 51 rows for the same reason)
+    assert hook.bestepisode >= 1 and len(hook.bestDF) == 11
+    row = hook.bestDF[-1]
+    assert row["y"].shape == (192,) and row["p"].shape == (192,) and row["action"].shape == (8,) and row["reward"].shape == (8,)
+    after = agent.policy.behavior_actor.params()
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(after, before))      # the actor was trained
+    assert len(agent.trajectory) == 33 * 8 * B
+    al, cl = agent.policy.losses()
+    assert np.isfinite(al) and np.isfinite(cl)
+
+
+def test_native_rccl_comm_single_rank(pkg):
+    """pdec_comm_* with nranks = 1: all-reduce of the gradient buffer is the identity"""
+    import ctypes as C
+    lib = pkg._lib.init(0)
+    uid = (C.c_char * 128)()
+    pkg._lib.check(lib.pdec_comm_unique_id(uid))
+    h = pkg._lib.Handle()
+    pkg._lib.check(lib.pdec_comm_create(C.byref(h), 1, 0, uid))
+    net = pkg.HipMLP([3, 16, 1], ["relu", "tanh"], pkg.glorot_uniform(np.random.default_rng(0), [3, 16, 1]), max_cols=32)
+    x = torch.randn(32, 3, device="cuda:0"); dy = torch.randn(32, 1, device="cuda:0")
+    g0, _ = net.backward(x, dy)
+    pkg._lib.check(lib.pdec_allreduce_grads(h, net.handle))
+    torch.cuda.synchronize()
+    red = pkg.distributed.GradReducer()._view(net).cpu().numpy()
+    flat = np.concatenate([g0[0].ravel(), g0[1], g0[2].ravel(), g0[3]])      # internal layout: W row-major
+    assert np.allclose(red, flat, atol=1e-6)
+    pkg._lib.check(lib.pdec_destroy(h))
