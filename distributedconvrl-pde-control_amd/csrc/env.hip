@@ -25,8 +25,13 @@ struct EnvDev {
   int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species;
   T sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
   T dx, hstep;           // K-S: cell size, RK4 sub-step
-  const T* Gt;           // [N][S]  sensor kernels, transposed (coalesced over sensors)
-  const T* Ga;           // [A][N]  actuator kernels
+  // sensor / actuator kernels as circular BAND tables (exact: every non-zero entry of the dense
+  // [S][N] / [A][N] matrices is kept; a kernel whose support is the whole domain gives Wd = N)
+  const T* Gs;           // [Wd][S]   Gs[j][s] = g_s[(sn0[s] + j) mod N]     (coalesced over s)
+  const int* sn0;        // [S]       first cell of sensor s's window
+  const T* GaC;          // [Cnt][N]  GaC[i][n] = ga_{(an0[n]+i) mod A}[n]   (coalesced over n)
+  const int* an0;        // [N]       first actuator reaching cell n
+  int Wd, Cnt;
   const T* gsum;         // [S]     sum of each sensor kernel (reward offset term)
   const int* a2s;        // [A]
   // KS CNAB2 per-mode constants
@@ -38,34 +43,39 @@ struct EnvDev {
 
 struct Env : Object {
   pdec_env_cfg cfg;
-  DevBuf Gt, Ga, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
+  DevBuf Gs, sn0, GaC, an0, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
+  int Wd = 0, Cnt = 0;
   DevBuf stage;  // staging for the _host wrappers
   FftPlan fft;
   int nthreads = 64;
+  int r4_log = 0;        // 4 / 5: N = 256 / 1024 use the register-resident radix-4 FFT engine
   size_t lds_bytes = 0;
   Env() : Object(Kind::Env) {}
 };
 
 // ------------------------------------------------------------------ shared device pieces
 
-// dots[r][s] = sum_n Gt[n][s] * y_r[n] for r in {0,1}; yf(r,n) reads LDS.  Threads are
-// split into groups that each cover a slice of n; partials are combined through `part`.
+// dots[r][s] = sum_j Gs[j][s] * y_r[(sn0[s]+j) mod N] for r in {0,1}; yf(r,n) reads LDS.  Threads
+// are split into groups that each cover a slice of the window; partials are combined via `part`.
 template <class T, class YF>
 __device__ __forceinline__ void sense_dots(const EnvDev<T>& e, YF yf, T* dots, T* part, int tid, int nt) {
-  const int S = e.S, N = e.N;
+  const int S = e.S, N = e.N, Wd = e.Wd;
   int ng = nt / S;
   if (ng < 1) ng = 1;
   if (ng > 8) ng = 8;
-  const int chunk = (N + ng - 1) / ng;
+  const int chunk = (Wd + ng - 1) / ng;
   for (int idx = tid; idx < ng * S; idx += nt) {
     const int grp = idx / S, s = idx - grp * S;
-    int n0 = grp * chunk, n1 = n0 + chunk;
-    if (n1 > N) n1 = N;
+    int j0 = grp * chunk, j1 = j0 + chunk;
+    if (j1 > Wd) j1 = Wd;
+    int n = e.sn0[s] + j0;
+    if (n >= N) n -= N;
     T a0 = 0, a1 = 0;
-    for (int n = n0; n < n1; ++n) {
-      const T gk = e.Gt[(size_t)n * S + s];
+    for (int j = j0; j < j1; ++j) {
+      const T gk = e.Gs[(size_t)j * S + s];
       a0 += gk * yf(0, n);
       a1 += gk * yf(1, n);
+      if (++n == N) n = 0;
     }
     part[(grp * 2 + 0) * S + s] = a0;
     part[(grp * 2 + 1) * S + s] = a1;
@@ -143,12 +153,30 @@ __device__ __forceinline__ void featurize_traj(const EnvDev<T>& e, const T* dots
   }
 }
 
-// p[n] = agent_power * sum_a act[a] * Ga[a][n]
+// p[n] = agent_power * sum_i act[(an0[n]+i) mod A] * GaC[i][n]
 template <class T>
 __device__ __forceinline__ T actuate_cell(const EnvDev<T>& e, const T* act, int n) {
   T acc = 0;
-  for (int a = 0; a < e.A; ++a) acc += act[a] * e.Ga[(size_t)a * e.N + n];
+  int a = e.an0[n];
+  for (int i = 0; i < e.Cnt; ++i) {
+    acc += act[a] * e.GaC[(size_t)i * e.N + n];
+    if (++a == e.A) a = 0;
+  }
   return acc * e.agent_power;
+}
+// two trajectories at once (shared table loads)
+template <class T>
+__device__ __forceinline__ void actuate_cell2(const EnvDev<T>& e, const T* act0, const T* act1, int n, T& p0, T& p1) {
+  T a0 = 0, a1 = 0;
+  int a = e.an0[n];
+  for (int i = 0; i < e.Cnt; ++i) {
+    const T gk = e.GaC[(size_t)i * e.N + n];
+    a0 += act0[a] * gk;
+    a1 += act1[a] * gk;
+    if (++a == e.A) a = 0;
+  }
+  p0 = a0 * e.agent_power;
+  p1 = a1 * e.agent_power;
 }
 
 template <class T>
@@ -169,7 +197,111 @@ __device__ __forceinline__ T block_max(T v, T* red, int tid, int nt) {
 // ------------------------------------------------------------------ KS CNAB2 kernel
 #define KS_MPT 4  // modes / cells owned per thread: k = tid + j*nt
 
-template <class T, bool FUSED>
+// FFT engines: transform the 4 values a thread owns (indices tid + j*nt) in place.
+// Generic engine: mixed-radix Stockham through LDS (any N = 2^a 3^b 5^c).
+template <class T>
+struct FftGeneric {
+  C2<T>*X, *Y;
+  const C2<T>* tw;
+  FftPlan pl;
+  int N, tid, nt;
+  __device__ __forceinline__ void init(unsigned char* smem, const EnvDev<T>& e, int tid_, int nt_) {
+    N = e.N; tid = tid_; nt = nt_; pl = e.fft;
+    X = reinterpret_cast<C2<T>*>(smem);
+    Y = X + N;
+    C2<T>* t = Y + N;
+    for (int k = tid; k < N; k += nt) t[k] = e.tw[k];
+    tw = t;
+  }
+  static __host__ __device__ size_t lds_complex(int N) { return 3 * (size_t)N; }
+  template <int SGN>
+  __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) X[k] = a[j];
+    }
+    C2<T>* R = fft_lds<SGN, T>(X, Y, tw, pl, tid, nt);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) a[j] = R[k];
+    }
+    __syncthreads();
+  }
+  // natural-order complex image of the last result for the sensing stage
+  __device__ __forceinline__ C2<T>* publish(const C2<T> (&a)[KS_MPT]) {
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = tid + j * nt;
+      if (k < N) X[k] = a[j];
+    }
+    __syncthreads();
+    return X;
+  }
+};
+
+// Radix-4 engine for N = 4^L with nt = N/4 threads: in the Stockham DIF form every stage of
+// thread t reads x[t + (N/4) j] -- its own registers for the first stage and conflict-free LDS
+// rows afterwards -- and the last stage lands back on the owned indices, so a transform costs
+// L-1 LDS round trips and L-1 barriers; all twiddles are per-thread constants held in registers.
+template <class T, int L>
+struct FftR4 {
+  C2<T>* buf[2];
+  C2<T> w[L - 1][3];
+  int tid, par;
+  static constexpr int N = 1 << (2 * L), NT = N / 4;
+  __device__ __forceinline__ void init(unsigned char* smem, const EnvDev<T>& e, int tid_, int) {
+    tid = tid_; par = 0;
+    buf[0] = reinterpret_cast<C2<T>*>(smem);
+    buf[1] = buf[0] + N;
+#pragma unroll
+    for (int st = 0; st < L - 1; ++st) {
+      const int s = 1 << (2 * st);
+      const int base = tid & ~(s - 1);          // p*s
+#pragma unroll
+      for (int k = 1; k < 4; ++k) w[st][k - 1] = e.tw[base * k];
+    }
+  }
+  static __host__ __device__ size_t lds_complex(int) { return 2 * (size_t)N; }
+  template <int SGN>
+  __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
+#pragma unroll
+    for (int st = 0; st < L; ++st) {
+      if (st > 0) {
+        const C2<T>* in = buf[par ^ ((st - 1) & 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = in[tid + NT * j];
+      }
+      dft_small<4, SGN, T>(a);
+      if (st < L - 1) {
+        const int s = 1 << (2 * st);
+        const int q = tid & (s - 1);
+        const int ob = q + 4 * (tid - q);       // q + 4 s p
+        C2<T>* out = buf[par ^ (st & 1)];
+        out[ob] = a[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          C2<T> tw = w[st][k - 1];
+          if (SGN > 0) tw.y = -tw.y;
+          out[ob + s * k] = cmul(a[k], tw);
+        }
+        __syncthreads();
+      }
+    }
+    if ((L - 1) & 1) par ^= 1;                  // next transform starts on the buffer not read last
+  }
+  __device__ __forceinline__ C2<T>* publish(const C2<T> (&a)[KS_MPT]) {
+    __syncthreads();
+    C2<T>* X = buf[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X[tid + NT * j] = a[j];
+    __syncthreads();
+    return X;
+  }
+};
+
+template <class T, class ENG, bool FUSED>
 __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
                                    const T* __restrict__ action, const T* __restrict__ action_prev,
                                    const T* __restrict__ state_prev, T* __restrict__ y_out,
@@ -177,11 +309,10 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
                                    T* __restrict__ reward_out, int32_t* __restrict__ done) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = e.N, tid = threadIdx.x, nt = blockDim.x;
-  C2<T>* X = reinterpret_cast<C2<T>*>(smem_raw);
-  C2<T>* Y = X + N;
-  C2<T>* tw = Y + N;
-  T* act = reinterpret_cast<T*>(tw + N);  // [2][A] current, then [2][A] previous
-  T* actp = act + 2 * e.A;
+  ENG eng;
+  eng.init(smem_raw, e, tid, nt);
+  T* act = reinterpret_cast<T*>(reinterpret_cast<C2<T>*>(smem_raw) + ENG::lds_complex(N));  // [2][A] current
+  T* actp = act + 2 * e.A;                // [2][A] previous
   T* dots = actp + 2 * e.A;               // [2][S]
   T* part = dots + 2 * e.S;               // [8][2][S]
   T* red = part + 16 * e.S;               // [16]
@@ -190,7 +321,6 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   const bool has1 = b1 < e.B;
   const size_t o0 = (size_t)b0 * N, o1 = (size_t)b1 * N;
 
-  for (int k = tid; k < N; k += nt) tw[k] = e.tw[k];
   if (FUSED) {
     for (int a = tid; a < e.A; a += nt) {
       act[a] = action[(size_t)b0 * e.A + a];
@@ -201,15 +331,17 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   }
   __syncthreads();
 
-  // forcing p (packed) -> X
+  C2<T> U[KS_MPT], Nn[KS_MPT], Ck[KS_MPT], v[KS_MPT];
+  T kc1[KS_MPT], kc2[KS_MPT], kc3[KS_MPT], kg[KS_MPT];
+  // forcing p (packed pair) -> spectrum -> constant term of the CNAB2 update
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
     const int n = tid + j * nt;
+    T pa = 0, pb = 0;
     if (n < N) {
-      T pa, pb;
       if (FUSED) {
-        pa = actuate_cell<T>(e, act, n);
-        pb = has1 ? actuate_cell<T>(e, act + e.A, n) : (T)0;
+        actuate_cell2<T>(e, act, act + e.A, n, pa, pb);
+        if (!has1) pb = 0;
         if (p_out) {
           p_out[o0 + n] = pa;
           if (has1) p_out[o1 + n] = pb;
@@ -218,113 +350,71 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
         pa = p_in[o0 + n];
         pb = has1 ? p_in[o1 + n] : (T)0;
       }
-      X[n] = mk<T>(pa, pb);
     }
+    v[j] = mk<T>(pa, pb);
   }
-  C2<T> U[KS_MPT], Nn[KS_MPT], Ck[KS_MPT];
-  T kc1[KS_MPT], kc2[KS_MPT], kc3[KS_MPT], kg[KS_MPT];
-  {
-    C2<T>* R = fft_lds<-1, T>(X, Y, tw, e.fft, tid, nt);
-#pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const int k = tid + j * nt;
-      if (k < N) {
-        const C2<T> d = e.dhat[k];
-        const T c4 = e.c4[k];
-        // (1+i)*dhat: the same real disturbance enters both packed trajectories
-        Ck[j] = mk<T>(c4 * R[k].x + (d.x - d.y), c4 * R[k].y + (d.x + d.y));
-        kc1[j] = e.c1[k];
-        kc2[j] = e.c2[k];
-        kc3[j] = e.c3[k];
-        kg[j] = e.g[k];
-      }
-    }
-    __syncthreads();
-  }
-  // Nn = G * fft(u^2)
-  C2<T> yv[KS_MPT];
-#pragma unroll
-  for (int j = 0; j < KS_MPT; ++j) {
-    const int n = tid + j * nt;
-    if (n < N) {
-      yv[j] = mk<T>(y_in[o0 + n], has1 ? y_in[o1 + n] : (T)0);
-      X[n] = mk<T>(yv[j].x * yv[j].x, yv[j].y * yv[j].y);
-    }
-  }
-  {
-    C2<T>* R = fft_lds<-1, T>(X, Y, tw, e.fft, tid, nt);
-#pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const int k = tid + j * nt;
-      if (k < N) Nn[j] = cscale(mul_i<+1, T>(R[k]), kg[j]);  // G = i * (-alpha/2)
-    }
-    __syncthreads();
-  }
-  // u_hat = fft(u)
-#pragma unroll
-  for (int j = 0; j < KS_MPT; ++j) {
-    const int n = tid + j * nt;
-    if (n < N) X[n] = yv[j];
-  }
-  {
-    C2<T>* R = fft_lds<-1, T>(X, Y, tw, e.fft, tid, nt);
-#pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const int k = tid + j * nt;
-      if (k < N) U[j] = R[k];
-    }
-    __syncthreads();
-  }
-  const T invN = (T)1 / (T)N;
-  for (int it = 0; it < e.K; ++it) {
-#pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const int k = tid + j * nt;
-      if (k < N) X[k] = U[j];
-    }
-    C2<T>* R = fft_lds<+1, T>(X, Y, tw, e.fft, tid, nt);
-    C2<T>* O = (R == X) ? Y : X;  // write squares into the other buffer
-#pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const int n = tid + j * nt;
-      if (n < N) {
-        const T wr = R[n].x * invN, wi = R[n].y * invN;
-        O[n] = mk<T>(wr * wr, wi * wi);
-      }
-    }
-    C2<T>* R2 = fft_lds<-1, T>(O, R, tw, e.fft, tid, nt);
-#pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const int k = tid + j * nt;
-      if (k < N) {
-        const C2<T> nn1 = Nn[j];
-        Nn[j] = cscale(mul_i<+1, T>(R2[k]), kg[j]);
-        U[j] = mk<T>(kc1[j] * U[j].x + kc2[j] * Nn[j].x - kc3[j] * nn1.x + Ck[j].x,
-                     kc1[j] * U[j].y + kc2[j] * Nn[j].y - kc3[j] * nn1.y + Ck[j].y);
-      }
-    }
-    __syncthreads();
-  }
-  // y+ = real(ifft(u_hat))
+  eng.template run<-1>(v);
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
     const int k = tid + j * nt;
-    if (k < N) X[k] = U[j];
+    if (k < N) {
+      const C2<T> d = e.dhat[k];
+      const T c4 = e.c4[k];
+      // (1+i)*dhat: the same real disturbance enters both packed trajectories
+      Ck[j] = mk<T>(c4 * v[j].x + (d.x - d.y), c4 * v[j].y + (d.x + d.y));
+      kc1[j] = e.c1[k];
+      kc2[j] = e.c2[k];
+      kc3[j] = e.c3[k];
+      kg[j] = e.g[k];
+    } else {
+      Ck[j] = mk<T>(0, 0);
+      kc1[j] = kc2[j] = kc3[j] = kg[j] = 0;
+    }
   }
-  C2<T>* R = fft_lds<+1, T>(X, Y, tw, e.fft, tid, nt);
+  // Nn = G * fft(u^2);  u_hat = fft(u)
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {
+    const int n = tid + j * nt;
+    U[j] = n < N ? mk<T>(y_in[o0 + n], has1 ? y_in[o1 + n] : (T)0) : mk<T>(0, 0);
+    v[j] = mk<T>(U[j].x * U[j].x, U[j].y * U[j].y);
+  }
+  eng.template run<-1>(v);
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) Nn[j] = cscale(mul_i<+1, T>(v[j]), kg[j]);   // G = i * (-alpha/2)
+  eng.template run<-1>(U);
+  const T invN = (T)1 / (T)N;
+  for (int it = 0; it < e.K; ++it) {
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) v[j] = U[j];
+    eng.template run<+1>(v);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const T wr = v[j].x * invN, wi = v[j].y * invN;
+      v[j] = mk<T>(wr * wr, wi * wi);
+    }
+    eng.template run<-1>(v);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const C2<T> nn1 = Nn[j];
+      Nn[j] = cscale(mul_i<+1, T>(v[j]), kg[j]);
+      U[j] = mk<T>(kc1[j] * U[j].x + kc2[j] * Nn[j].x - kc3[j] * nn1.x + Ck[j].x,
+                   kc1[j] * U[j].y + kc2[j] * Nn[j].y - kc3[j] * nn1.y + Ck[j].y);
+    }
+  }
+  // y+ = real(ifft(u_hat))
+  eng.template run<+1>(U);
   T mx0 = 0, mx1 = 0;
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
     const int n = tid + j * nt;
+    U[j] = mk<T>(U[j].x * invN, U[j].y * invN);
     if (n < N) {
-      const T ya = R[n].x * invN, yb = R[n].y * invN;
-      R[n] = mk<T>(ya, yb);
-      y_out[o0 + n] = ya;
-      if (has1) y_out[o1 + n] = yb;
+      y_out[o0 + n] = U[j].x;
+      if (has1) y_out[o1 + n] = U[j].y;
       // blow-up test max|y| > max_value (src/PDEenv.jl:227); a NaN also raises the flag
       // (deliberate deviation: Julia's `NaN > max_value` is false and the run would go on)
-      if (!(fabs(ya) <= e.max_value)) mx0 = 1;
-      if (!(fabs(yb) <= e.max_value)) mx1 = 1;
+      if (!(fabs(U[j].x) <= e.max_value)) mx0 = 1;
+      if (!(fabs(U[j].y) <= e.max_value)) mx1 = 1;
     }
   }
   if (done) {
@@ -337,8 +427,7 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
     }
   }
   if (!FUSED) return;
-  __syncthreads();
-  const T* Rt = reinterpret_cast<const T*>(R);
+  const T* Rt = reinterpret_cast<const T*>(eng.publish(U));
   sense_dots<T>(e, [&](int r, int n) { return Rt[2 * n + r]; }, dots, part, tid, nt);
   const int rw = e.mono ? 1 : e.A;             // reward entries per trajectory
   const int sw = e.mono ? e.S : e.A * e.ns;    // state entries per trajectory
@@ -537,16 +626,18 @@ static EnvDev<T> make_dev(const Env& E) {
   e.max_value = (T)c.max_value;
   e.dx = (T)(c.Lx / c.N);
   e.hstep = (T)(c.dt / c.K);
-  e.Gt = E.Gt.as<T>(); e.Ga = E.Ga.as<T>(); e.gsum = E.gsum.as<T>(); e.a2s = E.a2s.as<int>();
+  e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
+  e.Wd = E.Wd; e.Cnt = E.Cnt;
+  e.gsum = E.gsum.as<T>(); e.a2s = E.a2s.as<int>();
   e.c1 = E.c1.as<T>(); e.c2 = E.c2.as<T>(); e.c3 = E.c3.as<T>(); e.c4 = E.c4.as<T>(); e.g = E.g.as<T>();
   e.dhat = E.dhat.as<C2<T>>(); e.tw = E.tw.as<C2<T>>();
   e.fft = E.fft;
   return e;
 }
 
-static size_t ks_lds_bytes(const pdec_env_cfg& c) {
+static size_t ks_lds_bytes(const pdec_env_cfg& c, int r4_log) {
   const size_t ts = dtype_size(c.dtype);
-  return 3 * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
+  return (r4_log ? 2 : 3) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
 }
 static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
@@ -557,6 +648,7 @@ static size_t sense_lds_bytes(const pdec_env_cfg& c) {
   return (2 * (size_t)c.N + 2 * c.A + 2 * c.S + 16 * c.S) * ts;
 }
 
+#define COMMA ,
 template <class T>
 static int launch_step(Env& E, bool fused, int mode, const void* y_in, const void* p, const void* action,
                        const void* action_prev, const void* state_prev, void* y_out, void* p_out,
@@ -566,14 +658,14 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
   if (c.pde_kind == PDEC_PDE_KS_CNAB2) {
     dim3 grid((c.B + 1) / 2), block(E.nthreads);
     ProfScope ps(&E, fused ? "ks_env_step" : "ks_pde_step");
-    if (fused)
-      hipLaunchKernelGGL((ks_env_step_kernel<T, true>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,
-                         (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,
-                         (T*)p_out, (T*)state_out, (T*)reward_out, done);
-    else
-      hipLaunchKernelGGL((ks_env_step_kernel<T, false>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,
-                         (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,
-                         (T*)p_out, (T*)state_out, (T*)reward_out, done);
+#define KS_LAUNCH(ENG, F)                                                                                      \
+  hipLaunchKernelGGL((ks_env_step_kernel<T, ENG, F>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,    \
+                     (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,    \
+                     (T*)p_out, (T*)state_out, (T*)reward_out, done)
+    if (E.r4_log == 4) { if (fused) KS_LAUNCH(FftR4<T COMMA 4>, true); else KS_LAUNCH(FftR4<T COMMA 4>, false); }
+    else if (E.r4_log == 5) { if (fused) KS_LAUNCH(FftR4<T COMMA 5>, true); else KS_LAUNCH(FftR4<T COMMA 5>, false); }
+    else { if (fused) KS_LAUNCH(FftGeneric<T>, true); else KS_LAUNCH(FftGeneric<T>, false); }
+#undef KS_LAUNCH
   } else if (c.pde_kind == PDEC_PDE_KSEG_RK4) {
     dim3 grid(c.B), block(E.nthreads);
     ProfScope ps(&E, mode == 0 ? "kseg_env_step" : (mode == 1 ? "kseg_pde_step" : "kseg_rhs"));
@@ -642,7 +734,8 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
     int nt = ((N + KS_MPT - 1) / KS_MPT + 63) / 64 * 64;
     PDEC_REQUIRE(nt <= 1024, "N=%d too large for the in-LDS KS kernel (max 4096)", N);
     E->nthreads = nt;
-    E->lds_bytes = ks_lds_bytes(c);
+    E->r4_log = (N == 256 && !getenv("PDEC_KS_GENERIC_FFT")) ? 4 : ((N == 1024 && !getenv("PDEC_KS_GENERIC_FFT")) ? 5 : 0);
+    E->lds_bytes = ks_lds_bytes(c, E->r4_log);
     PDEC_REQUIRE(E->lds_bytes <= 160 * 1024, "KS kernel needs %zu B of LDS (> 160 KiB)", E->lds_bytes);
     // per-mode constants, scripts/KS/setup/KSSetup.jl:115-123,131-135
     std::vector<double> c1(N), c2(N), c3(N), c4(N), g(N), dh(2 * N), tw(2 * N), dist(N);
@@ -688,17 +781,53 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
     return PDEC_E_INVALID;
   }
   PDEC_REQUIRE(sense_lds_bytes(c) <= 160 * 1024, "sensor kernels need too much LDS");
-  // tables
-  std::vector<double> Gt((size_t)N * c.S), gs(c.S, 0.0);
-  for (int s = 0; s < c.S; ++s)
-    for (int n = 0; n < N; ++n) {
-      Gt[(size_t)n * c.S + s] = sensor_kernels[(size_t)s * N + n];
-      gs[s] += sensor_kernels[(size_t)s * N + n];
+  // tables: circular band form of the dense kernels.  An entry counts as non-zero if it is non-zero
+  // in the plan's dtype, so the band product equals the dense product term by term.
+  auto nz = [&](double v) { return c.dtype == PDEC_F64 ? v != 0.0 : (float)v != 0.0f; };
+  // window of a circular 0/1 pattern: start after the longest run of zeros
+  auto window = [&](const std::vector<char>& m, int& start, int& len) {
+    const int n = (int)m.size();
+    int best = -1, bestpos = 0, run = 0;
+    bool any = false;
+    for (int i = 0; i < n; ++i) any |= m[i] != 0;
+    if (!any) { start = 0; len = 0; return; }
+    for (int i = 0; i < 2 * n; ++i) {       // longest zero run on the ring
+      if (!m[i % n]) { if (++run > best && run <= n) { best = run; bestpos = i; } }
+      else run = 0;
     }
+    if (best <= 0) { start = 0; len = n; return; }
+    start = (bestpos + 1) % n;
+    len = n - best;
+  };
+  std::vector<double> gs(c.S, 0.0);
+  std::vector<int32_t> sn0(c.S), slen(c.S), an0(N), alen(N);
+  int Wd = 1, Cnt = 1;
+  for (int s = 0; s < c.S; ++s) {
+    std::vector<char> m(N);
+    for (int n = 0; n < N; ++n) { m[n] = nz(sensor_kernels[(size_t)s * N + n]); gs[s] += sensor_kernels[(size_t)s * N + n]; }
+    int st, ln; window(m, st, ln);
+    sn0[s] = st; slen[s] = ln; Wd = std::max(Wd, ln);
+  }
+  for (int n = 0; n < N; ++n) {
+    std::vector<char> m(c.A);
+    for (int a = 0; a < c.A; ++a) m[a] = nz(actuator_kernels[(size_t)a * N + n]);
+    int st, ln; window(m, st, ln);
+    an0[n] = st; alen[n] = ln; Cnt = std::max(Cnt, ln);
+  }
+  std::vector<double> Gs((size_t)Wd * c.S, 0.0), GaC((size_t)Cnt * N, 0.0);
+  for (int s = 0; s < c.S; ++s)
+    for (int j = 0; j < slen[s]; ++j) Gs[(size_t)j * c.S + s] = sensor_kernels[(size_t)s * N + (sn0[s] + j) % N];
+  for (int n = 0; n < N; ++n)
+    for (int i = 0; i < alen[n]; ++i) GaC[(size_t)i * N + n] = actuator_kernels[(size_t)((an0[n] + i) % c.A) * N + n];
+  E->Wd = Wd; E->Cnt = Cnt;
   int rc;
-  if ((rc = upload_converted(E->Gt, Gt.data(), Gt.size(), c.dtype))) return rc;
+  if ((rc = upload_converted(E->Gs, Gs.data(), Gs.size(), c.dtype))) return rc;
+  if ((rc = upload_converted(E->GaC, GaC.data(), GaC.size(), c.dtype))) return rc;
   if ((rc = upload_converted(E->gsum, gs.data(), gs.size(), c.dtype))) return rc;
-  if ((rc = upload_converted(E->Ga, actuator_kernels, (size_t)c.A * N, c.dtype))) return rc;
+  PDEC_HIP(E->sn0.alloc(sizeof(int32_t) * c.S));
+  PDEC_HIP(hipMemcpy(E->sn0.p, sn0.data(), sizeof(int32_t) * c.S, hipMemcpyHostToDevice));
+  PDEC_HIP(E->an0.alloc(sizeof(int32_t) * N));
+  PDEC_HIP(hipMemcpy(E->an0.p, an0.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
   PDEC_HIP(E->a2s.alloc(sizeof(int32_t) * c.A));
   PDEC_HIP(hipMemcpy(E->a2s.p, a2s_h.data(), sizeof(int32_t) * c.A, hipMemcpyHostToDevice));
   *h = register_object(std::move(E));

@@ -491,6 +491,7 @@ static int set_flat(Mlp* M, DevBuf& buf, const void* host) {
   else julia_to_internal<float>(*M, (const float*)host, (float*)tmp.data());
   PDEC_HIP(hipMemcpyAsync(buf.p, tmp.data(), n * ts, hipMemcpyHostToDevice, M->stream));
   PDEC_HIP(hipStreamSynchronize(M->stream));
+  M->fw_dirty = true;
   return PDEC_OK;
 }
 static int get_flat(Mlp* M, const DevBuf& buf, void* host) {
@@ -557,6 +558,7 @@ int pdec_mlp_copy(pdec_handle dst, pdec_handle src) {
     hipLaunchKernelGGL((cast_copy_kernel<float, double>), grid, block, 0, D->stream, D->params.as<float>(), S->params.as<double>(), n);
   }
   PDEC_HIP(hipGetLastError());
+  D->fw_dirty = true;
   return PDEC_OK;
 }
 
@@ -629,6 +631,7 @@ int pdec_adam_step(pdec_handle h, double eta, double beta1, double beta2, double
                          M->m.as<float>(), M->v.as<float>(), n, eta, beta1, beta2, eps, 1.0 - M->bp[0], 1.0 - M->bp[1]);
   }
   PDEC_HIP(hipGetLastError());
+  M->fw_dirty = true;
   M->bp[0] *= beta1;
   M->bp[1] *= beta2;
   return PDEC_OK;
@@ -668,6 +671,7 @@ int pdec_polyak(pdec_handle dst, pdec_handle src, double rho) {
     hipLaunchKernelGGL((polyak_kernel<float>), grid, block, 0, D->stream, D->params.as<float>(), S->params.as<float>(), n, r, 1.0f - r);
   }
   PDEC_HIP(hipGetLastError());
+  D->fw_dirty = true;
   return PDEC_OK;
 }
 
@@ -779,6 +783,9 @@ int pdec_ddpg_critic_grads(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec
   GET_MLP(Ct, hCt);
   PDEC_REQUIRE(s && a && r && t && snext && Bu >= 1, "pdec_ddpg_critic_grads: null/empty batch");
   PDEC_REQUIRE(A->dtype == C->dtype && At->dtype == C->dtype && Ct->dtype == C->dtype, "ddpg: dtype mismatch");
+  PDEC_REQUIRE(At->dims == A->dims && Ct->dims == C->dims, "ddpg: target networks must have the behaviour networks' shapes");
+  if (fused_supported(A, C) && A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream)
+    return fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev);
   return C->dtype == PDEC_F64
              ? critic_grads_t<double>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev)
              : critic_grads_t<float>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev);
@@ -789,6 +796,7 @@ int pdec_ddpg_actor_grads(pdec_handle hA, pdec_handle hC, const void* s, int Bu,
   GET_MLP(C, hC);
   PDEC_REQUIRE(s && Bu >= 1, "pdec_ddpg_actor_grads: null/empty batch");
   PDEC_REQUIRE(A->dtype == C->dtype, "ddpg: dtype mismatch");
+  if (fused_supported(A, C) && A->stream == C->stream) return fused_actor_grads(A, C, s, Bu, grad_scale, actor_loss_dev);
   return C->dtype == PDEC_F64 ? actor_grads_t<double>(A, C, s, Bu, grad_scale, actor_loss_dev)
                               : actor_grads_t<float>(A, C, s, Bu, grad_scale, actor_loss_dev);
 }

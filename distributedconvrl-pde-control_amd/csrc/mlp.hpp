@@ -18,6 +18,8 @@ struct Mlp : Object {
   DevBuf slabs;                      // split-K partial weight gradients
   DevBuf scratch;                    // loss statistics / device scalars
   int kchunk = 512, nsplit_max = 0, dx_index = 0;
+  DevBuf fw, fslab;                  // fused-path padded weight image / per-workgroup gradient slabs
+  bool fw_dirty = true;
 
   Mlp() : Object(Kind::Mlp) {}
   int init(int dtype, int L, const int32_t* dims, const int32_t* acts, int max_cols);
@@ -30,5 +32,11 @@ struct Mlp : Object {
   template <class T>
   T* dy_buf(int) { return dy.as<T>(); }
 };
+
+// mlp_mfma.hip: fused fp32 MFMA DDPG passes (3-layer actor/critic pairs)
+bool fused_supported(const Mlp* A, const Mlp* C);
+int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
+                       const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev);
+int fused_actor_grads(Mlp* A, Mlp* C, const void* s, int Bu, double grad_scale, void* loss_dev);
 
 }  // namespace pdec

@@ -1,0 +1,731 @@
+// mlp_mfma.hip -- fused fp32 MFMA path of the DDPG update for 3-layer actor/critic pairs
+// (the "conv im2col-GEMM where channels x kernel forms a dense contraction": the critic's
+// H x H hidden layer over B*A columns).  Restates src/PDEagent.jl:385-409 in two launches:
+//
+//   ddpg_critic_fused_kernel : a' = At(s'), qt = Ct([s';a']), q = C([s;a]), loss statistics,
+//                              dq, full critic backward (dW1,db1,dW2,db2,dW3,db3) -> per-WG slab
+//   ddpg_actor_fused_kernel  : a = A(s), q = C([s;a]) with the UPDATED critic, -mean(q),
+//                              backward through the critic to da, full actor backward -> slab
+//   fused_reduce_kernel      : deterministic sum of the per-workgroup slabs into the flat
+//                              gradient buffer (replicas stay bit-identical), loss finalisation
+//
+// Design (gfx950): one workgroup = 8 waves = 128 columns, each wave owns 16 columns for the
+// whole pass.  v_mfma_f32_16x16x4_f32 (exact f32, 64 FLOP/clk/SIMD = the f32 peak): a layer
+// output tile D[16 rows][16 cols] lives in 4 VGPRs per lane (col = lane&15, row = 4*(lane>>4)+r)
+// and is fed STRAIGHT back as the B operand of the next layer -- the contraction index is
+// permuted (k = 16m + 4*(lane>>4) + r) so no lane movement or LDS round trip is needed; the
+// matching A operand (4 consecutive k of one weight row) is one ds_read_b128 from the padded
+// weight image in LDS.  Backward-to-input uses a pre-transposed weight image the same way.
+// Weight gradients contract over COLUMNS, which sit on the wrong lane axis, so activations
+// and dz are transposed once through LDS ([feature][col] images, 64-column halves) and the
+// per-workgroup dW tiles are again MFMA products; bias gradients ride along as an appended
+// row of ones.  HBM traffic: the 5 input arrays once, one slab per workgroup out.
+#include "common.hpp"
+#include "mlp.hpp"
+
+namespace pdec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FCOLS 128          // columns per workgroup
+#define FTHREADS 512
+#define LDP 68             // leading dim of the 64-column LDS transposition images
+#define KXP 16             // padded input rows (ns+na+1 <= 16)
+#define LDW1 20            // LDS leading dim of W1 images
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// padded weight image of one 3-layer net [K0, H, H, 1] (device, floats)
+struct FNet {
+  const float* w;   // base
+  int K0, H, HP, LDW;
+  int oW1, ob1, oW2, oW2T, ob2, ow3, ob3, total;
+};
+
+static FNet make_fnet_layout(int K0, int H) {
+  FNet f{};
+  f.K0 = K0; f.H = H;
+  f.HP = (H + 1 + 15) / 16 * 16;
+  f.LDW = f.HP + 4;
+  int o = 0;
+  f.oW1 = o; o += f.HP * KXP;
+  f.ob1 = o; o += f.HP;
+  f.oW2 = o; o += f.HP * f.LDW;
+  f.oW2T = o; o += f.HP * f.LDW;
+  f.ob2 = o; o += f.HP;
+  f.ow3 = o; o += f.HP;
+  f.ob3 = o; o += 4;
+  f.total = o;
+  return f;
+}
+
+// builds the padded image from the internal flat parameters [W1 row-major, b1, W2, b2, W3, b3]
+__global__ void prep_fused_kernel(const float* __restrict__ p, float* __restrict__ out, FNet f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f.total) return;
+  const int K0 = f.K0, H = f.H;
+  const int pW1 = 0, pb1 = H * K0, pW2 = pb1 + H, pb2 = pW2 + H * H, pW3 = pb2 + H, pb3 = pW3 + H;
+  float v = 0.f;
+  if (i < f.ob1) { const int r = (i - f.oW1) / KXP, c = (i - f.oW1) % KXP; if (r < H && c < K0) v = p[pW1 + r * K0 + c]; }
+  else if (i < f.oW2) { const int r = i - f.ob1; if (r < H) v = p[pb1 + r]; }
+  else if (i < f.oW2T) { const int r = (i - f.oW2) / f.LDW, c = (i - f.oW2) % f.LDW; if (r < H && c < H) v = p[pW2 + r * H + c]; }
+  else if (i < f.ob2) { const int r = (i - f.oW2T) / f.LDW, c = (i - f.oW2T) % f.LDW; if (r < H && c < H) v = p[pW2 + c * H + r]; }
+  else if (i < f.ow3) { const int r = i - f.ob2; if (r < H) v = p[pb2 + r]; }
+  else if (i < f.ob3) { const int r = i - f.ow3; if (r < H) v = p[pW3 + r]; }
+  else { if (i == f.ob3) v = p[pb3]; }
+  out[i] = v;
+}
+
+// ------------------------------------------------------------------ device building blocks
+// LDS image of the "small" part of a net: W1 [HP][LDW1], b1 [HP], b2 [HP], w3 [HP], b3 [4]
+struct SmallLds {
+  float *W1, *b1, *b2, *w3, *b3;
+};
+__device__ __forceinline__ SmallLds carve_small(float* base, int HP) {
+  SmallLds s;
+  s.W1 = base; s.b1 = s.W1 + HP * LDW1; s.b2 = s.b1 + HP; s.w3 = s.b2 + HP; s.b3 = s.w3 + HP;
+  return s;
+}
+static inline int small_floats(int HP) { return HP * LDW1 + 3 * HP + 4; }
+// floats of the big region: the padded W2 image, or the staging images that later overlay it
+__host__ __device__ constexpr int wreg_floats(int MT, int MTA) {
+  const int HP = 16 * MT, HPa = 16 * MTA;
+  int a = HP * (HP + 4), b = 2 * HP * LDP, c = (32 + 4 * HPa) * LDP;
+  int m = a > b ? a : b;
+  return m > c ? m : c;
+}
+
+__device__ __forceinline__ void load_small(const SmallLds& s, const FNet& f, int tid) {
+  for (int i = tid; i < f.HP * KXP; i += FTHREADS) s.W1[(i / KXP) * LDW1 + (i % KXP)] = f.w[f.oW1 + i];
+  for (int i = tid; i < f.HP; i += FTHREADS) { s.b1[i] = f.w[f.ob1 + i]; s.b2[i] = f.w[f.ob2 + i]; s.w3[i] = f.w[f.ow3 + i]; }
+  if (tid < 4) s.b3[tid] = f.w[f.ob3 + tid];
+}
+__device__ __forceinline__ void load_big(float* dst, const float* src, int n, int tid) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+  for (int i = tid; i < n / 4; i += FTHREADS) d4[i] = s4[i];
+}
+
+// h = relu(W1 x + b1): x given as KT register rows (lane holds x[4t+q][col])
+template <int MT, int KT>
+__device__ __forceinline__ void layer_in(f32x4 (&h)[MT], const float (&x)[KT], const SmallLds& s, int lr, int q) {
+#pragma unroll
+  for (int mo = 0; mo < MT; ++mo) {
+    const float* b = s.b1 + 16 * mo + 4 * q;
+    f32x4 acc = {b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc = mfma4(s.W1[(16 * mo + lr) * LDW1 + 4 * t + q], x[t], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+    h[mo] = acc;
+  }
+}
+
+// out = W in (+ bias): W image row-major [..][ldw] in LDS, 4 consecutive k per ds_read_b128
+template <int MTO, int MTI, bool BIAS>
+__device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MTI], const float* W, int ldw,
+                                         const float* bias, int lr, int q) {
+#pragma unroll
+  for (int mo = 0; mo < MTO; ++mo) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS) {
+      const float* b = bias + 16 * mo + 4 * q;
+      acc = f32x4{b[0], b[1], b[2], b[3]};
+    }
+    const float* wrow = W + (16 * mo + lr) * ldw + 4 * q;
+#pragma unroll
+    for (int m = 0; m < MTI; ++m) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 16 * m);
+      acc = mfma4(wv[0], in[m][0], acc);
+      acc = mfma4(wv[1], in[m][1], acc);
+      acc = mfma4(wv[2], in[m][2], acc);
+      acc = mfma4(wv[3], in[m][3], acc);
+    }
+    out[mo] = acc;
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void relu_(f32x4 (&h)[MT]) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.f);
+}
+
+// scalar head: b3 + sum_rows w3[row] * h[row][col]; every lane of a column gets the result
+template <int MT>
+__device__ __forceinline__ float head(const f32x4 (&h)[MT], const float* w3, float b3, int q) {
+  float acc = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float* w = w3 + 16 * m + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc += w[r] * h[m][r];
+  }
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  return acc + b3;
+}
+
+// dz[row][col] = w3[row] * g[col] * (h > 0)
+template <int MT>
+__device__ __forceinline__ void head_bwd(f32x4 (&dz)[MT], const f32x4 (&h)[MT], const float* w3, float g, int q) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float* w = w3 + 16 * m + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dz[m][r] = h[m][r] > 0.f ? w[r] * g : 0.f;
+  }
+}
+
+// write a D-layout activation (MT tiles) into a [feature][LDP] LDS image at column cw;
+// ones_row >= 0 additionally sets that row to 1 (bias gradient rides the GEMM)
+template <int MT>
+__device__ __forceinline__ void stage_rows(float* img, const f32x4 (&v)[MT], int cw, int q, int ones_row) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * m + 4 * q + r;
+      img[row * LDP + cw] = row == ones_row ? 1.f : v[m][r];
+    }
+}
+
+// D[i][k] += sum over the 64 staged columns L[i][c] * R[k][c]; wave w takes tile pairs w, w+8, ...
+template <int NACC>
+__device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NACC], const float* L, const float* R, int nL, int nR, int w,
+                                          int lr, int q) {
+#pragma unroll
+  for (int pp = 0; pp < NACC; ++pp) {
+    const int p = w + 8 * pp;
+    if (p < nL * nR) {
+      const int ti = p / nR, tk = p - ti * nR;
+      const float* lrow = L + (16 * ti + lr) * LDP + 4 * q;
+      const float* rrow = R + (16 * tk + lr) * LDP + 4 * q;
+      f32x4 a = acc[pp];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(lrow + 16 * t);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(rrow + 16 * t);
+        a = mfma4(av[0], bv[0], a);
+        a = mfma4(av[1], bv[1], a);
+        a = mfma4(av[2], bv[2], a);
+        a = mfma4(av[3], bv[3], a);
+      }
+      acc[pp] = a;
+    }
+  }
+}
+template <int NACC>
+__device__ __forceinline__ void store_pass(const f32x4 (&acc)[NACC], float* out, int ldo, int nL, int nR, int w, int lr, int q) {
+#pragma unroll
+  for (int pp = 0; pp < NACC; ++pp) {
+    const int p = w + 8 * pp;
+    if (p < nL * nR) {
+      const int ti = p / nR, tk = p - ti * nR;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * ti + 4 * q + r) * ldo + 16 * tk + lr] = acc[pp][r];
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void zero_(f32x4 (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+struct FusedArgs {
+  FNet A, C, At, Ct;          // A/At unused fields are ignored by the actor pass
+  const float *s, *a, *r, *t, *sn;
+  int Bu, ns, na;
+  float gamma;
+  int quirk;
+  float* slab;                // [gridDim.x][slab_stride]
+  int slab_stride;
+};
+
+// slab layouts (floats)
+//   critic: dW3 [16][HP] | dW2 [HP][HP] | dW1 [HP][16] | stats[8]
+//   actor : dW3 [16][HPa] | dW2 [HPa][HPa] | dW1 [HPa][16] | stats[8]
+static inline int slab_floats(int HP) { return 16 * HP + HP * HP + HP * 16 + 8; }
+
+// block-wide deterministic sum (fixed tree)
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < FTHREADS / 64; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------ critic pass
+template <int MT, int MTA>
+__global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
+  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + 4, LDWa = HPa + 4;
+  float* Wreg = smem;                                   // [HP][LDW] big weight image / staging images
+  float* sc = Wreg + wreg_floats(MT, MTA);              // critic small image
+  float* sa = sc + (HP * LDW1 + 3 * HP + 4);            // actor small image
+  float* saW2 = sa + (HPa * LDW1 + 3 * HPa + 4);        // actor W2 [HPa][LDWa]
+  float* red = saW2 + HPa * LDWa;                       // [8]
+  const SmallLds SC = carve_small(sc, HP), SA = carve_small(sa, HPa);
+  const int ns = g.ns, na = g.na, K0 = ns + na;
+  const int col = blockIdx.x * FCOLS + w * 16 + lr;
+  const bool valid = col < g.Bu;
+
+  // ---- phase T: target actor + target critic
+  load_big(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
+  load_small(SC, g.Ct, tid);
+  load_small(SA, g.At, tid);
+  load_big(saW2, g.At.w + g.At.oW2, HPa * LDWa, tid);
+  // mean reward for the reference's (1xBu).+(Bu) broadcast: every workgroup reduces all of r in the
+  // same fixed order, so the value is identical everywhere
+  float rsum = 0.f;
+  for (int i = tid; i < g.Bu; i += FTHREADS) rsum += g.r[i];
+  const float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads
+
+  float x[4];   // input rows 4t+q for t < 4 (K0 <= 15)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 4 * t + q;
+    x[t] = (valid && row < ns) ? g.sn[(size_t)col * ns + row] : 0.f;
+  }
+  float tgt;
+  {
+    f32x4 ha1[MTA], ha2[MTA];
+    layer_in<MTA, 4>(ha1, x, SA, lr, q);
+    layer_hh<MTA, MTA, true>(ha2, ha1, saW2, LDWa, SA.b2, lr, q);
+    relu_<MTA>(ha2);
+    const float an = tanhf(head<MTA>(ha2, SA.w3, SA.b3[0], q));      // na == 1
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (4 * t + q == ns) x[t] = valid ? an : 0.f;
+    f32x4 h1[MT], h2[MT];
+    layer_in<MT, 4>(h1, x, SC, lr, q);
+    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
+    relu_<MT>(h2);
+    const float qt = head<MT>(h2, SC.w3, SC.b3[0], q);
+    const float tv = valid ? g.t[col] : 0.f;
+    tgt = g.gamma * (1.f - tv) * qt;
+  }
+  __syncthreads();
+  // ---- phase Q: behaviour critic forward
+  load_big(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
+  load_small(SC, g.C, tid);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 4 * t + q;
+    float v = 0.f;
+    if (valid && row < ns) v = g.s[(size_t)col * ns + row];
+    else if (valid && row < K0) v = g.a[(size_t)col * na + (row - ns)];
+    x[t] = v;
+  }
+  f32x4 h1[MT], h2[MT];
+  layer_in<MT, 4>(h1, x, SC, lr, q);
+  layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
+  relu_<MT>(h2);
+  const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
+  const float rv = valid ? g.r[col] : 0.f;
+  const float c = valid ? tgt - qv : 0.f;
+  const float dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
+  // loss statistics (one lane per column contributes)
+  const bool rep = valid && q == 0;
+  float st0 = rep ? c : 0.f, st1 = rep ? c * c : 0.f, st2 = rep ? rv : 0.f, st3 = rep ? rv * rv : 0.f,
+        st4 = rep ? (rv + c) * (rv + c) : 0.f;
+  float* slab = g.slab + (size_t)blockIdx.x * g.slab_stride;
+  float* Lm = Wreg;                 // staging images overlay the big weight region
+  float* Rm = Wreg + HP * LDP;
+  const int cw = (w & 3) * 16 + lr;
+
+  // ---- pass A: dW3/db3 = dq x [h2; 1]^T
+  __syncthreads();
+  for (int i = tid; i < 16 * LDP; i += FTHREADS) Lm[i] = 0.f;
+  {
+    f32x4 accA[(MT + 7) / 8];
+    zero_(accA);
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((w >> 2) == half) {
+        stage_rows<MT>(Rm, h2, cw, q, g.C.H);
+        if (q == 0) Lm[cw] = dq;
+      }
+      __syncthreads();
+      gemm_pass(accA, Lm, Rm, 1, MT, w, lr, q);
+    }
+    store_pass(accA, slab, HP, 1, MT, w, lr, q);
+  }
+  // ---- dz2, dh1 = W2^T dz2, dz1
+  f32x4 dz2[MT];
+  head_bwd<MT>(dz2, h2, SC.w3, dq, q);
+  __syncthreads();
+  load_big(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
+  __syncthreads();
+  f32x4 dz1[MT];
+  layer_hh<MT, MT, false>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dz1[m][r] = h1[m][r] > 0.f ? dz1[m][r] : 0.f;
+  // ---- pass B: dW2/db2 = dz2 x [h1; 1]^T
+  {
+    f32x4 accB[(MT * MT + 7) / 8];
+    zero_(accB);
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((w >> 2) == half) {
+        stage_rows<MT>(Lm, dz2, cw, q, -1);
+        stage_rows<MT>(Rm, h1, cw, q, g.C.H);
+      }
+      __syncthreads();
+      gemm_pass(accB, Lm, Rm, MT, MT, w, lr, q);
+    }
+    store_pass(accB, slab + 16 * HP, HP, MT, MT, w, lr, q);
+  }
+  // ---- pass C: dW1/db1 = dz1 x [x0; 1]^T
+  {
+    f32x4 accC[(MT + 7) / 8];
+    zero_(accC);
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((w >> 2) == half) {
+        stage_rows<MT>(Lm, dz1, cw, q, -1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = 4 * t + q;
+          Rm[row * LDP + cw] = row == K0 ? 1.f : x[t];
+        }
+      }
+      __syncthreads();
+      gemm_pass(accC, Lm, Rm, MT, 1, w, lr, q);
+    }
+    store_pass(accC, slab + 16 * HP + HP * HP, 16, MT, 1, w, lr, q);
+  }
+  st0 = block_sum(st0, red, tid);
+  st1 = block_sum(st1, red, tid);
+  st2 = block_sum(st2, red, tid);
+  st3 = block_sum(st3, red, tid);
+  st4 = block_sum(st4, red, tid);
+  if (tid == 0) {
+    float* st = slab + 16 * HP + HP * HP + HP * 16;
+    st[0] = st0; st[1] = st1; st[2] = st2; st[3] = st3; st[4] = st4; st[5] = 0.f; st[6] = 0.f; st[7] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ actor pass
+template <int MT, int MTA>
+__global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g) {
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
+  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + 4, LDWa = HPa + 4;
+  float* Wreg = smem;
+  float* sc = Wreg + wreg_floats(MT, MTA);
+  float* sa = sc + (HP * LDW1 + 3 * HP + 4);
+  float* saW2 = sa + (HPa * LDW1 + 3 * HPa + 4);
+  float* saW2T = saW2 + HPa * LDWa;
+  float* red = saW2T + HPa * LDWa;
+  const SmallLds SC = carve_small(sc, HP), SA = carve_small(sa, HPa);
+  const int ns = g.ns;
+  const int col = blockIdx.x * FCOLS + w * 16 + lr;
+  const bool valid = col < g.Bu;
+
+  load_big(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
+  load_small(SC, g.C, tid);
+  load_small(SA, g.A, tid);
+  load_big(saW2, g.A.w + g.A.oW2, HPa * LDWa, tid);
+  load_big(saW2T, g.A.w + g.A.oW2T, HPa * LDWa, tid);
+  __syncthreads();
+  float xs[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 4 * t + q;
+    xs[t] = (valid && row < ns) ? g.s[(size_t)col * ns + row] : 0.f;
+  }
+  f32x4 ha1[MTA], ha2[MTA];
+  layer_in<MTA, 4>(ha1, xs, SA, lr, q);
+  layer_hh<MTA, MTA, true>(ha2, ha1, saW2, LDWa, SA.b2, lr, q);
+  relu_<MTA>(ha2);
+  const float aout = tanhf(head<MTA>(ha2, SA.w3, SA.b3[0], q));
+  float x[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) x[t] = (4 * t + q == ns) ? (valid ? aout : 0.f) : xs[t];
+  f32x4 h1[MT], h2[MT];
+  layer_in<MT, 4>(h1, x, SC, lr, q);
+  layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
+  relu_<MT>(h2);
+  const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
+  float st0 = (valid && q == 0) ? qv : 0.f;
+  const float dq = valid ? -1.f / (float)g.Bu : 0.f;
+  f32x4 dz2[MT];
+  head_bwd<MT>(dz2, h2, SC.w3, dq, q);
+  __syncthreads();
+  load_big(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
+  __syncthreads();
+  f32x4 dz1[MT];
+  layer_hh<MT, MT, false>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
+  // da = sum_i W1[i][ns] * dz1[i]  (gradient w.r.t. the action input row of the critic)
+  float da = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * m + 4 * q + r;
+      const float d = h1[m][r] > 0.f ? dz1[m][r] : 0.f;
+      da += SC.W1[row * LDW1 + ns] * d;
+    }
+  da += __shfl_xor(da, 16);
+  da += __shfl_xor(da, 32);
+  const float dza3 = da * (1.f - aout * aout);
+  f32x4 dza2[MTA], dza1[MTA];
+  head_bwd<MTA>(dza2, ha2, SA.w3, dza3, q);
+  layer_hh<MTA, MTA, false>(dza1, dza2, saW2T, LDWa, nullptr, lr, q);
+#pragma unroll
+  for (int m = 0; m < MTA; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dza1[m][r] = ha1[m][r] > 0.f ? dza1[m][r] : 0.f;
+  // ---- weight gradients of the actor (three small column contractions)
+  float* slab = g.slab + (size_t)blockIdx.x * g.slab_stride;
+  float* I0 = Wreg;                       // DZ3 [16][LDP]
+  float* I1 = I0 + 16 * LDP;              // HA2aug [HPa][LDP]
+  float* I2 = I1 + HPa * LDP;             // DZA2 [HPa][LDP]
+  float* I3 = I2 + HPa * LDP;             // HA1aug [HPa][LDP]
+  float* I4 = I3 + HPa * LDP;             // DZA1 [HPa][LDP]
+  float* I5 = I4 + HPa * LDP;             // Xaug [16][LDP]
+  const int cw = (w & 3) * 16 + lr;
+  __syncthreads();
+  for (int i = tid; i < 16 * LDP; i += FTHREADS) { I0[i] = 0.f; I5[i] = 0.f; }
+  f32x4 acc3[1], acc2[(MTA * MTA + 7) / 8], acc1[1];
+  zero_(acc3); zero_(acc2); zero_(acc1);
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if ((w >> 2) == half) {
+      if (q == 0) I0[cw] = dza3;
+      stage_rows<MTA>(I1, ha2, cw, q, g.A.H);
+      stage_rows<MTA>(I2, dza2, cw, q, -1);
+      stage_rows<MTA>(I3, ha1, cw, q, g.A.H);
+      stage_rows<MTA>(I4, dza1, cw, q, -1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = 4 * t + q;
+        I5[row * LDP + cw] = row == ns ? 1.f : xs[t];
+      }
+    }
+    __syncthreads();
+    gemm_pass(acc3, I0, I1, 1, MTA, w, lr, q);
+    gemm_pass(acc2, I2, I3, MTA, MTA, w, lr, q);
+    gemm_pass(acc1, I4, I5, MTA, 1, w, lr, q);
+  }
+  store_pass(acc3, slab, HPa, 1, MTA, w, lr, q);
+  store_pass(acc2, slab + 16 * HPa, HPa, MTA, MTA, w, lr, q);
+  store_pass(acc1, slab + 16 * HPa + HPa * HPa, 16, MTA, 1, w, lr, q);
+  st0 = block_sum(st0, red, tid);
+  if (tid == 0) {
+    float* st = slab + 16 * HPa + HPa * HPa + HPa * 16;
+    st[0] = st0;
+    for (int i = 1; i < 8; ++i) st[i] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ slab reduction
+// flat internal gradient layout [W1 [H][K0], b1 [H], W2 [H][H], b2 [H], W3 [1][H], b3]
+__global__ __launch_bounds__(256) void fused_reduce_kernel(const float* __restrict__ slabs, int nslab, int stride, int K0, int H, int HP,
+                                    float* __restrict__ grads, float scale, int mode, int Bu, int quirk,
+                                    float* __restrict__ loss_out) {
+  // block = 16 outputs x 16 slab groups; each thread sums every 16th slab, then a fixed-order
+  // combine over the groups (deterministic; 16x shorter dependent chains than one thread per output)
+  __shared__ float part[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + tx;
+  const int n = H * K0 + H + H * H + H + H + 1;
+  const int o3 = 0, o2 = 16 * HP, o1 = 16 * HP + HP * HP, ost = o1 + HP * 16;
+  float acc = 0.f;
+  if (i < n) {
+    int src, j = i;
+    if (j < H * K0) src = o1 + (j / K0) * 16 + (j % K0);
+    else if ((j -= H * K0) < H) src = o1 + j * 16 + K0;
+    else if ((j -= H) < H * H) src = o2 + (j / H) * HP + (j % H);
+    else if ((j -= H * H) < H) src = o2 + j * HP + H;
+    else if ((j -= H) < H) src = o3 + j;
+    else src = o3 + H;
+    for (int z = ty; z < nslab; z += 16) acc += slabs[(size_t)z * stride + src];
+  }
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    float a = 0.f;
+    for (int k = 0; k < 16; ++k) a += part[k][tx];
+    grads[i] = a * scale;
+  }
+  if (blockIdx.x == 0 && loss_out) {   // block 0 also finalises the loss (fixed-order tree -> deterministic)
+    __shared__ double red[5][256];
+    const int tid = threadIdx.x;
+    double st[5] = {0, 0, 0, 0, 0};
+    for (int z = tid; z < nslab; z += 256)
+      for (int k = 0; k < 5; ++k) st[k] += (double)slabs[(size_t)z * stride + ost + k];
+    for (int k = 0; k < 5; ++k) red[k][tid] = st[k];
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+      if (tid < sft)
+        for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + sft];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double inv = 1.0 / Bu;
+      if (mode == 0)   // critic: quirk -> mean(c^2) + 2 mean(c) mean(r) + mean(r^2); else mean((r+c)^2)
+        *loss_out = (float)(quirk ? red[1][0] * inv + 2.0 * (red[0][0] * inv) * (red[2][0] * inv) + red[3][0] * inv
+                                  : red[4][0] * inv);
+      else             // actor: -mean(q)
+        *loss_out = (float)(-red[0][0] * inv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static bool fused_disabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PDEC_DISABLE_FUSED");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+static int mt_of(int H) { return (H + 1 + 15) / 16; }
+
+bool fused_supported(const Mlp* A, const Mlp* C) {
+  if (fused_disabled()) return false;
+  if (A->dtype != PDEC_F32 || C->dtype != PDEC_F32) return false;
+  if (A->L != 3 || C->L != 3) return false;
+  const int ns = A->dims[0], na = A->dims[3];
+  if (na != 1 || C->dims[0] != ns + na || C->dims[3] != 1 || ns + na + 1 > KXP) return false;
+  if (A->dims[1] != A->dims[2] || C->dims[1] != C->dims[2]) return false;
+  if (A->acts[0] != PDEC_ACT_RELU || A->acts[1] != PDEC_ACT_RELU || A->acts[2] != PDEC_ACT_TANH) return false;
+  if (C->acts[0] != PDEC_ACT_RELU || C->acts[1] != PDEC_ACT_RELU || C->acts[2] != PDEC_ACT_IDENTITY) return false;
+  const int mt = mt_of(C->dims[1]), mta = mt_of(A->dims[1]);
+  return (mt == 9 || mt == 2) && (mta == 2 || mta == 1);
+}
+
+static int ensure_prepped(Mlp* M) {
+  const FNet f = make_fnet_layout(M->dims[0], M->dims[1]);
+  if (M->fw.bytes < (size_t)f.total * 4) {
+    PDEC_HIP(M->fw.alloc((size_t)f.total * 4));
+    M->fw_dirty = true;
+  }
+  if (M->fw_dirty) {
+    ProfScope ps(M, "fused_prep");
+    hipLaunchKernelGGL(prep_fused_kernel, dim3((f.total + 255) / 256), dim3(256), 0, M->stream, M->params.as<float>(),
+                       M->fw.as<float>(), f);
+    PDEC_HIP(hipGetLastError());
+    M->fw_dirty = false;
+  }
+  return PDEC_OK;
+}
+
+static FNet fnet_of(const Mlp* M) {
+  FNet f = make_fnet_layout(M->dims[0], M->dims[1]);
+  f.w = M->fw.as<float>();
+  return f;
+}
+
+template <int MT, int MTA>
+static size_t lds_bytes(bool actor_pass) {
+  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + 4, LDWa = HPa + 4;
+  (void)LDW;
+  size_t f = (size_t)wreg_floats(MT, MTA) + small_floats(HP) + small_floats(HPa) + (size_t)HPa * LDWa * (actor_pass ? 2 : 1) + 8;
+  return f * 4;
+}
+
+template <int MT, int MTA>
+static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
+  const size_t lds = lds_bytes<MT, MTA>(false);
+  auto kern = ddpg_critic_fused_kernel<MT, MTA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  ProfScope ps(C, "ddpg_critic_fused");
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+template <int MT, int MTA>
+static int launch_actor(Mlp* C, const FusedArgs& g, int grid) {
+  const size_t lds = lds_bytes<MT, MTA>(true);
+  auto kern = ddpg_actor_fused_kernel<MT, MTA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  ProfScope ps(C, "ddpg_actor_fused");
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+static int ensure_slab(Mlp* M, size_t floats) {
+  if (M->fslab.bytes < floats * 4) PDEC_HIP(M->fslab.alloc(floats * 4));
+  return PDEC_OK;
+}
+
+int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
+                       const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev) {
+  int rc;
+  if ((rc = ensure_prepped(C)) || (rc = ensure_prepped(At)) || (rc = ensure_prepped(Ct))) return rc;
+  const int mt = mt_of(C->dims[1]), mta = mt_of(A->dims[1]);
+  const int HP = 16 * mt, grid = (Bu + FCOLS - 1) / FCOLS;
+  const int stride = slab_floats(HP);
+  if ((rc = ensure_slab(C, (size_t)grid * stride))) return rc;
+  FusedArgs g{};
+  g.C = fnet_of(C); g.At = fnet_of(At); g.Ct = fnet_of(Ct); g.A = g.At;
+  g.s = (const float*)s; g.a = (const float*)a; g.r = (const float*)r; g.t = (const float*)t; g.sn = (const float*)sn;
+  g.Bu = Bu; g.ns = A->dims[0]; g.na = 1; g.gamma = (float)gamma; g.quirk = quirk;
+  g.slab = C->fslab.as<float>(); g.slab_stride = stride;
+  if (mt == 9 && mta == 2) rc = launch_critic<9, 2>(C, g, grid);
+  else if (mt == 9 && mta == 1) rc = launch_critic<9, 1>(C, g, grid);
+  else if (mt == 2 && mta == 2) rc = launch_critic<2, 2>(C, g, grid);
+  else rc = launch_critic<2, 1>(C, g, grid);
+  if (rc) return rc;
+  const int n = C->nparams;
+  ProfScope ps(C, "fused_reduce");
+  hipLaunchKernelGGL(fused_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, C->stream, C->fslab.as<float>(), grid, stride,
+                     C->dims[0], C->dims[1], HP, C->grads.as<float>(), (float)grad_scale, 0, Bu, quirk, (float*)loss_dev);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int fused_actor_grads(Mlp* A, Mlp* C, const void* s, int Bu, double grad_scale, void* loss_dev) {
+  int rc;
+  if ((rc = ensure_prepped(C)) || (rc = ensure_prepped(A))) return rc;
+  const int mt = mt_of(C->dims[1]), mta = mt_of(A->dims[1]);
+  const int HPa = 16 * mta, grid = (Bu + FCOLS - 1) / FCOLS;
+  const int stride = slab_floats(HPa);
+  if ((rc = ensure_slab(A, (size_t)grid * stride))) return rc;
+  FusedArgs g{};
+  g.C = fnet_of(C); g.A = fnet_of(A); g.At = g.A; g.Ct = g.C;
+  g.s = (const float*)s; g.Bu = Bu; g.ns = A->dims[0]; g.na = 1;
+  g.slab = A->fslab.as<float>(); g.slab_stride = stride;
+  // the actor pass is launched on the critic's stream object for profiling labels but must follow
+  // ADAM(C); both handles share one stream in every caller (checked by the dispatcher)
+  if (mt == 9 && mta == 2) rc = launch_actor<9, 2>(C, g, grid);
+  else if (mt == 9 && mta == 1) rc = launch_actor<9, 1>(C, g, grid);
+  else if (mt == 2 && mta == 2) rc = launch_actor<2, 2>(C, g, grid);
+  else rc = launch_actor<2, 1>(C, g, grid);
+  if (rc) return rc;
+  const int n = A->nparams;
+  ProfScope ps(C, "fused_reduce");
+  hipLaunchKernelGGL(fused_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, C->stream, A->fslab.as<float>(), grid, stride,
+                     A->dims[0], A->dims[1], HPa, A->grads.as<float>(), (float)grad_scale, 1, Bu, 0, (float*)loss_dev);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+}  // namespace pdec
