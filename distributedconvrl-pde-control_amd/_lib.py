@@ -29,6 +29,7 @@ class EnvCfg(C.Structure):
         ("sensor_scale", C.c_double), ("agent_power", C.c_double), ("reward_in_scale", C.c_double),
         ("reward_offset", C.c_double), ("reward_power", C.c_double), ("reward_denom", C.c_double),
         ("action_punish", C.c_double), ("delta_action_punish", C.c_double),
+        ("ifpad", C.c_int), ("sensors_per_axis", C.c_int), ("nu", C.c_double),
     ]
 
 
@@ -45,6 +46,7 @@ SIGNATURES = {
     "pdec_prof_enable": [Handle, _i], "pdec_prof_reset": [Handle],
     "pdec_prof_get": [Handle, C.c_char_p, _pd, C.POINTER(_i)],
     "pdec_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _pd, _pd, _pi32],
+    "pdec_fluid_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _pd, _pi32, _pd, _pi32, _pi32],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
     "pdec_featurize": [Handle, _vp, _vp, _vp],

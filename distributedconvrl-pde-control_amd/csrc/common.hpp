@@ -40,12 +40,16 @@ enum class Kind { Env, Mlp, Comm };
 
 struct ProfEntry {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  int reps = 1;   // launches bracketed by each event pair (replay timing, see ProfScope::reps)
 };
 
 struct Object {
   Kind kind;
   hipStream_t stream = nullptr;
   bool prof = false;
+  int prof_reps = 1;   // pdec_prof_enable(h, R > 1): idempotent kernels are launched R times back to back
+                       // inside one event pair, so the per-launch figure is free of event-record overhead
+                       // and comparable with rocprofv3's kernel-trace duration
   std::map<std::string, ProfEntry> profs;
   explicit Object(Kind k) : kind(k) {}
   virtual ~Object();
@@ -56,8 +60,10 @@ struct ProfScope {
   Object* o;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const char* name;
-  ProfScope(Object* obj, const char* nm) : o(obj), name(nm) {
+  int reps = 1;   // the launch site loops `for (int i = 0; i < ps.reps; ++i) launch` when the kernel is idempotent
+  ProfScope(Object* obj, const char* nm, bool idempotent = false) : o(obj), name(nm) {
     if (o->prof) {
+      if (idempotent) reps = o->prof_reps;
       (void)hipEventCreate(&e0);
       (void)hipEventCreate(&e1);
       (void)hipEventRecord(e0, o->stream);
@@ -66,7 +72,9 @@ struct ProfScope {
   ~ProfScope() {
     if (o->prof) {
       (void)hipEventRecord(e1, o->stream);
-      o->profs[name].ev.emplace_back(e0, e1);
+      ProfEntry& pe = o->profs[name];
+      pe.ev.emplace_back(e0, e1);
+      pe.reps = reps;
     }
   }
 };

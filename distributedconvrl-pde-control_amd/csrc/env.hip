@@ -15,43 +15,9 @@
 // never has to be separated and one complex FFT serves two trajectories.  All 2K+3 FFTs of
 // a control step run out of LDS (mixed-radix Stockham); per-mode state lives in registers;
 // HBM sees only the compulsory traffic (y, action in; y, state, reward, done out).
-#include "common.hpp"
-#include "fft_lds.hpp"
+#include "env.hpp"
 
 namespace pdec {
-
-template <class T>
-struct EnvDev {
-  int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species;
-  T sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
-  T dx, hstep;           // K-S: cell size, RK4 sub-step
-  // sensor / actuator kernels as circular BAND tables (exact: every non-zero entry of the dense
-  // [S][N] / [A][N] matrices is kept; a kernel whose support is the whole domain gives Wd = N)
-  const T* Gs;           // [Wd][S]   Gs[j][s] = g_s[(sn0[s] + j) mod N]     (coalesced over s)
-  const int* sn0;        // [S]       first cell of sensor s's window
-  const T* GaC;          // [Cnt][N]  GaC[i][n] = ga_{(an0[n]+i) mod A}[n]   (coalesced over n)
-  const int* an0;        // [N]       first actuator reaching cell n
-  int Wd, Cnt;
-  const T* gsum;         // [S]     sum of each sensor kernel (reward offset term)
-  const int* a2s;        // [A]
-  // KS CNAB2 per-mode constants
-  const T *c1, *c2, *c3, *c4, *g;
-  const C2<T>* dhat;     // h * fft(mu cos(...))
-  const C2<T>* tw;       // exp(-2 pi i k/N)
-  FftPlan fft;
-};
-
-struct Env : Object {
-  pdec_env_cfg cfg;
-  DevBuf Gs, sn0, GaC, an0, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
-  int Wd = 0, Cnt = 0;
-  DevBuf stage;  // staging for the _host wrappers
-  FftPlan fft;
-  int nthreads = 64;
-  int r4_log = 0;        // 4 / 5: N = 256 / 1024 use the register-resident radix-4 FFT engine
-  size_t lds_bytes = 0;
-  Env() : Object(Kind::Env) {}
-};
 
 // ------------------------------------------------------------------ shared device pieces
 
@@ -657,8 +623,10 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
   const pdec_env_cfg& c = E.cfg;
   if (c.pde_kind == PDEC_PDE_KS_CNAB2) {
     dim3 grid((c.B + 1) / 2), block(E.nthreads);
-    ProfScope ps(&E, fused ? "ks_env_step" : "ks_pde_step");
+    // replay is safe when the step does not run in place (y_out != y_in)
+    ProfScope ps(&E, fused ? "ks_env_step" : "ks_pde_step", y_out != y_in && state_out != state_prev);
 #define KS_LAUNCH(ENG, F)                                                                                      \
+  for (int rep__ = 0; rep__ < ps.reps; ++rep__)                                                                \
   hipLaunchKernelGGL((ks_env_step_kernel<T, ENG, F>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,    \
                      (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,    \
                      (T*)p_out, (T*)state_out, (T*)reward_out, done)
@@ -844,6 +812,7 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
 int pdec_actuate(pdec_handle h, const void* action, void* p_out) {
   GET_ENV(E, h);
   PDEC_REQUIRE(action && p_out, "pdec_actuate: null");
+  if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_actuate(*E, action, p_out);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 0, nullptr, action, nullptr, nullptr, p_out)
                                   : launch_sense<float>(*E, 0, nullptr, action, nullptr, nullptr, p_out);
 }
@@ -852,6 +821,7 @@ int pdec_featurize(pdec_handle h, const void* y, const void* prev_state, void* s
   GET_ENV(E, h);
   PDEC_REQUIRE(y && state_out, "pdec_featurize: null");
   PDEC_REQUIRE(prev_state != state_out, "pdec_featurize: state_out must not alias prev_state");
+  if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_featurize(*E, y, prev_state, state_out);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 1, y, nullptr, nullptr, prev_state, state_out)
                                   : launch_sense<float>(*E, 1, y, nullptr, nullptr, prev_state, state_out);
 }
@@ -859,6 +829,7 @@ int pdec_featurize(pdec_handle h, const void* y, const void* prev_state, void* s
 int pdec_reward(pdec_handle h, const void* y, const void* action, const void* action_prev, void* r_out) {
   GET_ENV(E, h);
   PDEC_REQUIRE(y && action && action_prev && r_out, "pdec_reward: null");
+  if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_reward(*E, y, action, action_prev, r_out);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 2, y, action, action_prev, nullptr, r_out)
                                   : launch_sense<float>(*E, 2, y, action, action_prev, nullptr, r_out);
 }
@@ -866,6 +837,7 @@ int pdec_reward(pdec_handle h, const void* y, const void* action, const void* ac
 int pdec_pde_step(pdec_handle h, const void* y_in, const void* p, void* y_out, int32_t* done) {
   GET_ENV(E, h);
   PDEC_REQUIRE(y_in && p && y_out, "pdec_pde_step: null");
+  if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_pde_step(*E, y_in, p, y_out, done);
   return E->cfg.dtype == PDEC_F64
              ? launch_step<double>(*E, false, 1, y_in, p, nullptr, nullptr, nullptr, y_out, nullptr, nullptr, nullptr, done)
              : launch_step<float>(*E, false, 1, y_in, p, nullptr, nullptr, nullptr, y_out, nullptr, nullptr, nullptr, done);
@@ -874,6 +846,7 @@ int pdec_pde_step(pdec_handle h, const void* y_in, const void* p, void* y_out, i
 int pdec_rhs_eval(pdec_handle h, const void* y, const void* p, void* out) {
   GET_ENV(E, h);
   PDEC_REQUIRE(y && p && out, "pdec_rhs_eval: null");
+  if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_rhs_eval(*E, y, p, out);
   PDEC_REQUIRE(E->cfg.pde_kind == PDEC_PDE_KSEG_RK4, "pdec_rhs_eval: only RK4-type PDE kinds expose an RHS");
   return E->cfg.dtype == PDEC_F64
              ? launch_step<double>(*E, false, 2, y, p, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr)
@@ -887,6 +860,8 @@ int pdec_env_step(pdec_handle h, const void* y_in, const void* action, const voi
   PDEC_REQUIRE(y_in && action && action_prev && y_out && state_out && reward_out, "pdec_env_step: null");
   PDEC_REQUIRE(!(E->cfg.temporal_steps > 1 && state_prev == state_out),
                "pdec_env_step: state_out must not alias state_prev when temporal_steps > 1");
+  if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4)
+    return fluid_env_step(*E, y_in, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
   return E->cfg.dtype == PDEC_F64
              ? launch_step<double>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done)
              : launch_step<float>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
@@ -902,7 +877,10 @@ int pdec_pde_step_host(pdec_handle h, const void* y_in, const void* p, void* y_o
   GET_ENV(E, h);
   PDEC_REQUIRE(y_in && p && y_out, "pdec_pde_step_host: null");
   const pdec_env_cfg& c = E->cfg;
-  const size_t ts = dtype_size(c.dtype), ny = (size_t)c.B * c.n_species * c.N * ts, np = (size_t)c.B * c.N * ts;
+  const bool fl = c.pde_kind == PDEC_PDE_FLUID_RK4;   // fluid: y and p are complex [N][N] spectra
+  const size_t ts = dtype_size(c.dtype);
+  const size_t ny = fl ? (size_t)c.B * c.N * c.N * 2 * ts : (size_t)c.B * c.n_species * c.N * ts;
+  const size_t np = fl ? ny : (size_t)c.B * c.N * ts;
   int rc = env_stage(E, 2 * ny + np + c.B * sizeof(int32_t) + 64);
   if (rc) return rc;
   char* base = E->stage.as<char>();
@@ -924,8 +902,10 @@ int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, cons
   PDEC_REQUIRE(y_in && action && action_prev && y_out && state_out && reward_out, "pdec_env_step_host: null");
   const pdec_env_cfg& c = E->cfg;
   const size_t ts = dtype_size(c.dtype);
-  const int ns = c.mono ? c.S : c.window * c.n_species * c.temporal_steps;
-  const size_t ny = (size_t)c.B * c.n_species * c.N * ts, np = (size_t)c.B * c.N * ts, na = (size_t)c.B * c.A * ts;
+  const bool fl = c.pde_kind == PDEC_PDE_FLUID_RK4;
+  const int ns = c.mono ? c.S : (fl ? c.window * c.window : c.window * c.n_species) * c.temporal_steps;
+  const size_t ny = fl ? (size_t)c.B * c.N * c.N * 2 * ts : (size_t)c.B * c.n_species * c.N * ts;
+  const size_t np = fl ? ny : (size_t)c.B * c.N * ts, na = (size_t)c.B * c.A * ts;
   const size_t nst = (size_t)c.B * (c.mono ? c.S : c.A * ns) * ts, nr = (size_t)c.B * (c.mono ? 1 : c.A) * ts;
   auto al = [](size_t x) { return (x + 63) / 64 * 64; };
   int rc = env_stage(E, 2 * al(ny) + al(np) + 2 * al(na) + 2 * al(nst) + al(nr) + al(c.B * sizeof(int32_t)));

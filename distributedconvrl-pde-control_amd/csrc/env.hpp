@@ -1,0 +1,52 @@
+// env.hpp -- the environment object shared by env.hip (1-D KS / Keller-Segel kernels) and
+// fluid.hip (2-D pseudo-spectral vorticity solver).
+#pragma once
+#include "common.hpp"
+#include "fft_lds.hpp"
+
+namespace pdec {
+
+template <class T>
+struct EnvDev {
+  int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species;
+  T sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
+  T dx, hstep;           // K-S: cell size, RK4 sub-step
+  // sensor / actuator kernels as circular BAND tables (exact: every non-zero entry of the dense
+  // [S][N] / [A][N] matrices is kept; a kernel whose support is the whole domain gives Wd = N)
+  const T* Gs;           // [Wd][S]   Gs[j][s] = g_s[(sn0[s] + j) mod N]     (coalesced over s)
+  const int* sn0;        // [S]       first cell of sensor s's window
+  const T* GaC;          // [Cnt][N]  GaC[i][n] = ga_{(an0[n]+i) mod A}[n]   (coalesced over n)
+  const int* an0;        // [N]       first actuator reaching cell n
+  int Wd, Cnt;
+  const T* gsum;         // [S]     sum of each sensor kernel (reward offset term)
+  const int* a2s;        // [A]
+  // KS CNAB2 per-mode constants
+  const T *c1, *c2, *c3, *c4, *g;
+  const C2<T>* dhat;     // h * fft(mu cos(...))
+  const C2<T>* tw;       // exp(-2 pi i k/N)
+  FftPlan fft;
+};
+
+struct Env : Object {
+  pdec_env_cfg cfg;
+  DevBuf Gs, sn0, GaC, an0, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
+  int Wd = 0, Cnt = 0;
+  DevBuf stage;  // staging for the _host wrappers
+  FftPlan fft;
+  int nthreads = 64;
+  int r4_log = 0;        // 4 / 5: N = 256 / 1024 use the register-resident radix-4 FFT engine
+  size_t lds_bytes = 0;
+  Env() : Object(Kind::Env) {}
+};
+
+// fluid.hip: 2-D pseudo-spectral vorticity environment (src/fluid_rk4.jl + scripts/Fluid/setup/FluidSetup.jl)
+struct FluidEnv;
+int fluid_env_step(Env& E, const void* y_in, const void* action, const void* action_prev, const void* state_prev,
+                   void* y_out, void* p_out, void* state_out, void* reward_out, int32_t* done);
+int fluid_pde_step(Env& E, const void* y_in, const void* p, void* y_out, int32_t* done);
+int fluid_rhs_eval(Env& E, const void* y, const void* p, void* out);
+int fluid_actuate(Env& E, const void* action, void* p_out);
+int fluid_featurize(Env& E, const void* y, const void* state_prev, void* state_out);
+int fluid_reward(Env& E, const void* y, const void* action, const void* action_prev, void* r_out);
+
+}  // namespace pdec

@@ -1,0 +1,780 @@
+// fluid.hip -- batched 2-D pseudo-spectral vorticity environment for gfx950 (fp64).
+//
+// Restates (from scratch, batched over independent trajectories):
+//   rk4(f, p, dt)            src/fluid_rk4.jl:122-132      classical RK4, forcing frozen over the step
+//   rhs(omghat, p)           src/fluid_rk4.jl:134-143      -nu k^2 w + advection(w) + p
+//   advection(omghat)        src/fluid_rk4.jl:145-190      pseudo-spectral Jacobian, 3/2-rule de-aliasing
+//   pad / chop               src/fluid_rk4.jl:192-229      index maps only (never materialised here)
+//   do_step                  scripts/Fluid/setup/FluidSetup.jl:163-172   K = floor(16 nx dt) RK4 sub-steps
+//   featurize / reward_function / prepare_action          FluidSetup.jl:188-261
+//
+// Design (HBM-bound path, so the point is to move fewer bytes than the reference's 5 padded
+// 2-D FFTs per RHS):
+//  * real(ifft(A)) = ifft(Herm(A)), Herm(A)[k] = (A[k] + conj(A[-k]))/2, so the four inverse
+//    transforms of the reference (u, v, dw/dx, dw/dy; real part taken after each, :169-172)
+//    become TWO complex transforms of Z1 = Herm(u^) + i Herm(v^), Z2 = Herm(wx^) + i Herm(wy^).
+//    This is exact for any spectrum (Hermitian or not), including the +Nyquist modes the
+//    reference keeps (FluidSetup.jl:106-107).
+//  * the padded spectra are zero outside n (+1 mirror line) of the p = 3n/2 lines: the first
+//    inverse pass only transforms those lines and the last forward pass only produces the n kept
+//    ones (pruned 2-D FFT; pad()/chop() are index maps inside the kernels).
+//  * the three slow-axis transforms (2 inverse, product, 1 forward) of a tile of columns happen
+//    inside ONE kernel out of LDS: the physical-space fields never exist in HBM.  The forward
+//    transform of the real product packs two columns as Re/Im of one complex line.
+//  * RK4 stage updates and the linear term are fused into the last pass.
+//  Per RHS and trajectory the HBM traffic is ~ (3 + 3) n p + 7 n^2 complex values (70 MB at n = 512)
+//  instead of 5 * 2 * 2 * p^2 (189 MB) for un-fused library FFTs.
+//
+// Layout: Julia ComplexF64[ny, nx] column-major = memory [nx][ny] (y fastest); square box (nx = ny = n,
+// Lx = Ly) as in every shipped script.  "fast axis" = y, "slow axis" = x.
+#include "env.hpp"
+
+namespace pdec {
+
+#define FL_NTH 256
+#define FL_MAXE 12   // elements per thread of one tile: TL * p <= 3072
+
+__host__ __device__ inline int fl_unpad(int ip, int n, int p) {   // chop(): padded index -> kept index or -1
+  if (ip <= n / 2) return ip;
+  if (ip >= p - n / 2 + 1) return ip - (p - n);
+  return -1;
+}
+__host__ __device__ inline int fl_pad(int i, int n, int p) { return i <= n / 2 ? i : i + (p - n); }   // pad()
+// the nl slow lines carried between the two inverse passes (n kept lines + the mirror of the Nyquist line)
+__host__ __device__ inline int fl_line_jp(int s, int n, int p, int nl) { return s <= n / 2 ? s : s + p - nl; }
+__host__ __device__ inline int fl_line_of(int jp, int n, int p, int nl) {
+  if (jp <= n / 2) return jp;
+  if (jp >= p - (nl - n / 2 - 1)) return jp - (p - nl);
+  return -1;
+}
+
+template <class T>
+struct FluidDev {
+  int B, n, p, nl, TL, TLn, LS, LSn;
+  T nu, inv2, scale_out, invn2;
+  const T* k;          // [n] wavenumbers, [0..n/2, -n/2+1..-1] * 2 pi / L   (FluidSetup.jl:106-107)
+  const C2<T>* twp;    // exp(-2 pi i m / p)
+  const C2<T>* twn;    // exp(-2 pi i m / n)
+  FftPlan plp, pln;
+};
+
+// ------------------------------------------------------------------ tile FFT (nlines lines of one length in LDS)
+template <int R, int SGN, class T>
+__device__ __forceinline__ void tile_stage(const C2<T>* __restrict__ x, C2<T>* __restrict__ y,
+                                           const C2<T>* __restrict__ tw, int N, int n, int s, int u0, int tpl) {
+  const int m = n / R, nb = N / R;
+  const bool pow2 = (s & (s - 1)) == 0;
+  const int sh = 31 - __clz(s);
+  for (int u = u0; u < nb; u += tpl) {
+    int pp, q;
+    if (pow2) { pp = u >> sh; q = u & (s - 1); }
+    else { pp = u / s; q = u - pp * s; }
+    C2<T> a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = x[q + s * (pp + m * j)];
+    dft_small<R, SGN, T>(a);
+    const int base = q + s * R * pp, ps = pp * s;
+    y[base] = a[0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+      C2<T> w = tw[ps * k];
+      if (SGN > 0) w.y = -w.y;
+      y[base + s * k] = cmul(a[k], w);
+    }
+  }
+}
+
+// Transforms `nlines` (power of two <= FL_NTH) lines X[l*LS .. l*LS+N) -> returned buffer (X or Y).
+// Issues a barrier before the first stage and after every stage.
+template <int SGN, class T>
+__device__ __forceinline__ C2<T>* tile_fft(C2<T>* X, C2<T>* Y, const C2<T>* tw, const FftPlan& pl, int LS,
+                                           int nlines, int tid) {
+  const int tpl = FL_NTH / nlines;
+  const int line = tid / tpl, u0 = tid - line * tpl;
+  int n = pl.N, s = 1;
+  __syncthreads();
+  for (int st = 0; st < pl.nstages; ++st) {
+    const int r = pl.radix[st];
+    const C2<T>* x = X + line * LS;
+    C2<T>* y = Y + line * LS;
+    if (r == 4) tile_stage<4, SGN, T>(x, y, tw, pl.N, n, s, u0, tpl);
+    else if (r == 2) tile_stage<2, SGN, T>(x, y, tw, pl.N, n, s, u0, tpl);
+    else if (r == 3) tile_stage<3, SGN, T>(x, y, tw, pl.N, n, s, u0, tpl);
+    else tile_stage<5, SGN, T>(x, y, tw, pl.N, n, s, u0, tpl);
+    __syncthreads();
+    C2<T>* t = X; X = Y; Y = t;
+    n /= r;
+    s *= r;
+  }
+  return X;
+}
+
+// spectral velocities / vorticity gradients of one mode (src/fluid_rk4.jl:152-161)
+template <class T>
+__device__ __forceinline__ void fl_spec(C2<T> o, T kx, T ky, bool dc, C2<T>& u, C2<T>& v, C2<T>& wx, C2<T>& wy) {
+  const T k2 = kx * kx + ky * ky;
+  C2<T> psi = mk<T>(0, 0);
+  if (!dc) psi = mk<T>(o.x / k2, o.y / k2);       // psihat = omghat ./ kx2ky2; psihat[1,1] = 0
+  u = mk<T>(-ky * psi.y, ky * psi.x);             // uhat =  i ky psihat
+  v = mk<T>(kx * psi.y, -kx * psi.x);             // vhat = -i kx psihat
+  wx = mk<T>(-kx * o.y, kx * o.x);                // domgdx = i kx omghat
+  wy = mk<T>(-ky * o.y, ky * o.x);                // domgdy = i ky omghat
+}
+
+// ------------------------------------------------------------------ K1: spectra + pad + Herm + inverse pass along y
+// grid (ceil(nl/TL), B).  W[b][f][s][ip], f = 0: Z1, 1: Z2 (unnormalised inverse along y).
+template <class T>
+__global__ __launch_bounds__(FL_NTH) void fluid_k1_kernel(FluidDev<T> d, const C2<T>* __restrict__ omg,
+                                                          C2<T>* __restrict__ W) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  C2<T>* X = reinterpret_cast<C2<T>*>(smem_raw);
+  C2<T>* Y = X + d.TL * d.LS;
+  C2<T>* tw = Y + d.TL * d.LS;
+  const int tid = threadIdx.x, n = d.n, p = d.p, LS = d.LS;
+  for (int k = tid; k < p; k += FL_NTH) tw[k] = d.twp[k];
+  const int tpl = FL_NTH / d.TL, line = tid / tpl, u0 = tid - line * tpl;
+  const int s = blockIdx.x * d.TL + line, b = blockIdx.y;
+  const bool live = s < d.nl;
+  int j = -1, jm = -1;
+  if (live) {
+    const int jp = fl_line_jp(s, n, p, d.nl);
+    j = fl_unpad(jp, n, p);
+    jm = fl_unpad((p - jp) % p, n, p);
+  }
+  const C2<T>* oj = omg + ((size_t)b * n + (j >= 0 ? j : 0)) * n;
+  const C2<T>* om = omg + ((size_t)b * n + (jm >= 0 ? jm : 0)) * n;
+  const T kj = j >= 0 ? d.k[j] : (T)0, kjm = jm >= 0 ? d.k[jm] : (T)0;
+  C2<T> z2[FL_MAXE];
+#pragma unroll
+  for (int e = 0; e < FL_MAXE; ++e) {
+    const int ip = u0 + tpl * e;
+    z2[e] = mk<T>(0, 0);
+    if (ip < p) {
+      const int i = fl_unpad(ip, n, p), im = fl_unpad((p - ip) % p, n, p);
+      C2<T> au = mk<T>(0, 0), av = au, ax = au, ay = au, mu = au, mv = au, mx = au, my = au;
+      if (j >= 0 && i >= 0) fl_spec<T>(oj[i], kj, d.k[i], i == 0 && j == 0, au, av, ax, ay);
+      if (jm >= 0 && im >= 0) fl_spec<T>(om[im], kjm, d.k[im], im == 0 && jm == 0, mu, mv, mx, my);
+      // Herm(A) = (A(k) + conj(A(-k))) / 2
+      const C2<T> hu = mk<T>((T)0.5 * (au.x + mu.x), (T)0.5 * (au.y - mu.y));
+      const C2<T> hv = mk<T>((T)0.5 * (av.x + mv.x), (T)0.5 * (av.y - mv.y));
+      const C2<T> hx = mk<T>((T)0.5 * (ax.x + mx.x), (T)0.5 * (ax.y - mx.y));
+      const C2<T> hy = mk<T>((T)0.5 * (ay.x + my.x), (T)0.5 * (ay.y - my.y));
+      X[line * LS + ip] = mk<T>(hu.x - hv.y, hu.y + hv.x);   // Z1 = Herm(u) + i Herm(v)
+      z2[e] = mk<T>(hx.x - hy.y, hx.y + hy.x);               // Z2 = Herm(wx) + i Herm(wy)
+    }
+  }
+  C2<T>* R = tile_fft<+1, T>(X, Y, tw, d.plp, LS, d.TL, tid);
+  if (live) {
+    C2<T>* w0 = W + (((size_t)b * 2 + 0) * d.nl + s) * p;
+#pragma unroll
+    for (int e = 0; e < FL_MAXE; ++e) {
+      const int ip = u0 + tpl * e;
+      if (ip < p) w0[ip] = R[line * LS + ip];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < FL_MAXE; ++e) {
+    const int ip = u0 + tpl * e;
+    if (ip < p) X[line * LS + ip] = z2[e];
+  }
+  R = tile_fft<+1, T>(X, Y, tw, d.plp, LS, d.TL, tid);
+  if (live) {
+    C2<T>* w1 = W + (((size_t)b * 2 + 1) * d.nl + s) * p;
+#pragma unroll
+    for (int e = 0; e < FL_MAXE; ++e) {
+      const int ip = u0 + tpl * e;
+      if (ip < p) w1[ip] = R[line * LS + ip];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K2: inverse pass along x, product, forward pass along x
+// grid (ceil(p/TL), B).  W2[b][j][ip] = chop_x( FFT_x( -(u wx + v wy) ) ), two columns per complex line.
+template <class T>
+__global__ __launch_bounds__(FL_NTH) void fluid_k2_kernel(FluidDev<T> d, const C2<T>* __restrict__ W,
+                                                          C2<T>* __restrict__ W2) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  C2<T>* X = reinterpret_cast<C2<T>*>(smem_raw);
+  C2<T>* Y = X + d.TL * d.LS;
+  C2<T>* tw = Y + d.TL * d.LS;
+  const int tid = threadIdx.x, n = d.n, p = d.p, LS = d.LS, TL = d.TL;
+  for (int k = tid; k < p; k += FL_NTH) tw[k] = d.twp[k];
+  const int tlsh = 31 - __clz(TL);
+  const int tpl = FL_NTH / TL, line = tid / tpl, u0 = tid - line * tpl;
+  const int ip0 = blockIdx.x * TL, b = blockIdx.y;
+  C2<T> r0[FL_MAXE];
+  T wre[FL_MAXE];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    if (f) __syncthreads();
+    const C2<T>* Wf = W + (((size_t)b * 2 + f) * d.nl) * p;
+    for (int idx = tid; idx < TL * p; idx += FL_NTH) {       // transposed load, zero fill = pad() along x
+      const int t = idx & (TL - 1), jp = idx >> tlsh;
+      const int s = fl_line_of(jp, n, p, d.nl), ip = ip0 + t;
+      C2<T> v = mk<T>(0, 0);
+      if (s >= 0 && ip < p) v = Wf[(size_t)s * p + ip];
+      X[t * LS + jp] = v;
+    }
+    C2<T>* R = tile_fft<+1, T>(X, Y, tw, d.plp, LS, TL, tid);
+#pragma unroll
+    for (int e = 0; e < FL_MAXE; ++e) {
+      const int jp = u0 + tpl * e;
+      if (jp < p) {
+        const C2<T> v = R[line * LS + jp];
+        if (f == 0) r0[e] = v;
+        else wre[e] = -(r0[e].x * v.x + r0[e].y * v.y) * d.inv2;   // -(u wx + v wy), both ifft scalings
+      }
+    }
+  }
+  __syncthreads();
+  const int half = TL / 2;
+#pragma unroll
+  for (int e = 0; e < FL_MAXE; ++e) {
+    const int jp = u0 + tpl * e;
+    if (jp < p) {
+      T* dst = reinterpret_cast<T*>(&X[(line & (half - 1)) * LS + jp]);
+      dst[line >= half ? 1 : 0] = wre[e];
+    }
+  }
+  C2<T>* R = tile_fft<-1, T>(X, Y, tw, d.plp, LS, half, tid);
+  for (int idx = tid; idx < TL * n; idx += FL_NTH) {
+    const int t = idx & (TL - 1), jj = idx >> tlsh;
+    const int ip = ip0 + t;
+    if (ip >= p) continue;
+    const int jp = fl_pad(jj, n, p), jq = (p - jp) % p, tt = t & (half - 1);
+    const C2<T> y = R[tt * LS + jp], ym = R[tt * LS + jq];
+    C2<T> o;
+    if (t < half) o = mk<T>((T)0.5 * (y.x + ym.x), (T)0.5 * (y.y - ym.y));     // (Y + conj(Ym)) / 2
+    else o = mk<T>((T)0.5 * (y.y + ym.y), (T)-0.5 * (y.x - ym.x));              // (Y - conj(Ym)) / (2i)
+    W2[((size_t)b * n + jj) * p + ip] = o;
+  }
+}
+
+// ------------------------------------------------------------------ K3: forward pass along y, chop, rhs, RK4 stage
+// grid (ceil(n/TL), B).  mode 0: out = rhs;  1: out = f0 + ca k, acc = f0 + cb k;  2: out = f0 + ca k, acc += cb k;
+// 4: out = acc + cb k.
+template <class T>
+__global__ __launch_bounds__(FL_NTH) void fluid_k3_kernel(FluidDev<T> d, const C2<T>* __restrict__ W2,
+                                                          const C2<T>* omg_s, const C2<T>* __restrict__ phat,
+                                                          const C2<T>* f0, C2<T>* acc, C2<T>* out, int mode, T ca, T cb) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  C2<T>* X = reinterpret_cast<C2<T>*>(smem_raw);
+  C2<T>* Y = X + d.TL * d.LS;
+  C2<T>* tw = Y + d.TL * d.LS;
+  const int tid = threadIdx.x, n = d.n, p = d.p, LS = d.LS;
+  for (int k = tid; k < p; k += FL_NTH) tw[k] = d.twp[k];
+  const int tpl = FL_NTH / d.TL, line = tid / tpl, u0 = tid - line * tpl;
+  const int j = blockIdx.x * d.TL + line, b = blockIdx.y;
+  const bool live = j < n;
+  const C2<T>* w2 = W2 + ((size_t)b * n + (live ? j : 0)) * p;
+#pragma unroll
+  for (int e = 0; e < FL_MAXE; ++e) {
+    const int ip = u0 + tpl * e;
+    if (ip < p) X[line * LS + ip] = live ? w2[ip] : mk<T>(0, 0);
+  }
+  C2<T>* R = tile_fft<-1, T>(X, Y, tw, d.plp, LS, d.TL, tid);
+  if (!live) return;
+  const T kj = d.k[j];
+#pragma unroll
+  for (int e = 0; e < FL_MAXE; ++e) {
+    const int ip = u0 + tpl * e;
+    if (ip >= p) continue;
+    const int i = fl_unpad(ip, n, p);
+    if (i < 0) continue;
+    const size_t off = ((size_t)b * n + j) * n + i;
+    const T ki = d.k[i], lin = -d.nu * (kj * kj + ki * ki);
+    const C2<T> o = omg_s[off], nl = R[line * LS + ip], ph = phat[off];
+    const C2<T> k = mk<T>(lin * o.x + d.scale_out * nl.x + ph.x, lin * o.y + d.scale_out * nl.y + ph.y);
+    if (mode == 0) {
+      out[off] = k;
+    } else if (mode == 4) {
+      const C2<T> a = acc[off];
+      out[off] = mk<T>(a.x + cb * k.x, a.y + cb * k.y);
+    } else {
+      const C2<T> f = f0[off];
+      out[off] = mk<T>(f.x + ca * k.x, f.y + ca * k.y);
+      if (mode == 1) acc[off] = mk<T>(f.x + cb * k.x, f.y + cb * k.y);
+      else {
+        const C2<T> a = acc[off];
+        acc[off] = mk<T>(a.x + cb * k.x, a.y + cb * k.y);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ plain 2-D FFT passes of the n x n grid
+// (sensing: y = real(ifft(env.y)), FluidSetup.jl:189,206; actuation: fft(p), :260)
+template <class T, int SGN, bool REAL_IN>
+__global__ __launch_bounds__(FL_NTH) void fluid_fft_fast_kernel(FluidDev<T> d, const void* __restrict__ in,
+                                                                C2<T>* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  C2<T>* X = reinterpret_cast<C2<T>*>(smem_raw);
+  C2<T>* Y = X + d.TLn * d.LSn;
+  C2<T>* tw = Y + d.TLn * d.LSn;
+  const int tid = threadIdx.x, n = d.n, LS = d.LSn;
+  for (int k = tid; k < n; k += FL_NTH) tw[k] = d.twn[k];
+  const int tpl = FL_NTH / d.TLn, line = tid / tpl, u0 = tid - line * tpl;
+  const int j = blockIdx.x * d.TLn + line, b = blockIdx.y;
+  const bool live = j < n;
+  const size_t base = ((size_t)b * n + (live ? j : 0)) * n;
+#pragma unroll
+  for (int e = 0; e < FL_MAXE; ++e) {
+    const int i = u0 + tpl * e;
+    if (i < n) {
+      C2<T> v = mk<T>(0, 0);
+      if (live) v = REAL_IN ? mk<T>(static_cast<const T*>(in)[base + i], 0) : static_cast<const C2<T>*>(in)[base + i];
+      X[line * LS + i] = v;
+    }
+  }
+  C2<T>* R = tile_fft<SGN, T>(X, Y, tw, d.pln, LS, d.TLn, tid);
+  if (!live) return;
+#pragma unroll
+  for (int e = 0; e < FL_MAXE; ++e) {
+    const int i = u0 + tpl * e;
+    if (i < n) out[base + i] = R[line * LS + i];
+  }
+}
+
+template <class T, int SGN, bool REAL_OUT>
+__global__ __launch_bounds__(FL_NTH) void fluid_fft_slow_kernel(FluidDev<T> d, const C2<T>* __restrict__ in,
+                                                                void* __restrict__ out, T scale) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  C2<T>* X = reinterpret_cast<C2<T>*>(smem_raw);
+  C2<T>* Y = X + d.TLn * d.LSn;
+  C2<T>* tw = Y + d.TLn * d.LSn;
+  const int tid = threadIdx.x, n = d.n, LS = d.LSn, TL = d.TLn;
+  for (int k = tid; k < n; k += FL_NTH) tw[k] = d.twn[k];
+  const int tlsh = 31 - __clz(TL);
+  const int i0 = blockIdx.x * TL, b = blockIdx.y;
+  for (int idx = tid; idx < TL * n; idx += FL_NTH) {
+    const int t = idx & (TL - 1), j = idx >> tlsh, i = i0 + t;
+    X[t * LS + j] = i < n ? in[((size_t)b * n + j) * n + i] : mk<T>(0, 0);
+  }
+  C2<T>* R = tile_fft<SGN, T>(X, Y, tw, d.pln, LS, TL, tid);
+  for (int idx = tid; idx < TL * n; idx += FL_NTH) {
+    const int t = idx & (TL - 1), j = idx >> tlsh, i = i0 + t;
+    if (i >= n) continue;
+    const C2<T> v = R[t * LS + j];
+    const size_t off = ((size_t)b * n + j) * n + i;
+    if (REAL_OUT) static_cast<T*>(out)[off] = v.x * scale;
+    else static_cast<C2<T>*>(out)[off] = mk<T>(v.x * scale, v.y * scale);
+  }
+}
+
+// ------------------------------------------------------------------ sensing / actuation
+// dots[b][s] = <y, gaussians[s]>: one wave per sensor over its BW x BH box   (FluidSetup.jl:196,216)
+template <class T>
+__global__ __launch_bounds__(256) void fluid_dots_kernel(int n, int S, int BH, int BW, const T* __restrict__ boxes,
+                                                         const int* __restrict__ origin, const T* __restrict__ yreal,
+                                                         T* __restrict__ dots) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + wv, b = blockIdx.y;
+  if (s >= S) return;
+  const int j0 = origin[2 * s], i0 = origin[2 * s + 1];
+  const T* bx = boxes + (size_t)s * BH * BW;
+  const T* y = yreal + (size_t)b * n * n;
+  T acc = 0;
+  for (int e = lane; e < BH * BW; e += 64) {
+    const int dj = e / BH, di = e - dj * BH;
+    int jj = j0 + dj, ii = i0 + di;
+    if (jj >= n) jj -= n;
+    if (ii >= n) ii -= n;
+    acc += bx[e] * y[(size_t)jj * n + ii];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) dots[(size_t)b * S + s] = acc;
+}
+
+template <class T>
+struct FeatArgs {
+  int S, A, spa, window, ns, check_max;
+  T sensor_scale, r_in_scale, r_power, r_denom, a_pun, da_pun, max_value;
+  const int* a2s;
+};
+
+// featurize (3x3 circular window of the spa x spa sensor grid, FluidSetup.jl:219-224) + reward (:188-202)
+template <class T>
+__global__ __launch_bounds__(256) void fluid_feat_kernel(FeatArgs<T> g, const T* __restrict__ dots,
+                                                         const T* __restrict__ action, const T* __restrict__ action_prev,
+                                                         const T* __restrict__ state_prev, T* __restrict__ state_out,
+                                                         T* __restrict__ reward_out, int32_t* __restrict__ done) {
+  __shared__ int flag;
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const T* dt = dots + (size_t)b * g.S;
+  if (tid == 0) flag = 0;
+  __syncthreads();
+  if (state_out) {
+    const int w = g.window / 2, fresh = g.window * g.window;
+    const T* prev = state_prev ? state_prev + (size_t)b * g.A * g.ns : nullptr;
+    for (int idx = tid; idx < g.A * g.ns; idx += nt) {
+      const int a = idx / g.ns, rr = idx - a * g.ns;
+      T v;
+      if (rr < fresh || prev == nullptr) {
+        const int r0 = rr % fresh, wi = r0 / g.window - w, wj = r0 % g.window - w;
+        const int e = g.a2s[a];
+        int row = (e / g.spa - wi) % g.spa, col = (e % g.spa - wj) % g.spa;
+        if (row < 0) row += g.spa;
+        if (col < 0) col += g.spa;
+        v = dt[row * g.spa + col] * g.sensor_scale;
+      } else {
+        v = prev[a * g.ns + (rr - fresh)];
+      }
+      state_out[(size_t)b * g.A * g.ns + idx] = v;
+    }
+  }
+  if (reward_out) {
+    for (int a = tid; a < g.A; a += nt) {
+      const T dd = fabs(g.r_in_scale * dt[g.a2s[a]]);
+      const T pw = dd == 0 ? (T)0 : (T)pow((double)dd, (double)g.r_power);
+      const T ac = action[(size_t)b * g.A + a], da = ac - action_prev[(size_t)b * g.A + a];
+      const T r = -fabs(pw / g.r_denom) - g.a_pun * ac * ac - g.da_pun * da * da;
+      reward_out[(size_t)b * g.A + a] = r;
+      if (g.check_max == 2 && !(fabs(r) <= g.max_value)) atomicOr(&flag, 1);
+    }
+    __syncthreads();
+    if (done && tid == 0 && g.check_max == 2) done[b] = flag;
+  }
+}
+
+// max|y| > max_value on the spectrum (check_max_value == "y", src/PDEenv.jl:226-231)
+template <class T>
+__global__ __launch_bounds__(256) void fluid_maxabs_kernel(int nn, T max_value, const C2<T>* __restrict__ y,
+                                                           int32_t* __restrict__ done) {
+  __shared__ int flag;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) flag = 0;
+  __syncthreads();
+  int f = 0;
+  for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+    const C2<T> v = y[(size_t)b * nn + i];
+    if (!(hypot(v.x, v.y) <= max_value)) f = 1;
+  }
+  if (f) atomicOr(&flag, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) done[b] = flag;
+}
+
+// p = sum_a agent_power * action[a] * gaussians_actuators[a]   (FluidSetup.jl:254-258): one 16x16 block of
+// cells per workgroup, candidates = the actuators whose box meets the block (CSR built at setup time)
+template <class T>
+__global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH, int BW, int nb1,
+                                                            const T* __restrict__ boxes, const int* __restrict__ origin,
+                                                            const int* __restrict__ blk_ptr, const int* __restrict__ blk_idx,
+                                                            const T* __restrict__ action, T power, T* __restrict__ preal) {
+  const int blk = blockIdx.x, b = blockIdx.y;
+  const int bj = blk / nb1, bi = blk - bj * nb1;
+  const int di = threadIdx.x & 15, dj = threadIdx.x >> 4;
+  const int j = bj * 16 + dj, i = bi * 16 + di;
+  if (j >= n || i >= n) return;
+  T acc = 0;
+  for (int q = blk_ptr[blk]; q < blk_ptr[blk + 1]; ++q) {
+    const int a = blk_idx[q];
+    int dj2 = j - origin[2 * a], di2 = i - origin[2 * a + 1];
+    if (dj2 < 0) dj2 += n;
+    if (di2 < 0) di2 += n;
+    if (dj2 < BW && di2 < BH) acc += (power * action[(size_t)b * A + a]) * boxes[((size_t)a * BW + dj2) * BH + di2];
+  }
+  preal[((size_t)b * n + j) * n + i] = acc;
+}
+
+// ------------------------------------------------------------------ host side
+struct FluidEnv : Env {
+  int n = 0, p = 0, nl = 0, TL = 0, TLn = 0, BH = 0, BW = 0, nb1 = 0;
+  FftPlan plp, pln;
+  DevBuf k, twp, twn, sbox, sorg, abox, aorg, a2s_d, blkptr, blkidx;
+  DevBuf W, W2, fs, acc, yreal, tmpc, dots, phat;
+  size_t lds_p = 0, lds_n = 0;
+};
+
+static FluidDev<double> fluid_dev(const FluidEnv& E) {
+  FluidDev<double> d;
+  d.B = E.cfg.B; d.n = E.n; d.p = E.p; d.nl = E.nl; d.TL = E.TL; d.TLn = E.TLn;
+  d.LS = E.p + 2; d.LSn = E.n + 2;
+  d.nu = E.cfg.nu;
+  const double inv = 1.0 / ((double)E.p * E.p);
+  d.inv2 = inv * inv;
+  d.scale_out = E.cfg.ifpad ? 1.5 * 1.5 : 1.0;        // src/fluid_rk4.jl:176
+  d.invn2 = 1.0 / ((double)E.n * E.n);
+  d.k = E.k.as<double>(); d.twp = E.twp.as<C2<double>>(); d.twn = E.twn.as<C2<double>>();
+  d.plp = E.plp; d.pln = E.pln;
+  return d;
+}
+
+static int pick_tile(int len) {
+  int t = 16;
+  while (t > 1 && t * len > FL_NTH * FL_MAXE) t >>= 1;
+  return t;
+}
+
+template <class K>
+static int set_lds(K kern, size_t bytes) {
+  PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return PDEC_OK;
+}
+
+static int fluid_set_attrs(const FluidEnv& E) {
+  int rc;
+  if ((rc = set_lds(fluid_k1_kernel<double>, E.lds_p))) return rc;
+  if ((rc = set_lds(fluid_k2_kernel<double>, E.lds_p))) return rc;
+  if ((rc = set_lds(fluid_k3_kernel<double>, E.lds_p))) return rc;
+  if ((rc = set_lds(fluid_fft_fast_kernel<double, +1, false>, E.lds_n))) return rc;
+  if ((rc = set_lds(fluid_fft_fast_kernel<double, -1, true>, E.lds_n))) return rc;
+  if ((rc = set_lds(fluid_fft_slow_kernel<double, +1, true>, E.lds_n))) return rc;
+  if ((rc = set_lds(fluid_fft_slow_kernel<double, -1, false>, E.lds_n))) return rc;
+  return PDEC_OK;
+}
+
+// one rhs evaluation fused with an RK4 stage update (mode as in fluid_k3_kernel)
+static int fluid_rhs_launch(FluidEnv& E, const void* omg_s, const void* phat, const void* f0, void* acc, void* out,
+                            int mode, double ca, double cb) {
+  typedef C2<double> Z;
+  const FluidDev<double> d = fluid_dev(E);
+  const int B = E.cfg.B;
+  {
+    ProfScope ps(&E, "fluid_k1", true);
+    for (int r = 0; r < ps.reps; ++r)
+      hipLaunchKernelGGL(fluid_k1_kernel<double>, dim3((E.nl + E.TL - 1) / E.TL, B), dim3(FL_NTH), E.lds_p, E.stream, d,
+                         (const Z*)omg_s, E.W.as<Z>());
+  }
+  {
+    ProfScope ps(&E, "fluid_k2", true);
+    for (int r = 0; r < ps.reps; ++r)
+      hipLaunchKernelGGL(fluid_k2_kernel<double>, dim3((E.p + E.TL - 1) / E.TL, B), dim3(FL_NTH), E.lds_p, E.stream, d,
+                         E.W.as<Z>(), E.W2.as<Z>());
+  }
+  {
+    ProfScope ps(&E, "fluid_k3", mode == 0);
+    for (int r = 0; r < ps.reps; ++r)
+      hipLaunchKernelGGL(fluid_k3_kernel<double>, dim3((E.n + E.TL - 1) / E.TL, B), dim3(FL_NTH), E.lds_p, E.stream, d,
+                         E.W2.as<Z>(), (const Z*)omg_s, (const Z*)phat, (const Z*)f0, (Z*)acc, (Z*)out, mode, ca, cb);
+  }
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+// do_step (FluidSetup.jl:163-172): K sub-steps of rk4 (src/fluid_rk4.jl:122-132), in place on f
+static int fluid_integrate(FluidEnv& E, void* f, const void* phat) {
+  const double h = E.cfg.dt / E.cfg.K;
+  void *fs = E.fs.p, *acc = E.acc.p;
+  int rc;
+  for (int it = 0; it < E.cfg.K; ++it) {
+    if ((rc = fluid_rhs_launch(E, f, phat, f, acc, fs, 1, 0.5 * h, h / 6.0))) return rc;
+    if ((rc = fluid_rhs_launch(E, fs, phat, f, acc, fs, 2, 0.5 * h, h / 3.0))) return rc;
+    if ((rc = fluid_rhs_launch(E, fs, phat, f, acc, fs, 2, h, h / 3.0))) return rc;
+    if ((rc = fluid_rhs_launch(E, fs, phat, f, acc, f, 4, 0.0, h / 6.0))) return rc;
+  }
+  return PDEC_OK;
+}
+
+// yreal = real(ifft(y))
+static int fluid_to_physical(FluidEnv& E, const void* y) {
+  typedef C2<double> Z;
+  const FluidDev<double> d = fluid_dev(E);
+  const int B = E.cfg.B, gt = (E.n + E.TLn - 1) / E.TLn;
+  ProfScope ps(&E, "fluid_ifft2");
+  hipLaunchKernelGGL((fluid_fft_fast_kernel<double, +1, false>), dim3(gt, B), dim3(FL_NTH), E.lds_n, E.stream, d, y,
+                     E.tmpc.as<Z>());
+  hipLaunchKernelGGL((fluid_fft_slow_kernel<double, +1, true>), dim3(gt, B), dim3(FL_NTH), E.lds_n, E.stream, d,
+                     E.tmpc.as<Z>(), E.yreal.p, d.invn2);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+static int fluid_dots(FluidEnv& E, const void* y) {
+  int rc = fluid_to_physical(E, y);
+  if (rc) return rc;
+  const pdec_env_cfg& c = E.cfg;
+  ProfScope ps(&E, "fluid_dots");
+  hipLaunchKernelGGL(fluid_dots_kernel<double>, dim3((c.S + 3) / 4, c.B), dim3(256), 0, E.stream, E.n, c.S, E.BH, E.BW,
+                     E.sbox.as<double>(), E.sorg.as<int>(), E.yreal.as<double>(), E.dots.as<double>());
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+static FeatArgs<double> feat_args(const FluidEnv& E) {
+  const pdec_env_cfg& c = E.cfg;
+  FeatArgs<double> g;
+  g.S = c.S; g.A = c.A; g.spa = c.sensors_per_axis; g.window = c.window;
+  g.ns = c.window * c.window * c.temporal_steps; g.check_max = c.check_max_value;
+  g.sensor_scale = c.sensor_scale; g.r_in_scale = c.reward_in_scale; g.r_power = c.reward_power;
+  g.r_denom = c.reward_denom; g.a_pun = c.action_punish; g.da_pun = c.delta_action_punish; g.max_value = c.max_value;
+  g.a2s = E.a2s_d.as<int>();
+  return g;
+}
+
+static int fluid_feat_launch(FluidEnv& E, const void* action, const void* action_prev, const void* state_prev,
+                             void* state_out, void* reward_out, int32_t* done) {
+  ProfScope ps(&E, "fluid_feat");
+  hipLaunchKernelGGL(fluid_feat_kernel<double>, dim3(E.cfg.B), dim3(256), 0, E.stream, feat_args(E), E.dots.as<double>(),
+                     (const double*)action, (const double*)action_prev, (const double*)state_prev, (double*)state_out,
+                     (double*)reward_out, done);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+static FluidEnv& as_fluid(Env& E) { return static_cast<FluidEnv&>(E); }
+
+int fluid_actuate(Env& E0, const void* action, void* p_out) {
+  typedef C2<double> Z;
+  FluidEnv& E = as_fluid(E0);
+  const pdec_env_cfg& c = E.cfg;
+  const FluidDev<double> d = fluid_dev(E);
+  const int gt = (E.n + E.TLn - 1) / E.TLn;
+  ProfScope ps(&E, "fluid_actuate");
+  hipLaunchKernelGGL(fluid_actuate_kernel<double>, dim3(E.nb1 * E.nb1, c.B), dim3(256), 0, E.stream, E.n, c.A, E.BH, E.BW,
+                     E.nb1, E.abox.as<double>(), E.aorg.as<int>(), E.blkptr.as<int>(), E.blkidx.as<int>(),
+                     (const double*)action, c.agent_power, E.yreal.as<double>());
+  hipLaunchKernelGGL((fluid_fft_fast_kernel<double, -1, true>), dim3(gt, c.B), dim3(FL_NTH), E.lds_n, E.stream, d,
+                     E.yreal.p, E.tmpc.as<Z>());
+  hipLaunchKernelGGL((fluid_fft_slow_kernel<double, -1, false>), dim3(gt, c.B), dim3(FL_NTH), E.lds_n, E.stream, d,
+                     E.tmpc.as<Z>(), p_out, 1.0);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int fluid_featurize(Env& E0, const void* y, const void* state_prev, void* state_out) {
+  FluidEnv& E = as_fluid(E0);
+  int rc = fluid_dots(E, y);
+  if (rc) return rc;
+  return fluid_feat_launch(E, nullptr, nullptr, state_prev, state_out, nullptr, nullptr);
+}
+
+int fluid_reward(Env& E0, const void* y, const void* action, const void* action_prev, void* r_out) {
+  FluidEnv& E = as_fluid(E0);
+  int rc = fluid_dots(E, y);
+  if (rc) return rc;
+  return fluid_feat_launch(E, action, action_prev, nullptr, nullptr, r_out, nullptr);
+}
+
+int fluid_rhs_eval(Env& E0, const void* y, const void* p, void* out) {
+  FluidEnv& E = as_fluid(E0);
+  return fluid_rhs_launch(E, y, p, nullptr, nullptr, out, 0, 0.0, 0.0);
+}
+
+static int fluid_done_y(FluidEnv& E, const void* y, int32_t* done) {
+  hipLaunchKernelGGL(fluid_maxabs_kernel<double>, dim3(E.cfg.B), dim3(256), 0, E.stream, E.n * E.n, E.cfg.max_value,
+                     (const C2<double>*)y, done);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int fluid_pde_step(Env& E0, const void* y_in, const void* p, void* y_out, int32_t* done) {
+  FluidEnv& E = as_fluid(E0);
+  const size_t bytes = (size_t)E.cfg.B * E.n * E.n * 16;
+  if (y_out != y_in) PDEC_HIP(hipMemcpyAsync(y_out, y_in, bytes, hipMemcpyDeviceToDevice, E.stream));
+  int rc = fluid_integrate(E, y_out, p);
+  if (rc) return rc;
+  if (done) {
+    if (E.cfg.check_max_value == 1) return fluid_done_y(E, y_out, done);
+    PDEC_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * E.cfg.B, E.stream));
+  }
+  return PDEC_OK;
+}
+
+int fluid_env_step(Env& E0, const void* y_in, const void* action, const void* action_prev, const void* state_prev,
+                   void* y_out, void* p_out, void* state_out, void* reward_out, int32_t* done) {
+  FluidEnv& E = as_fluid(E0);
+  void* ph = p_out ? p_out : E.phat.p;
+  int rc;
+  if ((rc = fluid_actuate(E, action, ph))) return rc;                                   // src/PDEenv.jl:199
+  if ((rc = fluid_pde_step(E, y_in, ph, y_out, nullptr))) return rc;                    // :216-218
+  if ((rc = fluid_dots(E, y_out))) return rc;
+  if (done && E.cfg.check_max_value != 2) {
+    if (E.cfg.check_max_value == 1) { if ((rc = fluid_done_y(E, y_out, done))) return rc; }
+    else PDEC_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * E.cfg.B, E.stream));
+  }
+  return fluid_feat_launch(E, action, action_prev, state_prev, state_out, reward_out, done);   // :220-222
+}
+
+}  // namespace pdec
+
+using namespace pdec;
+
+extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, int BH, int BW, const double* sensor_boxes,
+                                     const int32_t* sensor_origin, const double* actuator_boxes,
+                                     const int32_t* actuator_origin, const int32_t* a2s) {
+  PDEC_REQUIRE(h && cfg && sensor_boxes && sensor_origin && actuator_boxes && actuator_origin && a2s,
+               "pdec_fluid_env_create: null argument");
+  const pdec_env_cfg& c = *cfg;
+  PDEC_REQUIRE(c.pde_kind == PDEC_PDE_FLUID_RK4, "pdec_fluid_env_create: pde_kind must be PDEC_PDE_FLUID_RK4");
+  PDEC_REQUIRE(c.dtype == PDEC_F64, "the fluid path computes in fp64 (ComplexF64 in the reference)");
+  const int n = c.N;
+  PDEC_REQUIRE(c.B >= 1 && n >= 8 && n % 4 == 0 && c.K >= 1, "pdec_fluid_env_create: bad sizes B=%d N=%d K=%d", c.B, n, c.K);
+  PDEC_REQUIRE(c.S >= 1 && c.A >= 1 && c.sensors_per_axis >= 1 && c.sensors_per_axis * c.sensors_per_axis == c.S,
+               "pdec_fluid_env_create: S must equal sensors_per_axis^2");
+  PDEC_REQUIRE(c.window >= 1 && (c.window & 1) && c.window <= c.sensors_per_axis && c.temporal_steps >= 1 && !c.mono,
+               "pdec_fluid_env_create: window must be odd and <= sensors_per_axis; no mono variant");
+  PDEC_REQUIRE(BH >= 1 && BW >= 1 && BH <= n && BW <= n, "pdec_fluid_env_create: bad box %dx%d", BH, BW);
+  PDEC_REQUIRE(c.Lx > 0 && c.dt > 0, "pdec_fluid_env_create: Lx and dt must be positive");
+  for (int a = 0; a < c.A; ++a) PDEC_REQUIRE(a2s[a] >= 0 && a2s[a] < c.S, "pdec_fluid_env_create: a2s[%d] out of range", a);
+  for (int s = 0; s < c.S; ++s)
+    PDEC_REQUIRE(sensor_origin[2 * s] >= 0 && sensor_origin[2 * s] < n && sensor_origin[2 * s + 1] >= 0 &&
+                     sensor_origin[2 * s + 1] < n, "pdec_fluid_env_create: sensor origin %d out of range", s);
+  for (int a = 0; a < c.A; ++a)
+    PDEC_REQUIRE(actuator_origin[2 * a] >= 0 && actuator_origin[2 * a] < n && actuator_origin[2 * a + 1] >= 0 &&
+                     actuator_origin[2 * a + 1] < n, "pdec_fluid_env_create: actuator origin %d out of range", a);
+  auto E = std::make_unique<FluidEnv>();
+  E->cfg = c;
+  E->n = n;
+  E->p = c.ifpad ? n * 3 / 2 : n;
+  E->nl = c.ifpad ? n + 1 : n;
+  E->BH = BH; E->BW = BW;
+  PDEC_REQUIRE(E->p <= 1536, "N=%d too large for the in-LDS line FFTs (max 1024 padded / 1536 un-padded)", n);
+  PDEC_REQUIRE(make_fft_plan(E->p, E->plp) && make_fft_plan(n, E->pln), "N=%d: sizes must factor into 2,3,5", n);
+  E->TL = pick_tile(E->p);
+  E->TLn = pick_tile(n);
+  PDEC_REQUIRE(E->TL >= 2, "internal: tile too small");
+  E->lds_p = ((size_t)2 * E->TL * (E->p + 2) + E->p) * 16;
+  E->lds_n = ((size_t)2 * E->TLn * (n + 2) + n) * 16;
+  PDEC_REQUIRE(E->lds_p <= 160 * 1024 && E->lds_n <= 160 * 1024, "fluid kernels need too much LDS");
+  std::vector<double> k(n), twp(2 * (size_t)E->p), twn(2 * (size_t)n);
+  for (int i = 0; i < n; ++i) k[i] = (i <= n / 2 ? i : i - n) / c.Lx * 2 * M_PI;     // FluidSetup.jl:106
+  for (int m = 0; m < E->p; ++m) { twp[2 * m] = cos(2 * M_PI * m / E->p); twp[2 * m + 1] = -sin(2 * M_PI * m / E->p); }
+  for (int m = 0; m < n; ++m) { twn[2 * m] = cos(2 * M_PI * m / n); twn[2 * m + 1] = -sin(2 * M_PI * m / n); }
+  int rc;
+  if ((rc = upload_converted(E->k, k.data(), n, PDEC_F64))) return rc;
+  if ((rc = upload_converted(E->twp, twp.data(), twp.size(), PDEC_F64))) return rc;
+  if ((rc = upload_converted(E->twn, twn.data(), twn.size(), PDEC_F64))) return rc;
+  if ((rc = upload_converted(E->sbox, sensor_boxes, (size_t)c.S * BH * BW, PDEC_F64))) return rc;
+  if ((rc = upload_converted(E->abox, actuator_boxes, (size_t)c.A * BH * BW, PDEC_F64))) return rc;
+  auto up_i = [](DevBuf& b, const int32_t* src, size_t cnt) -> int {
+    PDEC_HIP(b.alloc(sizeof(int32_t) * (cnt ? cnt : 1)));
+    if (cnt) PDEC_HIP(hipMemcpy(b.p, src, sizeof(int32_t) * cnt, hipMemcpyHostToDevice));
+    return PDEC_OK;
+  };
+  if ((rc = up_i(E->sorg, sensor_origin, 2 * (size_t)c.S))) return rc;
+  if ((rc = up_i(E->aorg, actuator_origin, 2 * (size_t)c.A))) return rc;
+  if ((rc = up_i(E->a2s_d, a2s, c.A))) return rc;
+  // candidate actuators per 16x16 block of cells
+  E->nb1 = (n + 15) / 16;
+  std::vector<int32_t> ptr(1, 0), idx;
+  auto meets = [&](int o, int len, int c0) {   // ring interval [o, o+len) meets cells [c0, c0+16)
+    for (int q = 0; q < 16 && c0 + q < n; ++q) {
+      int dlt = c0 + q - o;
+      if (dlt < 0) dlt += n;
+      if (dlt < len) return true;
+    }
+    return false;
+  };
+  for (int bj = 0; bj < E->nb1; ++bj)
+    for (int bi = 0; bi < E->nb1; ++bi) {
+      for (int a = 0; a < c.A; ++a)
+        if (meets(actuator_origin[2 * a], BW, bj * 16) && meets(actuator_origin[2 * a + 1], BH, bi * 16)) idx.push_back(a);
+      ptr.push_back((int32_t)idx.size());
+    }
+  if ((rc = up_i(E->blkptr, ptr.data(), ptr.size()))) return rc;
+  if ((rc = up_i(E->blkidx, idx.data(), idx.size()))) return rc;
+  const size_t nn = (size_t)n * n, Bz = c.B;
+  PDEC_HIP(E->W.alloc(Bz * 2 * E->nl * E->p * 16));
+  PDEC_HIP(E->W2.alloc(Bz * n * E->p * 16));
+  PDEC_HIP(E->fs.alloc(Bz * nn * 16));
+  PDEC_HIP(E->acc.alloc(Bz * nn * 16));
+  PDEC_HIP(E->tmpc.alloc(Bz * nn * 16));
+  PDEC_HIP(E->phat.alloc(Bz * nn * 16));
+  PDEC_HIP(E->yreal.alloc(Bz * nn * 8));
+  PDEC_HIP(E->dots.alloc(Bz * c.S * 8));
+  if ((rc = fluid_set_attrs(*E))) return rc;
+  *h = register_object(std::move(E));
+  return PDEC_OK;
+}

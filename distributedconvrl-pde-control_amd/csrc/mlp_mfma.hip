@@ -651,8 +651,9 @@ static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  ProfScope ps(C, "ddpg_critic_fused");
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
+  ProfScope ps(C, "ddpg_critic_fused", true);
+  for (int rep = 0; rep < ps.reps; ++rep)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
@@ -665,8 +666,9 @@ static int launch_actor(Mlp* C, const FusedArgs& g, int grid) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  ProfScope ps(C, "ddpg_actor_fused");
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
+  ProfScope ps(C, "ddpg_actor_fused", true);
+  for (int rep = 0; rep < ps.reps; ++rep)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }

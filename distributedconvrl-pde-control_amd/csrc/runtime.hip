@@ -171,6 +171,7 @@ int pdec_prof_enable(pdec_handle h, int on) {
   Object* o = lookup(h);
   if (!o) return PDEC_E_HANDLE;
   o->prof = on != 0;
+  o->prof_reps = on > 1 ? on : 1;
   return PDEC_OK;
 }
 
@@ -206,7 +207,7 @@ int pdec_prof_get(pdec_handle h, const char* name, double* mean_ms, int* count) 
     tot += ms;
     ++n;
   }
-  *mean_ms = tot / n;
+  *mean_ms = tot / n / it->second.reps;
   *count = n;
   return PDEC_OK;
 }

@@ -37,16 +37,23 @@ class PDEenv:
         self.oversampling = setup.oversampling
         self.max_value, self.check_max_value = setup.max_value, setup.check_max_value
         cfg = setup.env_cfg(self.B, _lib.dtype_code(dtype))
-        G, Ga, a2s = setup.tables()
         self._h = _lib.Handle()
-        _lib.check(self.lib.pdec_env_create(
-            C.byref(self._h), C.byref(cfg), G.ctypes.data_as(C.POINTER(C.c_double)),
-            Ga.ctypes.data_as(C.POINTER(C.c_double)), a2s.ctypes.data_as(C.POINTER(C.c_int32))))
+        self.is_fluid = bool(getattr(setup, "is_fluid", False))
+        pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        if self.is_fluid:     # spectra are complex: trailing (re, im) axis
+            sb, so, ab, ao, BH, BW, a2s = setup.box_tables()
+            _lib.check(self.lib.pdec_fluid_env_create(
+                C.byref(self._h), C.byref(cfg), BH, BW, sb.ctypes.data_as(pd), so.ctypes.data_as(pi),
+                ab.ctypes.data_as(pd), ao.ctypes.data_as(pi), a2s.ctypes.data_as(pi)))
+        else:
+            G, Ga, a2s = setup.tables()
+            _lib.check(self.lib.pdec_env_create(C.byref(self._h), C.byref(cfg), G.ctypes.data_as(pd),
+                                                Ga.ctypes.data_as(pd), a2s.ctypes.data_as(pi)))
         self.stream = stream
         if stream is not None:
             _lib.check(self.lib.pdec_set_stream(self._h, _stream_ptr(stream)))
         ns, A = setup.state_shape
-        self._yshape = (self.B,) + tuple(reversed(setup.y_shape))
+        self._yshape = (self.B,) + tuple(reversed(setup.y_shape)) + ((2,) if self.is_fluid else ())
         self._sshape = (self.B, A, ns)
         self._ashape = (self.B,) + tuple(reversed(setup.action_shape))
         kw = dict(dtype=dtype, device=self.device)
@@ -65,7 +72,8 @@ class PDEenv:
         self.state = self._state_ring[0]
         self.action = self.action0.clone()
         self._action_prev = self.action0.clone()
-        self.p = torch.zeros((self.B, setup.nx), **kw)
+        self._pshape = self._yshape if self.is_fluid else (self.B, setup.nx)
+        self.p = torch.zeros(self._pshape, **kw)
         self.reward = self._reward_ring[0]
         self._done_flags = self._flag_ring[0]
         self.prev_state = None
@@ -75,6 +83,13 @@ class PDEenv:
 
     # ---- helpers
     def _to_mem(self, a):
+        """Julia-shaped host array -> memory image (column-major == reversed axes); complex fields get a
+        trailing (re, im) axis"""
+        a = np.asarray(a)
+        if np.iscomplexobj(a) or self.is_fluid:
+            a = np.asarray(a, dtype=np.complex128)
+            a = np.swapaxes(a, -1, -2) if a.ndim >= 2 else a
+            return np.stack([a.real, a.imag], axis=-1)
         a = np.asarray(a, dtype=np.float64)
         return a.T if a.ndim == 2 else a
 
@@ -82,6 +97,9 @@ class PDEenv:
         if isinstance(a, torch.Tensor):
             t = a.to(device=self.device, dtype=self.dtype)
         else:
+            a = np.asarray(a)
+            if np.iscomplexobj(a):        # Julia-shaped complex field(s) [.., ny, nx]
+                a = self._to_mem(a)
             t = torch.as_tensor(np.array(a, copy=True), dtype=self.dtype, device=self.device)
         if t.dim() == len(shape) - 1:
             t = t.unsqueeze(0).expand(shape)
@@ -120,7 +138,7 @@ class PDEenv:
 
     def prepare_action(self, action=None):
         action = self.action if action is None else action
-        out = torch.empty((self.B, self.setup.nx), dtype=self.dtype, device=self.device)
+        out = torch.empty(self._pshape, dtype=self.dtype, device=self.device)
         _lib.check(self.lib.pdec_actuate(self._h, _lib.ptr(action), _lib.ptr(out)))
         return out
 
@@ -184,6 +202,8 @@ class PDEenv:
     # ---- Julia-shaped host views for B == 1 (what PDEhook logs, src/PDEhook.jl:54-62)
     def y_julia(self, b=0):
         a = self.y[b].detach().cpu().numpy().astype(np.float64)
+        if self.is_fluid:
+            return (a[..., 0] + 1j * a[..., 1]).T
         return a.T if a.ndim == 2 else a
 
     def state_julia(self, b=0):

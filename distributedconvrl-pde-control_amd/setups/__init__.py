@@ -1,2 +1,3 @@
 from .ks import KSSetup  # noqa: F401
 from .keller_segel import KellerSegelSetup  # noqa: F401
+from .fluid import FluidSetup  # noqa: F401

@@ -107,6 +107,11 @@ typedef struct pdec_env_cfg {
   double reward_denom;
   double action_punish;
   double delta_action_punish;
+  /* 2-D fluid (PDEC_PDE_FLUID_RK4) only; ignored by the 1-D kinds.  Square periodic box: N = nx = ny,
+   * Lx = Ly; y is the vorticity SPECTRUM, Julia ComplexF64[ny, nx] -> memory [B][nx][ny][re,im]. */
+  int ifpad;               /* 1: 3/2-rule de-aliasing (scripts/Fluid/setup/FluidSetup.jl:101) */
+  int sensors_per_axis;    /* sensors on a spa x spa grid, S = spa^2 (FluidSetup.jl:61) */
+  double nu;               /* viscosity (FluidSetup.jl:28) */
 } pdec_env_cfg;
 
 /* sensor_kernels [S][N], actuator_kernels [A][N] (host, double, row = one kernel: the
@@ -115,6 +120,19 @@ typedef struct pdec_env_cfg {
  * in KSSetup.jl:82-245 / KellerSegelSetup.jl:112-332. */
 int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* sensor_kernels,
                     const double* actuator_kernels, const int32_t* a2s);
+
+/* 2-D fluid environment (src/fluid_rk4.jl:122-229 + scripts/Fluid/setup/FluidSetup.jl:139-261).
+ * The sensor / actuator kernels are the thresholded Taylor-vortex bumps the reference keeps
+ * `sparse` (FluidSetup.jl:139-161); each is passed as the dense BW x BH box around its periodic
+ * support: boxes [S][BW][BH] (element (dj, di) at dj*BH + di; di runs along y = the fast axis of
+ * the Julia array), origin [S][2] = {j0 (first x column), i0 (first y row)}, 0-based, wrapping
+ * periodically; likewise for the A actuators.  The compute calls below then take
+ *   y, p   : [B][nx][ny][2]  (spectra; p = fft(forcing), what prepare_action returns, :260)
+ *   state  : [B][A][9*temporal_steps], reward [B][A], action [B][A]. */
+int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, int BH, int BW,
+                          const double* sensor_boxes, const int32_t* sensor_origin,
+                          const double* actuator_boxes, const int32_t* actuator_origin,
+                          const int32_t* a2s);
 
 /* prepare_action(; env): p[B][N] from action[B][A]      (KSSetup.jl:231-245) */
 int pdec_actuate(pdec_handle h, const void* action, void* p_out);

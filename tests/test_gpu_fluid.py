@@ -1,0 +1,154 @@
+"""GPU parity of the 2-D fluid path (src/fluid_rk4.jl + scripts/Fluid/setup/FluidSetup.jl) against the
+NumPy oracle (oracle/fluid.py; PARITY UNPINNED by reference artifacts -- the oracle itself is pinned by the
+analytic KATs in test_oracle.py) plus size-independent properties at the reference's grid sizes.
+fp64 throughout; tolerances are relative to max|reference| and written at each assert."""
+import numpy as np
+import pytest
+
+from util import to_dev
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+F64 = torch.float64
+
+
+def _mem(z):    # Julia complex [.., ny, nx] -> memory [.., nx, ny, 2]
+    z = np.swapaxes(np.asarray(z, dtype=np.complex128), -1, -2)
+    return np.ascontiguousarray(np.stack([z.real, z.imag], axis=-1))
+
+
+def _jul(t):    # memory [.., nx, ny, 2] -> Julia complex [.., ny, nx]
+    a = t.detach().cpu().numpy()
+    return np.swapaxes(a[..., 0] + 1j * a[..., 1], -1, -2)
+
+
+def _pair(pkg, n, ifpad=1, spa=4, K=None, variance=0.08, **kw):
+    from oracle import fluid
+    setup = pkg.FluidSetup(nx=n, ifpad=ifpad, sensors_per_axis=spa, variance=variance, oversampling=K, **kw)
+    cfg = fluid.FluidConfig(nx=n, ifpad=ifpad, sensors_per_axis=spa, variance=variance, oversampling=K)
+    return setup, cfg
+
+
+def _fields(cfg, B, seed, hermitian=True):
+    from oracle import fluid
+    rng = np.random.default_rng(seed)
+    y = np.stack([fluid.ic(cfg, 4, rng) for _ in range(B)])
+    if not hermitian:     # a generic (non-real-field) spectrum exercises the Herm() packing in full
+        y = y + 0.05 * np.abs(y).max() * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))
+    p = np.stack([np.fft.fft2(rng.standard_normal((cfg.ny, cfg.nx))) for _ in range(B)])
+    return y, p
+
+
+@pytest.mark.parametrize("n,ifpad,herm", [(16, 1, True), (16, 1, False), (16, 0, False), (32, 1, False), (24, 1, True),
+                                          (64, 1, True), (64, 0, True), (128, 1, True)])
+def test_rhs_matches_oracle(pkg, n, ifpad, herm):
+    from oracle import fluid
+    setup, cfg = _pair(pkg, n, ifpad)
+    B = 3
+    y, p = _fields(cfg, B, seed=n + ifpad, hermitian=herm)
+    env = pkg.PDEenv(setup, B=B, dtype=F64)
+    out = _jul(env.rhs(to_dev(_mem(y), F64), to_dev(_mem(p), F64)))
+    for b in range(B):
+        ref = fluid.rhs(cfg, y[b].copy(), p[b])
+        assert np.abs(out[b] - ref).max() <= 1e-11 * np.abs(ref).max(), (b, np.abs(out[b] - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,ifpad", [(16, 1), (32, 1), (32, 0)])
+def test_do_step_rk4_matches_oracle(pkg, n, ifpad):
+    from oracle import fluid
+    K = 3
+    setup, cfg = _pair(pkg, n, ifpad, K=K)
+    B = 2
+    y, p = _fields(cfg, B, seed=7)
+    env = pkg.PDEenv(setup, B=B, dtype=F64)
+    yin = to_dev(_mem(y), F64)
+    out, flags = env.do_step(yin, to_dev(_mem(p), F64))
+    assert np.abs(_jul(yin) - y).max() == 0.0          # do_step must not touch its input (src/PDEenv.jl:216-218)
+    for b in range(B):
+        ref = fluid.do_step(cfg, y[b], p[b], K)
+        assert np.abs(_jul(out)[b] - ref).max() <= 1e-11 * np.abs(ref).max()
+    assert int(flags.sum()) == 0
+
+
+def test_closures_and_env_step_match_oracle(pkg):
+    from oracle import fluid
+    n, spa, K = 32, 4, 2
+    setup, cfg = _pair(pkg, n, 1, spa=spa, K=K)
+    B = 3
+    rng = np.random.default_rng(3)
+    y, _ = _fields(cfg, B, seed=11)
+    a0 = rng.uniform(-1, 1, (B, 1, spa * spa))
+    a1 = rng.uniform(-1, 1, (B, 1, spa * spa))
+    env = pkg.PDEenv(setup, B=B, dtype=F64, y0=y)
+    # featurize at reset (FluidSetup.jl:204-245)
+    for b in range(B):
+        st = fluid.featurize(cfg, y[b])
+        assert np.abs(env.state[b].cpu().numpy().T - st).max() <= 1e-12 * max(1.0, np.abs(st).max())
+    # prepare_action (:247-261)
+    pa = _jul(env.prepare_action(to_dev(a1.reshape(B, -1, 1), F64)))
+    for b in range(B):
+        ref = fluid.prepare_action(cfg, a1[b])
+        assert np.abs(pa[b] - ref).max() <= 1e-12 * np.abs(ref).max()
+    # whole (env)(action): src/PDEenv.jl:195-241
+    env.action.copy_(to_dev(a0.reshape(B, -1, 1), F64))
+    env(to_dev(a1.reshape(B, -1, 1), F64))
+    for b in range(B):
+        p = fluid.prepare_action(cfg, a1[b])
+        yn = fluid.do_step(cfg, y[b], p, K)
+        assert np.abs(_jul(env.p)[b] - p).max() <= 1e-12 * np.abs(p).max()
+        assert np.abs(_jul(env.y)[b] - yn).max() <= 1e-11 * np.abs(yn).max()
+        r = fluid.reward_function(cfg, yn, a1[b], a1[b] - a0[b])
+        assert np.abs(env.reward[b].cpu().numpy() - r).max() <= 1e-11 * max(1.0, np.abs(r).max())
+        st = fluid.featurize(cfg, yn)
+        assert np.abs(env.state[b].cpu().numpy().T - st).max() <= 1e-11 * max(1.0, np.abs(st).max())
+    # stand-alone reward closure
+    rr = env.reward_function().cpu().numpy()
+    assert np.abs(rr - env.reward.cpu().numpy()).max() <= 1e-14
+
+
+def test_reward_blowup_flag(pkg):
+    """check_max_value = "reward": the episode ends when max|reward| > max_value (src/PDEenv.jl:232-237)"""
+    setup, cfg = _pair(pkg, 16, 1, spa=4, K=1, max_value=1e-9)
+    y, _ = _fields(cfg, 2, seed=5)
+    env = pkg.PDEenv(setup, B=2, dtype=F64, y0=y)
+    env(torch.zeros(env._ashape, dtype=F64, device="cuda:0"))
+    assert bool(env.done.all().item())
+
+
+@pytest.mark.parametrize("n", [128, 256])
+def test_single_fourier_mode_has_zero_advection_and_exact_viscous_rk4(pkg, n):
+    """Size-independent properties at the reference's own grid sizes: a single Fourier mode
+    has zero Jacobian, so rhs = -nu k^2 w and one RK4 sub-step multiplies it by the degree-4 Taylor
+    polynomial of exp(-nu k^2 h)."""
+    setup, cfg = _pair(pkg, n, 1, spa=8, K=1)
+    ky, kx = 3, 5
+    w = np.zeros((n, n), dtype=complex)
+    w[ky, kx] = n * n * 0.5
+    w[-ky, -kx] = n * n * 0.5
+    env = pkg.PDEenv(setup, B=1, dtype=F64)
+    z = torch.zeros_like(env.y)
+    out = _jul(env.rhs(to_dev(_mem(w[None]), F64), z))[0]
+    lin = -cfg.nu * cfg.kx2ky2 * w
+    assert np.abs(out - lin).max() <= 1e-12 * np.abs(w).max()
+    yn, _ = env.do_step(to_dev(_mem(w[None]), F64), z)
+    x = -cfg.nu * cfg.kx2ky2[ky, kx] * (cfg.dt / 1)
+    poly = 1 + x + x * x / 2 + x ** 3 / 6 + x ** 4 / 24
+    assert np.abs(_jul(yn)[0] - poly * w).max() <= 1e-13 * np.abs(w).max()
+
+
+def test_padded_equals_unpadded_for_band_limited_data(pkg):
+    """3/2-rule property (checks the 1.5*1.5 factor, src/fluid_rk4.jl:176): for spectra confined to |k| < n/3 the
+    de-aliased and the plain product agree."""
+    n = 96
+    rng = np.random.default_rng(2)
+    f = rng.standard_normal((n, n))
+    fh = np.fft.fft2(f)
+    kk = np.abs(np.fft.fftfreq(n, 1.0 / n))
+    fh[kk > n // 6, :] = 0
+    fh[:, kk > n // 6] = 0
+    outs = []
+    for ifpad in (1, 0):
+        setup, _ = _pair(pkg, n, ifpad, spa=4)
+        env = pkg.PDEenv(setup, B=1, dtype=F64)
+        outs.append(_jul(env.rhs(to_dev(_mem(fh[None]), F64), torch.zeros_like(env.y)))[0])
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-11 * np.abs(outs[0]).max()

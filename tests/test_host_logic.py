@@ -139,3 +139,26 @@ def test_world2_gradient_allreduce_equals_single_rank(tmp_path):
         assert p.returncode == 0, e[-2000:]
         m = re.search(r"RESULT (\S+) (\d)", o)
         assert m and float(m.group(1)) <= 1e-12 and m.group(2) == "1", o
+
+
+def test_fluid_setup_box_tables_reproduce_dense_kernels(pkg):
+    """the BW x BH boxes handed to pdec_fluid_env_create are exactly the reference's thresholded bumps
+    (scripts/Fluid/setup/FluidSetup.jl:139-161), and the product setup agrees with the oracle's"""
+    import numpy as np
+    from oracle import fluid
+    n, spa = 32, 4
+    setup = pkg.FluidSetup(nx=n, sensors_per_axis=spa, variance=0.08)
+    cfg = fluid.FluidConfig(nx=n, sensors_per_axis=spa, variance=0.08)
+    assert np.abs(setup.gaussians - cfg.gaussians).max() == 0.0
+    assert np.abs(setup.gaussians_actuators - cfg.gaussians_actuators).max() == 0.0
+    sb, so, ab, ao, BH, BW, a2s = setup.box_tables()
+    for boxes, org, dense in ((sb, so, setup.gaussians), (ab, ao, setup.gaussians_actuators)):
+        for s in range(spa * spa):
+            rebuilt = np.zeros((n, n))
+            for dj in range(BW):
+                for di in range(BH):
+                    rebuilt[(org[s, 1] + di) % n, (org[s, 0] + dj) % n] += boxes[s, dj, di]
+            assert np.abs(rebuilt - dense[s]).max() == 0.0
+    assert setup.oversampling == int(np.floor(16 * n * 0.02)) and setup.state_shape == (9, 16)
+    c = setup.env_cfg(2, 1)
+    assert (c.ifpad, c.sensors_per_axis, c.N, c.S, c.A) == (1, spa, n, 16, 16)
