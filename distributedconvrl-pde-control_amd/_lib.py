@@ -65,6 +65,11 @@ SIGNATURES = {
     "pdec_adam_step": [Handle, _d, _d, _d, _d],
     "pdec_adam_get_state": [Handle, _vp, _vp, _pd], "pdec_adam_set_state": [Handle, _vp, _vp, _pd],
     "pdec_polyak": [Handle, Handle, _d],
+    "pdec_adam_polyak_step": [Handle, Handle, _d, _d, _d, _d, _d],
+    "pdec_policy_act_rng": [Handle, _vp, _i, _d, _d, _i, _u64, _u64, _vp],
+    "pdec_ddpg_update_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _vp],
+    "pdec_ddpg_update_critic_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _vp],
+    "pdec_ddpg_update_actor_async": [Handle] * 4 + [_vp, _i, _d, _d, _vp],
     "pdec_policy_act": [Handle, _vp, _vp, _i, _d, _d, _vp],
     "pdec_randn": [Handle, _vp, _sz, _i, _u64, _u64],
     "pdec_ddpg_critic_grads": [Handle] * 4 + [_vp] * 5 + [_i, _d, _i, _d, _vp],

@@ -140,22 +140,25 @@ class CustomDDPGPolicy:
         actor = self._actor_for(env.dtype, cols)
         na = actor.dims[-1]
         if self._actions is None or self._actions.shape != (cols, na) or self._actions.dtype != env.dtype:
-            self._actions = torch.empty((cols, na), dtype=env.dtype, device=env.device)
-            self._noise = torch.empty((cols, na), dtype=env.dtype, device=env.device)
-        noise = None
-        if learning:                                      # randn(rng, ...) .* act_noise (:201)
-            n = cols * na
-            _lib.check(self.lib.pdec_randn(actor.handle, _lib.ptr(self._noise), n, _lib.dtype_code(env.dtype),
-                                           self._noise_seed, self._noise_off))
-            self._noise_off += (n + 3) // 4
-            noise = self._noise
-        _lib.check(self.lib.pdec_policy_act(actor.handle, _lib.ptr(s), _lib.ptr(noise), cols, float(self.act_noise),
-                                            float(self.act_limit), _lib.ptr(self._actions)))
+            # two buffers, alternated: the env may adopt the returned tensor without copying (PDEenv.__call__(adopt=True))
+            self._action_ring = [torch.empty((cols, na), dtype=env.dtype, device=env.device) for _ in range(2)]
+            self._actions = self._action_ring[0]
+        self._action_ring.reverse()
+        self._actions = self._action_ring[0]
+        # actor forward + randn(rng, ...) .* act_noise + clamp (:189-204): one launch, noise drawn in-kernel from
+        # the counter stream (seed, offset) -- the same numbers pdec_randn would produce
+        _lib.check(self.lib.pdec_policy_act_rng(actor.handle, _lib.ptr(s), cols, float(self.act_noise),
+                                                float(self.act_limit), int(bool(learning)), self._noise_seed,
+                                                self._noise_off, _lib.ptr(self._actions)))
+        if learning:
+            self._noise_off += (cols * na + 3) // 4
         return self._actions.view(env._ashape)
 
     # ---- update!(policy, batch) (src/PDEagent.jl:363-418), fused on the device
-    def update(self, batch):
-        """batch: dict(state [Bu,ns], action [Bu,na], reward [Bu], terminal [Bu], next_state [Bu,ns])"""
+    def update(self, batch, before_actor_half=None):
+        """batch: dict(state [Bu,ns], action [Bu,na], reward [Bu], terminal [Bu], next_state [Bu,ns]).
+        before_actor_half: optional callable run between the critic half and the actor half of the update
+        (e.g. a stream wait on the event of a concurrent acting kernel that still reads the actor)."""
         A, Cn, At, Ct = (self.behavior_actor.model, self.behavior_critic.model, self.target_actor.model,
                          self.target_critic.model)
         dt = Cn.dtype
@@ -163,20 +166,38 @@ class CustomDDPGPolicy:
         Bu = s.shape[0]
         scale = 1.0 if self.reducer is None else 1.0 / self.reducer.world_size
         L = self._losses
+        oc, oa = self.behavior_critic.optimizer, self.behavior_actor.optimizer
+        self._batch_keepalive = (s, a, r, t, sn)
+        if self.reducer is None or self.reducer.world_size == 1:
+            # single device: nothing to all-reduce, so gradient reduction, ADAM and Polyak fuse (4 launches)
+            if before_actor_half is None:
+                _lib.check(self.lib.pdec_ddpg_update_async(
+                    A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r), _lib.ptr(t),
+                    _lib.ptr(sn), Bu, float(self.y), float(self.p), int(self.quirk), float(oa.eta), float(oc.eta),
+                    C.c_void_p(L.data_ptr())))
+                return
+            _lib.check(self.lib.pdec_ddpg_update_critic_async(
+                A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r), _lib.ptr(t),
+                _lib.ptr(sn), Bu, float(self.y), float(self.p), int(self.quirk), float(oc.eta), C.c_void_p(L.data_ptr())))
+            before_actor_half()
+            _lib.check(self.lib.pdec_ddpg_update_actor_async(
+                A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), Bu, float(self.p), float(oa.eta),
+                C.c_void_p(L.data_ptr())))
+            return
         _lib.check(self.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a),
                                                    _lib.ptr(r), _lib.ptr(t), _lib.ptr(sn), Bu, float(self.y), int(self.quirk),
                                                    scale, C.c_void_p(L.data_ptr())))
-        if self.reducer is not None:
-            self.reducer.all_reduce(Cn)
-        self.behavior_critic.update()                                                  # :400
+        self.reducer.all_reduce(Cn)
+        # update!(critic) :400 fused with the critic's Polyak step :415-417 (independent of the actor)
+        _lib.check(self.lib.pdec_adam_polyak_step(Cn.handle, Ct.handle, float(oc.eta), oc.beta[0], oc.beta[1],
+                                                  oc.epsilon, float(self.p)))
+        if before_actor_half is not None:
+            before_actor_half()
         _lib.check(self.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, _lib.ptr(s), Bu, scale,
                                                   C.c_void_p(L.data_ptr() + L.element_size())))
-        if self.reducer is not None:
-            self.reducer.all_reduce(A)
-        self.behavior_actor.update()                                                   # :412
-        _lib.check(self.lib.pdec_polyak(At.handle, A.handle, float(self.p)))           # :415-417
-        _lib.check(self.lib.pdec_polyak(Ct.handle, Cn.handle, float(self.p)))
-        self._batch_keepalive = (s, a, r, t, sn)
+        self.reducer.all_reduce(A)
+        _lib.check(self.lib.pdec_adam_polyak_step(A.handle, At.handle, float(oa.eta), oa.beta[0], oa.beta[1],
+                                                  oa.epsilon, float(self.p)))                  # :412, :415-417
 
     def losses(self):
         """(actor_loss, critic_loss) of the last update (synchronises)"""

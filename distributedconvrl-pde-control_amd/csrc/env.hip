@@ -180,6 +180,8 @@ struct FftGeneric {
     tw = t;
   }
   static __host__ __device__ size_t lds_complex(int N) { return 3 * (size_t)N; }
+  // wave-space mode held in slot j after a forward transform (natural order for this engine)
+  __device__ __forceinline__ int mode_index(int j) const { return tid + j * nt; }
   template <int SGN>
   __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
 #pragma unroll
@@ -230,6 +232,7 @@ struct FftR4 {
     }
   }
   static __host__ __device__ size_t lds_complex(int) { return 2 * (size_t)N; }
+  __device__ __forceinline__ int mode_index(int j) const { return tid + j * NT; }
   template <int SGN>
   __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
 #pragma unroll
@@ -267,6 +270,132 @@ struct FftR4 {
   }
 };
 
+// ---- register-resident single-wave engine for N = 256 (64 lanes x 4 points): NO LDS traffic.
+// In-place radix-4 decimation in frequency: stage st transforms the index digit that currently lives in
+// the register index, then that digit is exchanged with one 2-bit digit of the lane id -- lane bits 5:4 by
+// v_permlane32_swap / v_permlane16_swap, bits 3:2 by bank-masked DPP row shifts, bits 1:0 by DPP quad
+// permutes -- so the next stage again works on the 4 registers of a lane.  The forward transform leaves mode
+// k = (lane>>4) + 4((lane>>2)&3) + 16(lane&3) + 64 j in slot j (digit-reversed); the inverse runs the same
+// steps backwards and returns to the natural order n = lane + 64 j.  The CNAB2 update is pointwise in wave
+// space, so the permuted order only changes which per-mode constants a lane loads (mode_index).
+// Besides being shorter, the transform does not queue behind other kernels' LDS traffic when the PDE step
+// shares CUs with the MFMA update passes (measured: the LDS engine slowed 46 -> 140 us there).
+__device__ __forceinline__ void lane_swap32(unsigned& a, unsigned& b) {   // a[lanes 32-63] <-> b[lanes 0-31]
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void lane_swap16(unsigned& a, unsigned& b) {   // odd 16-lane rows of a <-> even rows of b
+  auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+#define PDEC_DPP(old, src, ctrl, bank) (unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, 0xF, bank, false)
+// exchange the register index (0..3) with lane bits 5:4
+__device__ __forceinline__ void xch_rows(unsigned (&v)[4]) {
+  lane_swap32(v[0], v[2]); lane_swap32(v[1], v[3]);
+  lane_swap16(v[0], v[1]); lane_swap16(v[2], v[3]);
+}
+// ... with lane bits 3:2 (row_ror:8 = lane^8; row_shr:4 / row_shl:4 = lane-4 / lane+4 inside a 16-lane row)
+__device__ __forceinline__ void xch_mid(unsigned (&v)[4]) {
+  unsigned t;
+  t = v[0]; v[0] = PDEC_DPP(v[0], v[2], 0x128, 0xC); v[2] = PDEC_DPP(v[2], t, 0x128, 0x3);
+  t = v[1]; v[1] = PDEC_DPP(v[1], v[3], 0x128, 0xC); v[3] = PDEC_DPP(v[3], t, 0x128, 0x3);
+  t = v[0]; v[0] = PDEC_DPP(v[0], v[1], 0x114, 0xA); v[1] = PDEC_DPP(v[1], t, 0x104, 0x5);
+  t = v[2]; v[2] = PDEC_DPP(v[2], v[3], 0x114, 0xA); v[3] = PDEC_DPP(v[3], t, 0x104, 0x5);
+}
+// ... with lane bits 1:0 (quad_perm [2,3,0,1] = lane^2, [1,0,3,2] = lane^1)
+__device__ __forceinline__ void xch_low(unsigned (&v)[4], bool b1, bool b0) {
+  unsigned s, t;
+  s = PDEC_DPP(0, v[2], 0x4E, 0xF); t = PDEC_DPP(0, v[0], 0x4E, 0xF); v[0] = b1 ? s : v[0]; v[2] = b1 ? v[2] : t;
+  s = PDEC_DPP(0, v[3], 0x4E, 0xF); t = PDEC_DPP(0, v[1], 0x4E, 0xF); v[1] = b1 ? s : v[1]; v[3] = b1 ? v[3] : t;
+  s = PDEC_DPP(0, v[1], 0xB1, 0xF); t = PDEC_DPP(0, v[0], 0xB1, 0xF); v[0] = b0 ? s : v[0]; v[1] = b0 ? v[1] : t;
+  s = PDEC_DPP(0, v[3], 0xB1, 0xF); t = PDEC_DPP(0, v[2], 0xB1, 0xF); v[2] = b0 ? s : v[2]; v[3] = b0 ? v[3] : t;
+}
+// apply an exchange to every 32-bit word of the 4 complex values a lane holds
+template <int WHICH, class T>
+__device__ __forceinline__ void xch_complex(C2<T> (&a)[4], bool b1, bool b0) {
+  constexpr int W = sizeof(T) / 4;      // words per real
+  unsigned w[2 * W][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned tmp[2 * W];
+    __builtin_memcpy(tmp, &a[j], sizeof(C2<T>));
+#pragma unroll
+    for (int c = 0; c < 2 * W; ++c) w[c][j] = tmp[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 2 * W; ++c) {
+    if (WHICH == 2) xch_rows(w[c]);
+    else if (WHICH == 1) xch_mid(w[c]);
+    else xch_low(w[c], b1, b0);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned tmp[2 * W];
+#pragma unroll
+    for (int c = 0; c < 2 * W; ++c) tmp[c] = w[c][j];
+    __builtin_memcpy(&a[j], tmp, sizeof(C2<T>));
+  }
+}
+
+template <class T>
+struct FftWave256 {
+  C2<T>* buf;
+  C2<T> w[3][3];       // twiddles of the three inner stages, per lane
+  int tid;
+  bool b1, b0;
+  static constexpr int N = 256, NT = 64;
+  __device__ __forceinline__ void init(unsigned char* smem, const EnvDev<T>& e, int tid_, int) {
+    tid = tid_;
+    b1 = (tid & 2) != 0; b0 = (tid & 1) != 0;
+    buf = reinterpret_cast<C2<T>*>(smem);
+    const int low[3] = {tid, 4 * (tid & 15), 16 * (tid & 3)};   // k * (index formed by the digits still to transform)
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+      for (int k = 1; k < 4; ++k) w[st][k - 1] = e.tw[(k * low[st]) & 255];
+  }
+  static __host__ __device__ size_t lds_complex(int) { return (size_t)N; }   // only for publish()
+  __device__ __forceinline__ int mode_index(int j) const {
+    return (tid >> 4) + 4 * ((tid >> 2) & 3) + 16 * (tid & 3) + 64 * j;
+  }
+  template <int ST>
+  __device__ __forceinline__ void exchange(C2<T> (&a)[4]) {
+    if (ST == 0) xch_complex<2, T>(a, b1, b0);
+    else if (ST == 1) xch_complex<1, T>(a, b1, b0);
+    else xch_complex<0, T>(a, b1, b0);
+  }
+  template <int ST, int SGN>
+  __device__ __forceinline__ void twiddle(C2<T> (&a)[4]) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      C2<T> tw = w[ST][k - 1];
+      if (SGN > 0) tw.y = -tw.y;
+      a[k] = cmul(a[k], tw);
+    }
+  }
+  template <int SGN>
+  __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
+    if (SGN < 0) {   // forward: natural -> digit-reversed
+      dft_small<4, -1, T>(a); twiddle<0, -1>(a); exchange<0>(a);
+      dft_small<4, -1, T>(a); twiddle<1, -1>(a); exchange<1>(a);
+      dft_small<4, -1, T>(a); twiddle<2, -1>(a); exchange<2>(a);
+      dft_small<4, -1, T>(a);
+    } else {         // inverse: digit-reversed -> natural (unnormalised)
+      dft_small<4, +1, T>(a);
+      exchange<2>(a); twiddle<2, +1>(a); dft_small<4, +1, T>(a);
+      exchange<1>(a); twiddle<1, +1>(a); dft_small<4, +1, T>(a);
+      exchange<0>(a); twiddle<0, +1>(a); dft_small<4, +1, T>(a);
+    }
+  }
+  __device__ __forceinline__ C2<T>* publish(const C2<T> (&a)[KS_MPT]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) buf[tid + NT * j] = a[j];
+    __syncthreads();
+    return buf;
+  }
+};
+
 template <class T, class ENG, bool FUSED>
 __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
                                    const T* __restrict__ action, const T* __restrict__ action_prev,
@@ -275,6 +404,10 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
                                    T* __restrict__ reward_out, int32_t* __restrict__ done) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = e.N, tid = threadIdx.x, nt = blockDim.x;
+  // This kernel is a long dependent chain (63 FFTs) issued by very few waves; when it shares CUs with the
+  // MFMA-dense update kernels it must win issue arbitration or it is starved (measured 46 -> 155 us).
+  // It uses a few percent of the issue slots, so the priority costs the co-running kernels little.
+  __builtin_amdgcn_s_setprio(3);
   ENG eng;
   eng.init(smem_raw, e, tid, nt);
   T* act = reinterpret_cast<T*>(reinterpret_cast<C2<T>*>(smem_raw) + ENG::lds_complex(N));  // [2][A] current
@@ -322,7 +455,7 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   eng.template run<-1>(v);
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
-    const int k = tid + j * nt;
+    const int k = eng.mode_index(j);
     if (k < N) {
       const C2<T> d = e.dhat[k];
       const T c4 = e.c4[k];
@@ -603,7 +736,7 @@ static EnvDev<T> make_dev(const Env& E) {
 
 static size_t ks_lds_bytes(const pdec_env_cfg& c, int r4_log) {
   const size_t ts = dtype_size(c.dtype);
-  return (r4_log ? 2 : 3) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
+  return (r4_log == 1 ? 1 : (r4_log ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
 }
 static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
@@ -630,7 +763,8 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
   hipLaunchKernelGGL((ks_env_step_kernel<T, ENG, F>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,    \
                      (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,    \
                      (T*)p_out, (T*)state_out, (T*)reward_out, done)
-    if (E.r4_log == 4) { if (fused) KS_LAUNCH(FftR4<T COMMA 4>, true); else KS_LAUNCH(FftR4<T COMMA 4>, false); }
+    if (E.r4_log == 1) { if (fused) KS_LAUNCH(FftWave256<T>, true); else KS_LAUNCH(FftWave256<T>, false); }
+    else if (E.r4_log == 4) { if (fused) KS_LAUNCH(FftR4<T COMMA 4>, true); else KS_LAUNCH(FftR4<T COMMA 4>, false); }
     else if (E.r4_log == 5) { if (fused) KS_LAUNCH(FftR4<T COMMA 5>, true); else KS_LAUNCH(FftR4<T COMMA 5>, false); }
     else { if (fused) KS_LAUNCH(FftGeneric<T>, true); else KS_LAUNCH(FftGeneric<T>, false); }
 #undef KS_LAUNCH
@@ -702,7 +836,9 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
     int nt = ((N + KS_MPT - 1) / KS_MPT + 63) / 64 * 64;
     PDEC_REQUIRE(nt <= 1024, "N=%d too large for the in-LDS KS kernel (max 4096)", N);
     E->nthreads = nt;
-    E->r4_log = (N == 256 && !getenv("PDEC_KS_GENERIC_FFT")) ? 4 : ((N == 1024 && !getenv("PDEC_KS_GENERIC_FFT")) ? 5 : 0);
+    // engines: 1 = single-wave register FFT (N = 256), 4 / 5 = radix-4 through LDS (N = 256 / 1024), 0 = generic
+    E->r4_log = (N == 256 && !getenv("PDEC_KS_GENERIC_FFT")) ? (getenv("PDEC_KS_LDS_FFT") ? 4 : 1)
+                                                              : ((N == 1024 && !getenv("PDEC_KS_GENERIC_FFT")) ? 5 : 0);
     E->lds_bytes = ks_lds_bytes(c, E->r4_log);
     PDEC_REQUIRE(E->lds_bytes <= 160 * 1024, "KS kernel needs %zu B of LDS (> 160 KiB)", E->lds_bytes);
     // per-mode constants, scripts/KS/setup/KSSetup.jl:115-123,131-135

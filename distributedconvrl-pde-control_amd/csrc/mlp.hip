@@ -216,17 +216,7 @@ __global__ void act_noise_clamp_kernel(const T* __restrict__ H, const T* __restr
   }
 }
 
-// ---- counter-based normals: Philox4x32-10 + Box-Muller (replaces randn(rng), PDEagent.jl:201)
-__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
+// ---- counter-based normals: Philox4x32-10 + Box-Muller (philox4x32 in mlp.hpp; replaces randn(rng), PDEagent.jl:201)
 template <class T>
 __global__ void randn_kernel(T* __restrict__ dst, size_t n, uint64_t seed, uint64_t offset) {
   const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // 4 normals per thread
@@ -785,7 +775,7 @@ int pdec_ddpg_critic_grads(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec
   PDEC_REQUIRE(A->dtype == C->dtype && At->dtype == C->dtype && Ct->dtype == C->dtype, "ddpg: dtype mismatch");
   PDEC_REQUIRE(At->dims == A->dims && Ct->dims == C->dims, "ddpg: target networks must have the behaviour networks' shapes");
   if (fused_supported(A, C) && A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream)
-    return fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev);
+    return fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev, nullptr);
   return C->dtype == PDEC_F64
              ? critic_grads_t<double>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev)
              : critic_grads_t<float>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev);
@@ -796,7 +786,7 @@ int pdec_ddpg_actor_grads(pdec_handle hA, pdec_handle hC, const void* s, int Bu,
   GET_MLP(C, hC);
   PDEC_REQUIRE(s && Bu >= 1, "pdec_ddpg_actor_grads: null/empty batch");
   PDEC_REQUIRE(A->dtype == C->dtype, "ddpg: dtype mismatch");
-  if (fused_supported(A, C) && A->stream == C->stream) return fused_actor_grads(A, C, s, Bu, grad_scale, actor_loss_dev);
+  if (fused_supported(A, C) && A->stream == C->stream) return fused_actor_grads(A, C, nullptr, s, Bu, grad_scale, actor_loss_dev, nullptr);
   return C->dtype == PDEC_F64 ? actor_grads_t<double>(A, C, s, Bu, grad_scale, actor_loss_dev)
                               : actor_grads_t<float>(A, C, s, Bu, grad_scale, actor_loss_dev);
 }
@@ -830,6 +820,98 @@ int pdec_ddpg_update(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handl
     }
   }
   return PDEC_OK;
+}
+
+
+int pdec_adam_polyak_step(pdec_handle h, pdec_handle h_target, double eta, double beta1, double beta2, double eps,
+                          double rho) {
+  GET_MLP(M, h);
+  Mlp* T = lookup_as<Mlp>(h_target, Kind::Mlp);
+  if (!T) { set_error("pdec_adam_polyak_step: bad target handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(T->dims == M->dims && T->dtype == M->dtype, "pdec_adam_polyak_step: shape/dtype mismatch");
+  if (fused_net_supported(M) && M->stream == T->stream) {
+    const AdamPolyak ap{eta, beta1, beta2, eps, rho};
+    return fused_adam_polyak(M, T, ap);
+  }
+  int rc = pdec_adam_step(h, eta, beta1, beta2, eps);
+  if (rc) return rc;
+  if (M->stream != T->stream) PDEC_HIP(hipStreamSynchronize(M->stream));
+  return pdec_polyak(h_target, h, rho);
+}
+
+// phase bit 0: critic half (critic pass, reduce + ADAM(C) + Polyak(Ct)); bit 1: actor half (actor pass with the
+// updated critic, reduce + ADAM(A) + Polyak(At)).  The split lets a caller order the actor half behind a
+// concurrent reader of the actor's weights (e.g. the acting kernel of the same control step on another stream).
+static int ddpg_update_phases(int phase, pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* s,
+                              const void* a, const void* r, const void* t, const void* snext, int Bu, double gamma,
+                              double rho, int quirk, double eta_actor, double eta_critic, void* losses_dev) {
+  GET_MLP(A, hA);
+  GET_MLP(C, hC);
+  GET_MLP(At, hAt);
+  GET_MLP(Ct, hCt);
+  PDEC_REQUIRE(s && Bu >= 1, "pdec_ddpg_update_async: null/empty batch");
+  PDEC_REQUIRE(!(phase & 1) || (a && r && t && snext), "pdec_ddpg_update_async: null batch array");
+  PDEC_REQUIRE(A->dtype == C->dtype && At->dtype == C->dtype && Ct->dtype == C->dtype, "ddpg: dtype mismatch");
+  PDEC_REQUIRE(At->dims == A->dims && Ct->dims == C->dims, "ddpg: target networks must have the behaviour networks' shapes");
+  const size_t ts = dtype_size(C->dtype);
+  char* l0 = (char*)losses_dev;
+  char* l1 = l0 ? l0 + ts : nullptr;
+  const bool one_stream = A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream;
+  int rc;
+  if (fused_supported(A, C) && one_stream) {
+    // 4 launches: critic pass, reduce+ADAM(C)+Polyak(Ct), actor pass (updated critic), reduce+ADAM(A)+Polyak(At)
+    const AdamPolyak apc{eta_critic, 0.9, 0.999, 1e-8, rho}, apa{eta_actor, 0.9, 0.999, 1e-8, rho};
+    if ((phase & 1) &&
+        (rc = fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, 1.0, l0, &apc)))
+      return rc;
+    if (phase & 2) return fused_actor_grads(A, C, At, s, Bu, 1.0, l1, &apa);
+    return PDEC_OK;
+  }
+  if (phase & 1) {
+    if ((rc = pdec_ddpg_critic_grads(hA, hC, hAt, hCt, s, a, r, t, snext, Bu, gamma, quirk, 1.0, l0))) return rc;
+    if ((rc = pdec_adam_step(hC, eta_critic, 0.9, 0.999, 1e-8))) return rc;         // :400
+    if ((rc = pdec_polyak(hCt, hC, rho))) return rc;                                // :415-417 (critic pair)
+  }
+  if (phase & 2) {
+    if ((rc = pdec_ddpg_actor_grads(hA, hC, s, Bu, 1.0, l1))) return rc;
+    if (A->stream != C->stream) PDEC_HIP(hipStreamSynchronize(C->stream));
+    if ((rc = pdec_adam_step(hA, eta_actor, 0.9, 0.999, 1e-8))) return rc;          // :412
+    if ((rc = pdec_polyak(hAt, hA, rho))) return rc;                                // :415-417 (actor pair)
+  }
+  return PDEC_OK;
+}
+
+int pdec_ddpg_update_async(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* s,
+                           const void* a, const void* r, const void* t, const void* snext, int Bu, double gamma,
+                           double rho, int quirk, double eta_actor, double eta_critic, void* losses_dev) {
+  return ddpg_update_phases(3, hA, hC, hAt, hCt, s, a, r, t, snext, Bu, gamma, rho, quirk, eta_actor, eta_critic, losses_dev);
+}
+int pdec_ddpg_update_critic_async(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* s,
+                                  const void* a, const void* r, const void* t, const void* snext, int Bu, double gamma,
+                                  double rho, int quirk, double eta_critic, void* losses_dev) {
+  return ddpg_update_phases(1, hA, hC, hAt, hCt, s, a, r, t, snext, Bu, gamma, rho, quirk, 0.0, eta_critic, losses_dev);
+}
+int pdec_ddpg_update_actor_async(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* s, int Bu,
+                                 double rho, double eta_actor, void* losses_dev) {
+  return ddpg_update_phases(2, hA, hC, hAt, hCt, s, nullptr, nullptr, nullptr, nullptr, Bu, 0.0, rho, 0, eta_actor, 0.0,
+                            losses_dev);
+}
+
+int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
+                        int learning, uint64_t seed, uint64_t offset, void* actions_out) {
+  GET_MLP(M, actor);
+  PDEC_REQUIRE(state && actions_out && cols >= 1, "pdec_policy_act_rng: null/empty");
+  if (fused_net_supported(M) && M->dims[M->L] == 1 && M->dims[1] <= 31)
+    return fused_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out);
+  void* noise = nullptr;
+  if (learning) {
+    const size_t n = (size_t)cols * M->dims[M->L];
+    if (M->noise.bytes < n * dtype_size(M->dtype)) PDEC_HIP(M->noise.alloc(n * dtype_size(M->dtype)));
+    int rc = pdec_randn(actor, M->noise.p, n, M->dtype, seed, offset);
+    if (rc) return rc;
+    noise = M->noise.p;
+  }
+  return pdec_policy_act(actor, state, noise, cols, act_noise, act_limit, actions_out);
 }
 
 }  // extern "C"

@@ -1,6 +1,7 @@
 // mlp.hpp -- the MLP object shared by mlp.hip (generic path) and mlp_mfma.hip (fp32 MFMA path)
 #pragma once
 #include <algorithm>
+#include <cstdint>
 
 #include "common.hpp"
 
@@ -19,6 +20,8 @@ struct Mlp : Object {
   DevBuf scratch;                    // loss statistics / device scalars
   int kchunk = 512, nsplit_max = 0, dx_index = 0;
   DevBuf fw, fslab;                  // fused-path padded weight image / per-workgroup gradient slabs
+  DevBuf stamps;                     // diagnostic phase stamps (PDEC_STAMPS=1)
+  DevBuf noise;                      // internal exploration-noise buffer (pdec_policy_act_rng fallback)
   bool fw_dirty = true;
 
   Mlp() : Object(Kind::Mlp) {}
@@ -33,10 +36,33 @@ struct Mlp : Object {
   T* dy_buf(int) { return dy.as<T>(); }
 };
 
+// Philox4x32-10 counter-based generator (the exploration noise that replaces randn(rng), src/PDEagent.jl:201)
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
 // mlp_mfma.hip: fused fp32 MFMA DDPG passes (3-layer actor/critic pairs)
+struct AdamPolyak {
+  double eta, b1, b2, eps, rho;
+};
 bool fused_supported(const Mlp* A, const Mlp* C);
+bool fused_net_supported(const Mlp* M);
+// apply != nullptr: the slab reduction also performs ADAM on the network, Polyak into its target and refreshes
+// the padded weight images (single-GPU path: no all-reduce between gradient and update)
 int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
-                       const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev);
-int fused_actor_grads(Mlp* A, Mlp* C, const void* s, int Bu, double grad_scale, void* loss_dev);
+                       const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,
+                       const AdamPolyak* apply);
+int fused_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double grad_scale, void* loss_dev,
+                      const AdamPolyak* apply);
+int fused_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap);
+int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning,
+                     uint64_t seed, uint64_t offset, void* actions_out);
 
 }  // namespace pdec

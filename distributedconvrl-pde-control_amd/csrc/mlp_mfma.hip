@@ -102,10 +102,21 @@ __device__ __forceinline__ void load_small(const SmallLds& s, const FNet& f, int
   for (int i = tid; i < f.HP; i += FTHREADS) { s.b1[i] = f.w[f.ob1 + i]; s.b2[i] = f.w[f.ob2 + i]; s.w3[i] = f.w[f.ow3 + i]; }
   if (tid < 4) s.b3[tid] = f.w[f.ob3 + tid];
 }
+// global -> LDS copy of a padded weight image: loads are issued in batches of 6 x 16 B per lane before the
+// first LDS store so that the L2 latency is paid once per batch, not once per element
 __device__ __forceinline__ void load_big(float* dst, const float* src, int n, int tid) {
   const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
   f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-  for (int i = tid; i < n / 4; i += FTHREADS) d4[i] = s4[i];
+  const int n4 = n / 4;
+  int i = tid;
+  for (; i + 5 * FTHREADS < n4; i += 6 * FTHREADS) {
+    f32x4 v[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) v[u] = s4[i + u * FTHREADS];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) d4[i + u * FTHREADS] = v[u];
+  }
+  for (; i < n4; i += FTHREADS) d4[i] = s4[i];
 }
 
 // h = relu(W1 x + b1): x given as KT register rows (lane holds x[4t+q][col])
@@ -219,15 +230,19 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NACC], const float* L, co
     }
   }
 }
+// Slab layout (chunk-major): a "chunk" is one accumulator register of one 16x16 output tile = 64 floats in lane
+// order; chunk c of workgroup z lives at ((c * nslab + z) * 64).  A wave therefore stores 256 contiguous bytes
+// per instruction, and the reduction kernel streams one contiguous nslab * 256 B region per chunk.
+// Tiles are numbered T = T0 + ti * nR + tk; element (r, lane) of a tile is row 16 ti + 4 (lane>>4) + r,
+// column 16 tk + (lane & 15) of the pass's output matrix.
 template <int NACC>
-__device__ __forceinline__ void store_pass(const f32x4 (&acc)[NACC], float* out, int ldo, int nL, int nR, int w, int lr, int q) {
+__device__ __forceinline__ void store_pass(const f32x4 (&acc)[NACC], float* slab, int nslab, int T0, int nL, int nR, int w, int l) {
 #pragma unroll
   for (int pp = 0; pp < NACC; ++pp) {
     const int p = w + 8 * pp;
     if (p < nL * nR) {
-      const int ti = p / nR, tk = p - ti * nR;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[(16 * ti + 4 * q + r) * ldo + 16 * tk + lr] = acc[pp][r];
+      for (int r = 0; r < 4; ++r) slab[((size_t)(4 * (T0 + p) + r) * nslab + blockIdx.x) * 64 + l] = acc[pp][r];
     }
   }
 }
@@ -243,14 +258,19 @@ struct FusedArgs {
   int Bu, ns, na;
   float gamma;
   int quirk;
-  float* slab;                // [gridDim.x][slab_stride]
-  int slab_stride;
+  float* slab;                // chunk-major partial gradients, see store_pass
+  unsigned long long* stamps; // diagnostic only (PDEC_STAMPS=1): [gridDim.x][16] s_memtime at phase boundaries
 };
 
-// slab layouts (floats)
-//   critic: dW3 [16][HP] | dW2 [HP][HP] | dW1 [HP][16] | stats[8]
-//   actor : dW3 [16][HPa] | dW2 [HPa][HPa] | dW1 [HPa][16] | stats[8]
-static inline int slab_floats(int HP) { return 16 * HP + HP * HP + HP * 16 + 8; }
+// diagnostic phase stamp: wave 0 / lane 0 of each workgroup; a null pointer (the default) costs one scalar branch
+#define STAMP(k)                                                                                       \
+  do {                                                                                                 \
+    if (g.stamps && threadIdx.x == 0) g.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// tiles per workgroup: dW3 [16][HP] (MT tiles) | dW2 [HP][HP] (MT*MT) | dW1 [HP][16] (MT); then one stats chunk
+static inline int slab_tiles(int MT) { return MT + MT * MT + MT; }
+static inline size_t slab_floats_total(int MT, int nslab) { return ((size_t)4 * slab_tiles(MT) + 1) * nslab * 64; }
 
 // block-wide deterministic sum (fixed tree)
 __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
@@ -281,6 +301,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   const bool valid = col < g.Bu;
 
   // ---- phase T: target actor + target critic
+  STAMP(0);
   load_big(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
   load_small(SC, g.Ct, tid);
   load_small(SA, g.At, tid);
@@ -288,8 +309,22 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   // mean reward for the reference's (1xBu).+(Bu) broadcast: every workgroup reduces all of r in the
   // same fixed order, so the value is identical everywhere
   float rsum = 0.f;
-  for (int i = tid; i < g.Bu; i += FTHREADS) rsum += g.r[i];
+  if (g.quirk) {   // 16-B loads, 8 in flight per lane: the L2 latency is paid per batch, not per element
+    const int n4 = ((reinterpret_cast<uintptr_t>(g.r) & 15) == 0) ? g.Bu / 4 : 0;
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(g.r);
+    int i = tid;
+    for (; i + 7 * FTHREADS < n4; i += 8 * FTHREADS) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r4[i + u * FTHREADS];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rsum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+    for (; i < n4; i += FTHREADS) { const f32x4 v = r4[i]; rsum += (v[0] + v[1]) + (v[2] + v[3]); }
+    for (int k = 4 * n4 + tid; k < g.Bu; k += FTHREADS) rsum += g.r[k];
+  }
   const float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads
+  STAMP(1);
 
   float x[4];   // input rows 4t+q for t < 4 (K0 <= 15)
 #pragma unroll
@@ -316,10 +351,12 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     tgt = g.gamma * (1.f - tv) * qt;
   }
   __syncthreads();
+  STAMP(2);
   // ---- phase Q: behaviour critic forward
   load_big(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
   load_small(SC, g.C, tid);
   __syncthreads();
+  STAMP(3);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int row = 4 * t + q;
@@ -340,13 +377,14 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   const bool rep = valid && q == 0;
   float st0 = rep ? c : 0.f, st1 = rep ? c * c : 0.f, st2 = rep ? rv : 0.f, st3 = rep ? rv * rv : 0.f,
         st4 = rep ? (rv + c) * (rv + c) : 0.f;
-  float* slab = g.slab + (size_t)blockIdx.x * g.slab_stride;
+  const int nslab = gridDim.x;
   float* Lm = Wreg;                 // staging images overlay the big weight region
   float* Rm = Wreg + HP * LDP;
   const int cw = (w & 3) * 16 + lr;
 
   // ---- pass A: dW3/db3 = dq x [h2; 1]^T
   __syncthreads();
+  STAMP(4);
   for (int i = tid; i < 16 * LDP; i += FTHREADS) Lm[i] = 0.f;
   {
     f32x4 accA[(MT + 7) / 8];
@@ -360,14 +398,16 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
       __syncthreads();
       gemm_pass(accA, Lm, Rm, 1, MT, w, lr, q);
     }
-    store_pass(accA, slab, HP, 1, MT, w, lr, q);
+    store_pass(accA, g.slab, nslab, 0, 1, MT, w, l);
   }
   // ---- dz2, dh1 = W2^T dz2, dz1
   f32x4 dz2[MT];
   head_bwd<MT>(dz2, h2, SC.w3, dq, q);
   __syncthreads();
+  STAMP(5);
   load_big(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
   __syncthreads();
+  STAMP(6);
   f32x4 dz1[MT];
   layer_hh<MT, MT, false>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
 #pragma unroll
@@ -375,6 +415,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
 #pragma unroll
     for (int r = 0; r < 4; ++r) dz1[m][r] = h1[m][r] > 0.f ? dz1[m][r] : 0.f;
   // ---- pass B: dW2/db2 = dz2 x [h1; 1]^T
+  STAMP(7);
   {
     f32x4 accB[(MT * MT + 7) / 8];
     zero_(accB);
@@ -387,9 +428,10 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
       __syncthreads();
       gemm_pass(accB, Lm, Rm, MT, MT, w, lr, q);
     }
-    store_pass(accB, slab + 16 * HP, HP, MT, MT, w, lr, q);
+    store_pass(accB, g.slab, nslab, MT, MT, MT, w, l);
   }
   // ---- pass C: dW1/db1 = dz1 x [x0; 1]^T
+  STAMP(8);
   {
     f32x4 accC[(MT + 7) / 8];
     zero_(accC);
@@ -406,17 +448,28 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
       __syncthreads();
       gemm_pass(accC, Lm, Rm, MT, 1, w, lr, q);
     }
-    store_pass(accC, slab + 16 * HP + HP * HP, 16, MT, 1, w, lr, q);
+    store_pass(accC, g.slab, nslab, MT + MT * MT, MT, 1, w, l);
   }
-  st0 = block_sum(st0, red, tid);
-  st1 = block_sum(st1, red, tid);
-  st2 = block_sum(st2, red, tid);
-  st3 = block_sum(st3, red, tid);
-  st4 = block_sum(st4, red, tid);
-  if (tid == 0) {
-    float* st = slab + 16 * HP + HP * HP + HP * 16;
-    st[0] = st0; st[1] = st1; st[2] = st2; st[3] = st3; st[4] = st4; st[5] = 0.f; st[6] = 0.f; st[7] = 0.f;
+  STAMP(9);
+  {   // the five loss statistics in one fixed-order block reduction
+    float sv[5] = {st0, st1, st2, st3, st4};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      for (int off = 32; off > 0; off >>= 1) sv[k] += __shfl_xor(sv[k], off);
+    __syncthreads();
+    float* red5 = Wreg;   // staging region is free again
+    if (l == 0)
+      for (int k = 0; k < 5; ++k) red5[w * 8 + k] = sv[k];
+    __syncthreads();
+    if (tid < 8) {
+      float* st = g.slab + ((size_t)(4 * (2 * MT + MT * MT)) * nslab + blockIdx.x) * 64;
+      float a = 0.f;
+      if (tid < 5)
+        for (int ww = 0; ww < FTHREADS / 64; ++ww) a += red5[ww * 8 + tid];
+      st[tid] = a;
+    }
   }
+  STAMP(10);
 }
 
 // ------------------------------------------------------------------ actor pass
@@ -491,7 +544,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dza1[m][r] = ha1[m][r] > 0.f ? dza1[m][r] : 0.f;
   // ---- weight gradients of the actor (three small column contractions)
-  float* slab = g.slab + (size_t)blockIdx.x * g.slab_stride;
+  const int nslab = gridDim.x;
   float* I0 = Wreg;                       // DZ3 [16][LDP]
   float* I1 = I0 + 16 * LDP;              // HA2aug [HPa][LDP]
   float* I2 = I1 + HPa * LDP;             // DZA2 [HPa][LDP]
@@ -522,54 +575,135 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
     gemm_pass(acc2, I2, I3, MTA, MTA, w, lr, q);
     gemm_pass(acc1, I4, I5, MTA, 1, w, lr, q);
   }
-  store_pass(acc3, slab, HPa, 1, MTA, w, lr, q);
-  store_pass(acc2, slab + 16 * HPa, HPa, MTA, MTA, w, lr, q);
-  store_pass(acc1, slab + 16 * HPa + HPa * HPa, 16, MTA, 1, w, lr, q);
+  store_pass(acc3, g.slab, nslab, 0, 1, MTA, w, l);
+  store_pass(acc2, g.slab, nslab, MTA, MTA, MTA, w, l);
+  store_pass(acc1, g.slab, nslab, MTA + MTA * MTA, MTA, 1, w, l);
   st0 = block_sum(st0, red, tid);
   if (tid == 0) {
-    float* st = slab + 16 * HPa + HPa * HPa + HPa * 16;
+    float* st = g.slab + ((size_t)(4 * (2 * MTA + MTA * MTA)) * nslab + blockIdx.x) * 64;
     st[0] = st0;
     for (int i = 1; i < 8; ++i) st[i] = 0.f;
   }
 }
 
-// ------------------------------------------------------------------ slab reduction
+// ------------------------------------------------------------------ slab reduction + ADAM + Polyak + image refresh
 // flat internal gradient layout [W1 [H][K0], b1 [H], W2 [H][H], b2 [H], W3 [1][H], b3]
-__global__ __launch_bounds__(256) void fused_reduce_kernel(const float* __restrict__ slabs, int nslab, int stride, int K0, int H, int HP,
-                                    float* __restrict__ grads, float scale, int mode, int Bu, int quirk,
-                                    float* __restrict__ loss_out) {
-  // block = 16 outputs x 16 slab groups; each thread sums every 16th slab, then a fixed-order
-  // combine over the groups (deterministic; 16x shorter dependent chains than one thread per output)
-  __shared__ float part[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + tx;
+struct FinishArgs {
+  const float* slabs;          // chunk-major per-workgroup partial gradients (store_pass)
+  int nslab, K0, H, MT;
+  float* grads;                // flat gradient buffer (written when nslab > 0, read when nslab == 0)
+  float scale;
+  int mode, Bu, quirk;         // loss finalisation (mode 0 critic, 1 actor)
+  float* loss_out;
+  int apply;                   // != 0: ADAM step on p, Polyak into pt, refresh the padded images
+  float *p, *m, *v, *pt, *fw, *fwt;
+  FNet lay;
+  double eta, b1, b2, eps, omb1p, omb2p;
+  float rho, omr;
+};
+
+// Flux.Optimise.ADAM (Float64 arithmetic, as the broadcast promotes; src/custom_nna.jl:23-24), then
+// dest = rho dest + (1-rho) src (src/PDEagent.jl:415-417) for this one parameter, and its copies in the
+// padded LDS images the fused passes stage from (so no separate prep launch is needed)
+__device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float gi, float p0, float m0, float v0, float pt0) {
+  // no FMA contraction: Julia evaluates these broadcasts with separate multiplies and adds, and the two call
+  // sites of this function (fused reduce+apply, apply after an all-reduce) must round identically
+#pragma clang fp contract(off)
+  const double gd = (double)gi;
+  const float mt = (float)(g.b1 * (double)m0 + (1.0 - g.b1) * gd);
+  const float vt = (float)(g.b2 * (double)v0 + (1.0 - g.b2) * gd * gd);
+  g.m[i] = mt;
+  g.v[i] = vt;
+  const float delta = (float)((double)mt / g.omb1p / (sqrt((double)vt / g.omb2p) + g.eps) * g.eta);
+  const float pn = p0 - delta;
+  g.p[i] = pn;
+  const int K0 = g.K0, H = g.H;
+  int o1, o2 = -1, j = i;
+  if (j < H * K0) o1 = g.lay.oW1 + (j / K0) * KXP + (j % K0);
+  else if ((j -= H * K0) < H) o1 = g.lay.ob1 + j;
+  else if ((j -= H) < H * H) { o1 = g.lay.oW2 + (j / H) * g.lay.LDW + (j % H); o2 = g.lay.oW2T + (j % H) * g.lay.LDW + (j / H); }
+  else if ((j -= H * H) < H) o1 = g.lay.ob2 + j;
+  else if ((j -= H) < H) o1 = g.lay.ow3 + j;
+  else o1 = g.lay.ob3;
+  if (g.fw) { g.fw[o1] = pn; if (o2 >= 0) g.fw[o2] = pn; }
+  if (g.pt) {
+    const float tn = g.rho * pt0 + g.omr * pn;
+    g.pt[i] = tn;
+    if (g.fwt) { g.fwt[o1] = tn; if (o2 >= 0) g.fwt[o2] = tn; }
+  }
+}
+
+// grid: nslab > 0 -> one block per chunk (4 * slab_tiles(MT)); nslab == 0 -> ceil(n / 64) blocks (apply from grads).
+// block = 64 chunk elements x 16 slab groups (1024 threads): each thread sums every 16th slab (16 loads in flight,
+// a contiguous 256-B row each), then a fixed-order combine over the groups -> deterministic, so data-parallel
+// replicas stay bit-identical.
+__global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g) {
+  __shared__ float part[16][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int K0 = g.K0, H = g.H, MT = g.MT;
   const int n = H * K0 + H + H * H + H + H + 1;
-  const int o3 = 0, o2 = 16 * HP, o1 = 16 * HP + HP * HP, ost = o1 + HP * 16;
-  float acc = 0.f;
-  if (i < n) {
-    int src, j = i;
-    if (j < H * K0) src = o1 + (j / K0) * 16 + (j % K0);
-    else if ((j -= H * K0) < H) src = o1 + j * 16 + K0;
-    else if ((j -= H) < H * H) src = o2 + (j / H) * HP + (j % H);
-    else if ((j -= H * H) < H) src = o2 + j * HP + H;
-    else if ((j -= H) < H) src = o3 + j;
-    else src = o3 + H;
-    for (int z = ty; z < nslab; z += 16) acc += slabs[(size_t)z * stride + src];
+  const int offb1 = H * K0, offW2 = offb1 + H, offb2 = offW2 + H * H, offW3 = offb2 + H, offb3 = offW3 + H;
+  if (g.nslab > 0) {
+    const int c = blockIdx.x, T = c >> 2, r = c & 3;
+    int i = -1;   // flat parameter index of this chunk element (-1: padding)
+    {
+      const int q = tx >> 4, lr = tx & 15;
+      if (T < MT) {                                  // dW3 / db3: only row 0 of the [16][HP] product is real
+        const int row = 4 * q + r, col = 16 * T + lr;
+        if (row == 0) i = col < H ? offW3 + col : (col == H ? offb3 : -1);
+      } else if (T < MT + MT * MT) {                 // dW2 / db2
+        const int u = T - MT, ti = u / MT, tk = u - ti * MT;
+        const int row = 16 * ti + 4 * q + r, col = 16 * tk + lr;
+        if (row < H) i = col < H ? offW2 + row * H + col : (col == H ? offb2 + row : -1);
+      } else {                                       // dW1 / db1
+        const int ti = T - MT - MT * MT;
+        const int row = 16 * ti + 4 * q + r, col = lr;
+        if (row < H) i = col < K0 ? row * K0 + col : (col == K0 ? offb1 + row : -1);
+      }
+    }
+    if (__syncthreads_or(i >= 0)) {
+      float p0 = 0.f, m0 = 0.f, v0 = 0.f, pt0 = 0.f;
+      if (g.apply && ty == 0 && i >= 0) {            // issue the parameter loads before the slab stream
+        p0 = g.p[i]; m0 = g.m[i]; v0 = g.v[i];
+        if (g.pt) pt0 = g.pt[i];
+      }
+      float acc = 0.f;
+      if (i >= 0) {
+        const float* sp = g.slabs + (size_t)c * g.nslab * 64 + tx;
+        int z = ty;
+        for (; z + 240 < g.nslab; z += 256) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = sp[(size_t)(z + 16 * u) * 64];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; z < g.nslab; z += 16) acc += sp[(size_t)z * 64];
+      }
+      part[ty][tx] = acc;
+      __syncthreads();
+      if (ty == 0 && i >= 0) {
+        float a = 0.f;
+        for (int k = 0; k < 16; ++k) a += part[k][tx];
+        a *= g.scale;
+        g.grads[i] = a;
+        if (g.apply) finish_param(g, i, a, p0, m0, v0, pt0);
+      }
+    }
+  } else {
+    const int i = blockIdx.x * 64 + tx;
+    if (ty == 0 && i < n && g.apply) finish_param(g, i, g.grads[i], g.p[i], g.m[i], g.v[i], g.pt ? g.pt[i] : 0.f);
   }
-  part[ty][tx] = acc;
-  __syncthreads();
-  if (ty == 0 && i < n) {
-    float a = 0.f;
-    for (int k = 0; k < 16; ++k) a += part[k][tx];
-    grads[i] = a * scale;
-  }
-  if (blockIdx.x == 0 && loss_out) {   // block 0 also finalises the loss (fixed-order tree -> deterministic)
+  if (blockIdx.x == 0 && g.loss_out && g.nslab > 0) {   // block 0 also finalises the loss (fixed-order tree -> deterministic)
     __shared__ double red[5][256];
     const int tid = threadIdx.x;
+    const float* stc = g.slabs + (size_t)(4 * (2 * MT + MT * MT)) * g.nslab * 64;   // stats chunk
     double st[5] = {0, 0, 0, 0, 0};
-    for (int z = tid; z < nslab; z += 256)
-      for (int k = 0; k < 5; ++k) st[k] += (double)slabs[(size_t)z * stride + ost + k];
-    for (int k = 0; k < 5; ++k) red[k][tid] = st[k];
+    if (tid < 256) {
+      for (int z = tid; z < g.nslab; z += 256)
+        for (int k = 0; k < 5; ++k) st[k] += (double)stc[(size_t)z * 64 + k];
+      for (int k = 0; k < 5; ++k) red[k][tid] = st[k];
+    }
     __syncthreads();
     for (int sft = 128; sft > 0; sft >>= 1) {
       if (tid < sft)
@@ -577,17 +711,71 @@ __global__ __launch_bounds__(256) void fused_reduce_kernel(const float* __restri
       __syncthreads();
     }
     if (tid == 0) {
-      const double inv = 1.0 / Bu;
-      if (mode == 0)   // critic: quirk -> mean(c^2) + 2 mean(c) mean(r) + mean(r^2); else mean((r+c)^2)
-        *loss_out = (float)(quirk ? red[1][0] * inv + 2.0 * (red[0][0] * inv) * (red[2][0] * inv) + red[3][0] * inv
-                                  : red[4][0] * inv);
-      else             // actor: -mean(q)
-        *loss_out = (float)(-red[0][0] * inv);
+      const double inv = 1.0 / g.Bu;
+      if (g.mode == 0)   // critic: quirk -> mean(c^2) + 2 mean(c) mean(r) + mean(r^2); else mean((r+c)^2)
+        *g.loss_out = (float)(g.quirk ? red[1][0] * inv + 2.0 * (red[0][0] * inv) * (red[2][0] * inv) + red[3][0] * inv
+                                      : red[4][0] * inv);
+      else               // actor: -mean(q)
+        *g.loss_out = (float)(-red[0][0] * inv);
     }
   }
 }
 
+// ------------------------------------------------------------------ fused policy act
+// actions = clamp(actor(state) + randn * act_noise, +-act_limit)  (src/PDEagent.jl:183-207) in ONE launch on the
+// same MFMA building blocks as the update passes (16 columns per wave, layer outputs chained as B operands);
+// exploration noise from the same Philox counter stream as pdec_randn (element index = column), so both
+// paths draw identical numbers.
+#define ACT_THREADS 256
+template <int MTA>
+__global__ __launch_bounds__(ACT_THREADS) void policy_act_fused_kernel(FNet f, const float* __restrict__ state, int cols, int ns,
+                                                                      float act_noise, float lim, int learning, int tanh_out,
+                                                                      uint64_t seed, uint64_t offset, float* __restrict__ out) {
+  extern __shared__ __align__(16) float smem[];
+  // short latency-critical kernel (the PDE step waits for it): outrank the update passes it may share CUs with
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
+  const int HPa = 16 * MTA, LDWa = HPa + 4;
+  float* sa = smem;                                  // small image
+  float* saW2 = sa + (HPa * LDW1 + 3 * HPa + 4);     // W2 [HPa][LDWa]
+  const SmallLds SA = carve_small(sa, HPa);
+  for (int i = tid; i < HPa * KXP; i += ACT_THREADS) SA.W1[(i / KXP) * LDW1 + (i % KXP)] = f.w[f.oW1 + i];
+  for (int i = tid; i < HPa; i += ACT_THREADS) { SA.b1[i] = f.w[f.ob1 + i]; SA.b2[i] = f.w[f.ob2 + i]; SA.w3[i] = f.w[f.ow3 + i]; }
+  if (tid < 4) SA.b3[tid] = f.w[f.ob3 + tid];
+  for (int i = tid; i < HPa * LDWa; i += ACT_THREADS) saW2[i] = f.w[f.oW2 + i];
+  __syncthreads();
+  const int c = blockIdx.x * (ACT_THREADS / 4) + w * 16 + lr;
+  const bool valid = c < cols;
+  float x[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 4 * t + q;
+    x[t] = (valid && row < ns) ? state[(size_t)c * ns + row] : 0.f;
+  }
+  f32x4 h1[MTA], h2[MTA];
+  layer_in<MTA, 4>(h1, x, SA, lr, q);
+  layer_hh<MTA, MTA, true>(h2, h1, saW2, LDWa, SA.b2, lr, q);
+  relu_<MTA>(h2);
+  float o = head<MTA>(h2, SA.w3, SA.b3[0], q);
+  if (!valid || q != 0) return;
+  if (tanh_out) o = tanhf(o);
+  if (learning) {
+    const uint64_t ctr = offset + (uint64_t)(c >> 2);
+    uint32_t ph[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    philox4x32(ph, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int hsel = (c >> 1) & 1;
+    const double sc = 1.0 / 4294967296.0;
+    const double u1 = ((double)ph[2 * hsel] + 0.5) * sc, u2 = ((double)ph[2 * hsel + 1] + 0.5) * sc;
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+    const float z = (float)((c & 1) ? rad * sin(ang) : rad * cos(ang));
+    o += z * act_noise;
+  }
+  out[c] = fminf(fmaxf(o, -lim), lim);
+}
+
 // ------------------------------------------------------------------ host side
+static int mt_of(int H) { return (H + 1 + 15) / 16; }
+
 static bool fused_disabled() {
   static int v = -1;
   if (v < 0) {
@@ -597,7 +785,14 @@ static bool fused_disabled() {
   return v == 1;
 }
 
-static int mt_of(int H) { return (H + 1 + 15) / 16; }
+// one 3-layer fp32 net [K0, H, H, 1] relu/relu/(tanh|identity) whose padded image the fused kernels can stage
+bool fused_net_supported(const Mlp* M) {
+  if (fused_disabled() || M->dtype != PDEC_F32 || M->L != 3) return false;
+  if (M->dims[1] != M->dims[2] || M->dims[0] + 1 > KXP || M->dims[3] != 1) return false;
+  if (M->acts[0] != PDEC_ACT_RELU || M->acts[1] != PDEC_ACT_RELU) return false;
+  const int mt = mt_of(M->dims[1]);
+  return mt == 9 || mt == 2 || mt == 1;
+}
 
 bool fused_supported(const Mlp* A, const Mlp* C) {
   if (fused_disabled()) return false;
@@ -642,6 +837,25 @@ static size_t lds_bytes(bool actor_pass) {
   return f * 4;
 }
 
+// PDEC_STAMPS=1 (diagnostic): per-phase s_memtime deltas of the critic pass, averaged over workgroups, to stderr
+static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
+  PDEC_HIP(hipStreamSynchronize(C->stream));
+  std::vector<unsigned long long> h((size_t)grid * 16);
+  PDEC_HIP(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
+  double d[10] = {0};
+  unsigned long long tmin = ~0ull, tmax = 0;
+  for (int b = 0; b < grid; ++b) {
+    for (int k = 0; k < 10; ++k) d[k] += (double)(h[b * 16 + k + 1] - h[b * 16 + k]);
+    tmin = std::min(tmin, h[b * 16]);
+    tmax = std::max(tmax, h[b * 16 + 10]);
+  }
+  fprintf(stderr, "[pdec stamps] critic pass, mean s_memtime ticks (100 MHz) per phase over %d WGs:", grid);
+  static const char* nm[10] = {"load+rbar", "target", "loadQ", "fwdQ", "passA", "loadW2T", "dz1", "passB", "passC", "stats"};
+  for (int k = 0; k < 10; ++k) fprintf(stderr, " %s=%.0f", nm[k], d[k] / grid);
+  fprintf(stderr, " | span=%llu\n", tmax - tmin);
+  return PDEC_OK;
+}
+
 template <int MT, int MTA>
 static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
   const size_t lds = lds_bytes<MT, MTA>(false);
@@ -651,10 +865,19 @@ static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  ProfScope ps(C, "ddpg_critic_fused", true);
-  for (int rep = 0; rep < ps.reps; ++rep)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
+  static const bool want_stamps = getenv("PDEC_STAMPS") != nullptr;
+  FusedArgs ga = g;
+  if (want_stamps) {
+    if (C->stamps.bytes < (size_t)grid * 16 * 8) PDEC_HIP(C->stamps.alloc((size_t)grid * 16 * 8));
+    ga.stamps = C->stamps.as<unsigned long long>();
+  }
+  {
+    ProfScope ps(C, "ddpg_critic_fused", true);
+    for (int rep = 0; rep < ps.reps; ++rep)
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, ga);
+  }
   PDEC_HIP(hipGetLastError());
+  if (want_stamps) return dump_stamps(C, ga.stamps, grid);
   return PDEC_OK;
 }
 template <int MT, int MTA>
@@ -678,43 +901,103 @@ static int ensure_slab(Mlp* M, size_t floats) {
   return PDEC_OK;
 }
 
+// Slab reduction (nslab > 0) and/or the parameter update (apply): ADAM on M with M->adam_* hyper-parameters,
+// Polyak into Mt, refresh of both padded images.  One launch.
+static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT, double grad_scale, int mode,
+                         int Bu, int quirk, void* loss_dev, const AdamPolyak* ap) {
+  FinishArgs g{};
+  g.slabs = slabs; g.nslab = nslab; g.K0 = M->dims[0]; g.H = M->dims[1]; g.MT = MT;
+  g.grads = M->grads.as<float>(); g.scale = (float)grad_scale; g.mode = mode; g.Bu = Bu; g.quirk = quirk;
+  g.loss_out = (float*)loss_dev;
+  g.apply = ap != nullptr;
+  if (ap) {
+    if (M->bp[0] < 0) { M->bp[0] = ap->b1; M->bp[1] = ap->b2; }
+    g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
+    g.fw = M->fw.as<float>();
+    g.lay = make_fnet_layout(M->dims[0], M->dims[1]);
+    g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps; g.omb1p = 1.0 - M->bp[0]; g.omb2p = 1.0 - M->bp[1];
+    if (Mt) {
+      g.pt = Mt->params.as<float>(); g.fwt = Mt->fw.as<float>();
+      const float r = (float)ap->rho;   // the reference holds p = 0.995f0 and computes (1 - p) in Float32
+      g.rho = r; g.omr = 1.0f - r;
+    }
+  }
+  const int n = M->nparams;
+  {
+    ProfScope ps(M, ap ? (nslab > 0 ? "fused_finish" : "fused_apply") : "fused_reduce");
+    const int nblk = nslab > 0 ? 4 * slab_tiles(MT) : (n + 63) / 64;
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(1024), 0, M->stream, g);
+  }
+  PDEC_HIP(hipGetLastError());
+  if (ap) {
+    M->bp[0] *= ap->b1;
+    M->bp[1] *= ap->b2;
+  }
+  return PDEC_OK;
+}
+
+int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning, uint64_t seed,
+                     uint64_t offset, void* actions_out) {
+  int rc = ensure_prepped(A);
+  if (rc) return rc;
+  const FNet f = fnet_of(A);
+  const int mta = mt_of(A->dims[1]);
+  const int HPa = 16 * mta;
+  const size_t lds = ((size_t)small_floats(HPa) + (size_t)HPa * (HPa + 4)) * 4;
+  const int tanh_out = A->acts[2] == PDEC_ACT_TANH;
+  PDEC_REQUIRE(A->acts[2] == PDEC_ACT_TANH || A->acts[2] == PDEC_ACT_IDENTITY, "fused act: unsupported output activation");
+  PDEC_REQUIRE(mta <= 2 && lds <= 64 * 1024, "fused act: hidden width %d too large", A->dims[1]);
+  ProfScope ps(A, "policy_act_fused");
+  const dim3 grid((cols + 63) / 64), block(ACT_THREADS);
+  if (mta == 1)
+    hipLaunchKernelGGL(policy_act_fused_kernel<1>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
+                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out);
+  else
+    hipLaunchKernelGGL(policy_act_fused_kernel<2>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
+                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+// ADAM(M) + Polyak(Mt <- M) + image refresh from the gradient buffer (after an external all-reduce)
+int fused_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap) {
+  int rc;
+  if ((rc = ensure_prepped(M)) || (Mt && (rc = ensure_prepped(Mt)))) return rc;
+  return launch_finish(M, Mt, nullptr, 0, mt_of(M->dims[1]), 1.0, 0, 1, 0, nullptr, &ap);
+}
+
 int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
-                       const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev) {
+                       const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,
+                       const AdamPolyak* apply) {
   int rc;
   if ((rc = ensure_prepped(C)) || (rc = ensure_prepped(At)) || (rc = ensure_prepped(Ct))) return rc;
   const int mt = mt_of(C->dims[1]), mta = mt_of(A->dims[1]);
-  const int HP = 16 * mt, grid = (Bu + FCOLS - 1) / FCOLS;
-  const int stride = slab_floats(HP);
-  if ((rc = ensure_slab(C, (size_t)grid * stride))) return rc;
+  const int grid = (Bu + FCOLS - 1) / FCOLS;
+  if ((rc = ensure_slab(C, slab_floats_total(mt, grid)))) return rc;
   FusedArgs g{};
   g.C = fnet_of(C); g.At = fnet_of(At); g.Ct = fnet_of(Ct); g.A = g.At;
   g.s = (const float*)s; g.a = (const float*)a; g.r = (const float*)r; g.t = (const float*)t; g.sn = (const float*)sn;
   g.Bu = Bu; g.ns = A->dims[0]; g.na = 1; g.gamma = (float)gamma; g.quirk = quirk;
-  g.slab = C->fslab.as<float>(); g.slab_stride = stride;
+  g.slab = C->fslab.as<float>();
   if (mt == 9 && mta == 2) rc = launch_critic<9, 2>(C, g, grid);
   else if (mt == 9 && mta == 1) rc = launch_critic<9, 1>(C, g, grid);
   else if (mt == 2 && mta == 2) rc = launch_critic<2, 2>(C, g, grid);
   else rc = launch_critic<2, 1>(C, g, grid);
   if (rc) return rc;
-  const int n = C->nparams;
-  ProfScope ps(C, "fused_reduce");
-  hipLaunchKernelGGL(fused_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, C->stream, C->fslab.as<float>(), grid, stride,
-                     C->dims[0], C->dims[1], HP, C->grads.as<float>(), (float)grad_scale, 0, Bu, quirk, (float*)loss_dev);
-  PDEC_HIP(hipGetLastError());
-  return PDEC_OK;
+  return launch_finish(C, apply ? Ct : nullptr, C->fslab.as<float>(), grid, mt, grad_scale, 0, Bu, quirk, loss_dev, apply);
 }
 
-int fused_actor_grads(Mlp* A, Mlp* C, const void* s, int Bu, double grad_scale, void* loss_dev) {
+int fused_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double grad_scale, void* loss_dev,
+                      const AdamPolyak* apply) {
   int rc;
-  if ((rc = ensure_prepped(C)) || (rc = ensure_prepped(A))) return rc;
+  if ((rc = ensure_prepped(C)) || (rc = ensure_prepped(A)) || (apply && At && (rc = ensure_prepped(At)))) return rc;
   const int mt = mt_of(C->dims[1]), mta = mt_of(A->dims[1]);
-  const int HPa = 16 * mta, grid = (Bu + FCOLS - 1) / FCOLS;
-  const int stride = slab_floats(HPa);
-  if ((rc = ensure_slab(A, (size_t)grid * stride))) return rc;
+  const int grid = (Bu + FCOLS - 1) / FCOLS;
+  if ((rc = ensure_slab(A, slab_floats_total(mta, grid)))) return rc;
   FusedArgs g{};
   g.C = fnet_of(C); g.A = fnet_of(A); g.At = g.A; g.Ct = g.C;
   g.s = (const float*)s; g.Bu = Bu; g.ns = A->dims[0]; g.na = 1;
-  g.slab = A->fslab.as<float>(); g.slab_stride = stride;
+  g.slab = A->fslab.as<float>();
   // the actor pass is launched on the critic's stream object for profiling labels but must follow
   // ADAM(C); both handles share one stream in every caller (checked by the dispatcher)
   if (mt == 9 && mta == 2) rc = launch_actor<9, 2>(C, g, grid);
@@ -722,12 +1005,8 @@ int fused_actor_grads(Mlp* A, Mlp* C, const void* s, int Bu, double grad_scale, 
   else if (mt == 2 && mta == 2) rc = launch_actor<2, 2>(C, g, grid);
   else rc = launch_actor<2, 1>(C, g, grid);
   if (rc) return rc;
-  const int n = A->nparams;
-  ProfScope ps(C, "fused_reduce");
-  hipLaunchKernelGGL(fused_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, C->stream, A->fslab.as<float>(), grid, stride,
-                     A->dims[0], A->dims[1], HPa, A->grads.as<float>(), (float)grad_scale, 1, Bu, 0, (float*)loss_dev);
-  PDEC_HIP(hipGetLastError());
-  return PDEC_OK;
+  (void)C;
+  return launch_finish(A, apply ? At : nullptr, A->fslab.as<float>(), grid, mta, grad_scale, 1, Bu, 0, loss_dev, apply);
 }
 
 }  // namespace pdec

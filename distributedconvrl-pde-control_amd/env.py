@@ -72,6 +72,7 @@ class PDEenv:
         self.state = self._state_ring[0]
         self.action = self.action0.clone()
         self._action_prev = self.action0.clone()
+        self._adopted = set()
         self._pshape = self._yshape if self.is_fluid else (self.B, setup.nx)
         self.p = torch.zeros(self._pshape, **kw)
         self.reward = self._reward_ring[0]
@@ -177,11 +178,22 @@ class PDEenv:
         self.done.zero_()
 
     # ---- (env::PDEenv)(action), src/PDEenv.jl:195-241
-    def __call__(self, action):
+    def __call__(self, action, adopt=False):
+        """adopt=True: keep a reference to `action` instead of copying it (no D2D copy on the step's critical
+        path); the caller must then leave that buffer untouched until the step AFTER the next one has been
+        issued (env.action / env.delta_action read it), e.g. by alternating two buffers."""
         if action.dtype != self.dtype or not action.is_contiguous() or tuple(action.shape) != self._ashape:
             action = action.to(self.dtype).reshape(self._ashape).contiguous()
-        self._action_prev, self.action = self.action, self._action_prev
-        self.action.copy_(action)
+            adopt = False
+        if adopt:
+            self._action_prev, self.action = self.action, action
+        else:
+            self._action_prev, self.action = self.action, self._action_prev
+            if self.action.data_ptr() == action.data_ptr() or self.action.data_ptr() in self._adopted:
+                self.action = torch.empty_like(action)     # never write into a caller-owned (adopted) buffer
+            self.action.copy_(action)
+        if adopt:
+            self._adopted.add(action.data_ptr())
         self._si = (self._si + 1) % 3
         self._ri ^= 1
         state_next = self._state_ring[self._si]

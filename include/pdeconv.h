@@ -187,11 +187,24 @@ int pdec_adam_set_state(pdec_handle h, const void* m_host, const void* v_host, c
 /* dest .= rho .* dest .+ (1-rho) .* src                          (src/PDEagent.jl:415-417) */
 int pdec_polyak(pdec_handle dst, pdec_handle src, double rho);
 
+/* update!(app, gs) immediately followed by the Polyak step of the app's target network
+ * (src/custom_nna.jl:23-24 + src/PDEagent.jl:415-417 for one network pair) in ONE launch; gradients are
+ * taken from the internal gradient buffer (e.g. after pdec_allreduce_grads).  Polyak of a target only
+ * depends on its own behaviour network, so doing it right after that network's ADAM step is equivalent
+ * to the reference's order. */
+int pdec_adam_polyak_step(pdec_handle h, pdec_handle h_target, double eta, double beta1, double beta2,
+                          double eps, double rho);
+
 /* policy act: actions[cols][na] = clamp(actor(state) + noise*act_noise, +-act_limit)
  * (src/PDEagent.jl:183-207).  noise [cols][na] device standard normals or NULL (-> no noise,
  * `learning=false`). */
 int pdec_policy_act(pdec_handle actor, const void* state, const void* noise, int cols,
                     double act_noise, double act_limit, void* actions_out);
+/* the same with the exploration noise drawn inside the kernel from the counter-based generator of
+ * pdec_randn (identical numbers: element i of the stream (seed, offset) belongs to column i);
+ * learning = 0 -> no noise (`learning=false`, src/PDEagent.jl:199).  One launch for 3-layer fp32 actors. */
+int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
+                        int learning, uint64_t seed, uint64_t offset, void* actions_out);
 /* fill dst[n] with standard normals from a counter-based generator (replaces randn(rng),
  * src/PDEagent.jl:201) */
 int pdec_randn(pdec_handle any_handle, void* dst, size_t n, int dtype, uint64_t seed, uint64_t offset);
@@ -213,6 +226,23 @@ int pdec_ddpg_update(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle C
                      const void* s, const void* a, const void* r, const void* t, const void* snext,
                      int Bu, double gamma, double rho, int quirk, double eta_actor, double eta_critic,
                      double* actor_loss, double* critic_loss);
+
+/* whole update on one device WITHOUT host synchronisation: losses_dev[0] = critic loss, [1] = actor loss
+ * (device scalars of the plan's dtype, may be NULL).  For 3-layer fp32 nets this is 4 launches: critic
+ * pass, slab-reduce + ADAM(C) + Polyak(Ct), actor pass, slab-reduce + ADAM(A) + Polyak(At). */
+int pdec_ddpg_update_async(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
+                           const void* s, const void* a, const void* r, const void* t, const void* snext,
+                           int Bu, double gamma, double rho, int quirk, double eta_actor, double eta_critic,
+                           void* losses_dev);
+
+/* the two halves of pdec_ddpg_update_async as separate calls (critic half: critic pass + ADAM(C) + Polyak(Ct);
+ * actor half: actor pass with the updated critic + ADAM(A) + Polyak(At)), so that a caller can order the
+ * actor half behind a concurrent reader of the actor's weights on another stream.  losses_dev as above. */
+int pdec_ddpg_update_critic_async(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
+                                  const void* s, const void* a, const void* r, const void* t, const void* snext,
+                                  int Bu, double gamma, double rho, int quirk, double eta_critic, void* losses_dev);
+int pdec_ddpg_update_actor_async(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
+                                 const void* s, int Bu, double rho, double eta_actor, void* losses_dev);
 
 /* ---------------------------------------------------------------- multi-GPU ---------- */
 /* One RCCL communicator per process (one process per GPU).  unique_id: 128 bytes from

@@ -156,3 +156,77 @@ def test_randn_moments_and_determinism(pkg):
     assert abs(float((a ** 4).mean()) - 3.0) < 0.05
     pkg._lib.check(net.lib.pdec_randn(net.handle, pkg._lib.ptr(b), n, 0, 1234, n // 4))
     assert not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dims_scale", [1.6, 1.2])
+def test_policy_act_rng_equals_randn_plus_act(pkg, dims_scale):
+    """pdec_policy_act_rng (one launch, noise drawn in-kernel) == pdec_randn + pdec_policy_act: the same Philox
+    stream element per column; forward within the fp32 tolerance (1e-5 rel) of the fp64 oracle"""
+    from oracle import nn
+    rng = np.random.default_rng(9)
+    dims, acts = nn.layer_sizes(3, 1, dims_scale, True, False)     # 3->16->16->1 / 3->12->12->1
+    cols = 1000
+    net, P = make_net(pkg, rng, dims, acts, torch.float32, cols)
+    state = rng.standard_normal((3, cols)).astype(np.float32)
+    dstate = to_dev(state.T, torch.float32)
+    noise = torch.empty((cols, 1), dtype=torch.float32, device="cuda:0")
+    seed, off = 4321, 17
+    L = pkg._lib
+    L.check(net.lib.pdec_randn(net.handle, L.ptr(noise), cols, 0, seed, off))
+    out = torch.empty((cols, 1), dtype=torch.float32, device="cuda:0")
+    L.check(net.lib.pdec_policy_act_rng(net.handle, L.ptr(dstate), cols, 0.7, 1.0, 1, seed, off, L.ptr(out)))
+    ref = nn.policy_act([p.astype(np.float64) for p in P], acts, state.astype(np.float64),
+                        noise.cpu().numpy().T.astype(np.float64), 0.7, 1.0)
+    assert np.abs(out.cpu().numpy().T - ref).max() <= 2e-5
+    L.check(net.lib.pdec_policy_act_rng(net.handle, L.ptr(dstate), cols, 0.7, 1.0, 0, seed, off, L.ptr(out)))   # learning=false
+    ref0 = nn.policy_act([p.astype(np.float64) for p in P], acts, state.astype(np.float64), None, 0.0, 1.0, learning=False)
+    assert np.abs(out.cpu().numpy().T - ref0).max() <= 1e-5
+    assert np.abs(ref - ref0).max() > 0.1
+
+
+@pytest.mark.parametrize("quirk", [1, 0])
+def test_update_async_and_split_sequence_agree(pkg, quirk):
+    """pdec_ddpg_update_async (4 launches: reduce+ADAM+Polyak fused) and the data-parallel split sequence
+    critic_grads -> [all-reduce] -> adam_polyak_step -> actor_grads -> [all-reduce] -> adam_polyak_step
+    leave bit-identical networks (replicas must not drift), and both match the oracle"""
+    from oracle import nn
+    rng = np.random.default_rng(21)
+    ns, na, Bu = 3, 1, 1500
+    da, aa = nn.layer_sizes(ns, na, 1.6, True, False)
+    dc, ac = nn.layer_sizes(ns, na, 7.0, False, False)
+    dtype, npdt = torch.float32, np.float32
+    L = pkg._lib
+    nets = []
+    for rep in range(2):
+        r2 = np.random.default_rng(5)
+        nets.append([make_net(pkg, r2, d, a_, dtype, Bu) for d, a_ in ((da, aa), (dc, ac), (da, aa), (dc, ac))])
+    PA, PC, PAt, PCt = (nets[0][i][1] for i in range(4))
+    optA, optC = nn.Adam(PA, 5e-4), nn.Adam(PC, 1e-3)
+    losses = torch.zeros(2, dtype=dtype, device="cuda:0")
+    losses2 = torch.zeros(2, dtype=dtype, device="cuda:0")
+    for it in range(3):
+        s = rng.standard_normal((ns, Bu)).astype(npdt)
+        sn = rng.standard_normal((ns, Bu)).astype(npdt)
+        a = rng.uniform(-1, 1, (na, Bu)).astype(npdt)
+        r = -rng.uniform(0, 1, Bu).astype(npdt)
+        t = (rng.uniform(0, 1, Bu) < 0.1).astype(npdt)
+        out = nn.ddpg_update(PA, PC, PAt, PCt, optA, optC, aa, ac, s, a, r, t, sn, npdt(np.float32(0.99)), np.float32(0.995), bool(quirk))
+        ds, da_, dr, dt_, dsn = (to_dev(s.T, dtype), to_dev(a.T, dtype), to_dev(r, dtype), to_dev(t, dtype), to_dev(sn.T, dtype))
+        A, Cn, At, Ct = (nets[0][i][0] for i in range(4))
+        L.check(A.lib.pdec_ddpg_update_async(A.handle, Cn.handle, At.handle, Ct.handle, L.ptr(ds), L.ptr(da_), L.ptr(dr),
+                                             L.ptr(dt_), L.ptr(dsn), Bu, 0.99, 0.995, quirk, 5e-4, 1e-3, L.ptr(losses)))
+        A2, C2, At2, Ct2 = (nets[1][i][0] for i in range(4))
+        import ctypes as C_
+        L.check(A.lib.pdec_ddpg_critic_grads(A2.handle, C2.handle, At2.handle, Ct2.handle, L.ptr(ds), L.ptr(da_), L.ptr(dr),
+                                             L.ptr(dt_), L.ptr(dsn), Bu, 0.99, quirk, 1.0, C_.c_void_p(losses2.data_ptr())))
+        L.check(A.lib.pdec_adam_polyak_step(C2.handle, Ct2.handle, 1e-3, 0.9, 0.999, 1e-8, 0.995))
+        L.check(A.lib.pdec_ddpg_actor_grads(A2.handle, C2.handle, L.ptr(ds), Bu, 1.0, C_.c_void_p(losses2.data_ptr() + 4)))
+        L.check(A.lib.pdec_adam_polyak_step(A2.handle, At2.handle, 5e-4, 0.9, 0.999, 1e-8, 0.995))
+        assert torch.equal(losses, losses2)
+        lv = losses.cpu().numpy()
+        assert abs(lv[0] - out["critic_loss"]) <= 2e-4 * max(1.0, abs(out["critic_loss"]))
+        assert abs(lv[1] - out["actor_loss"]) <= 2e-4 * max(1.0, abs(out["actor_loss"]))
+        for i, P in enumerate((PA, PC, PAt, PCt)):
+            for x, y, z in zip(nets[0][i][0].params(), nets[1][i][0].params(), P):
+                assert np.array_equal(x, y)
+                assert relerr(x, z) <= 2e-4
