@@ -134,12 +134,43 @@ __device__ __forceinline__ void layer_in(f32x4 (&h)[MT], const float (&x)[KT], c
   }
 }
 
-// out = W in (+ bias): W image row-major [..][ldw] in LDS, 4 consecutive k per ds_read_b128
+// out = W in (+ bias): W image row-major [..][ldw] in LDS, 4 consecutive k per ds_read_b128.
+// Two output tiles are accumulated at a time with their MFMAs interleaved, so consecutive MFMAs of a wave are
+// independent (issue interval 32 cycles instead of the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32).
 template <int MTO, int MTI, bool BIAS>
 __device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MTI], const float* W, int ldw,
                                          const float* bias, int lr, int q) {
+#ifndef PDEC_LAYER_PAIR
+#define PDEC_LAYER_PAIR 1
+#endif
 #pragma unroll
-  for (int mo = 0; mo < MTO; ++mo) {
+  for (int mo = 0; PDEC_LAYER_PAIR && mo + 1 < MTO; mo += 2) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (BIAS) {
+      const float* b = bias + 16 * mo + 4 * q;
+      acc0 = f32x4{b[0], b[1], b[2], b[3]};
+      acc1 = f32x4{b[16], b[17], b[18], b[19]};
+    }
+    const float* wrow0 = W + (16 * mo + lr) * ldw + 4 * q;
+    const float* wrow1 = wrow0 + 16 * ldw;
+#pragma unroll
+    for (int m = 0; m < MTI; ++m) {
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(wrow0 + 16 * m);
+      const f32x4 wb = *reinterpret_cast<const f32x4*>(wrow1 + 16 * m);
+      acc0 = mfma4(wa[0], in[m][0], acc0);
+      acc1 = mfma4(wb[0], in[m][0], acc1);
+      acc0 = mfma4(wa[1], in[m][1], acc0);
+      acc1 = mfma4(wb[1], in[m][1], acc1);
+      acc0 = mfma4(wa[2], in[m][2], acc0);
+      acc1 = mfma4(wb[2], in[m][2], acc1);
+      acc0 = mfma4(wa[3], in[m][3], acc0);
+      acc1 = mfma4(wb[3], in[m][3], acc1);
+    }
+    out[mo] = acc0;
+    out[mo + 1] = acc1;
+  }
+#pragma unroll
+  for (int mo = PDEC_LAYER_PAIR ? (MTO & ~1) : 0; mo < MTO; ++mo) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (BIAS) {
       const float* b = bias + 16 * mo + 4 * q;
@@ -228,6 +259,9 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NACC], const float* L, co
       }
       acc[pp] = a;
     }
+    // keep the scheduler from hoisting the next tiles' operand loads over this tile (register pressure: the
+    // whole dz2 / h1 / dz1 activation set is live here); the partner wave on the SIMD hides the LDS latency
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // Slab layout (chunk-major): a "chunk" is one accumulator register of one 16x16 output tile = 64 floats in lane
@@ -245,6 +279,14 @@ __device__ __forceinline__ void store_pass(const f32x4 (&acc)[NACC], float* slab
       for (int r = 0; r < 4; ++r) slab[((size_t)(4 * (T0 + p) + r) * nslab + blockIdx.x) * 64 + l] = acc[pp][r];
     }
   }
+}
+// sum over the 16 lanes of a DPP row (= the 16 columns a wave owns), result in every lane; pure VALU
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane^1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane^2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  return v;
 }
 template <int N>
 __device__ __forceinline__ void zero_(f32x4 (&a)[N]) {
@@ -382,23 +424,28 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   float* Rm = Wreg + HP * LDP;
   const int cw = (w & 3) * 16 + lr;
 
-  // ---- pass A: dW3/db3 = dq x [h2; 1]^T
+  // ---- pass A: dW3/db3 = dq x [h2; 1]^T.  A single output row: reduce dq*h2 over the 16 columns of each wave
+  // with lane shuffles, then over the 8 waves through LDS (fixed order -> deterministic); no MFMA/staging round.
   __syncthreads();
   STAMP(4);
-  for (int i = tid; i < 16 * LDP; i += FTHREADS) Lm[i] = 0.f;
   {
-    f32x4 accA[(MT + 7) / 8];
-    zero_(accA);
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
-      if ((w >> 2) == half) {
-        stage_rows<MT>(Rm, h2, cw, q, g.C.H);
-        if (q == 0) Lm[cw] = dq;
+    float* redA = Wreg;               // [8][HP]
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * m + 4 * q + r;
+        const float v = row_sum16((row == g.C.H ? 1.f : h2[m][r]) * dq);
+        if (lr == 0) redA[w * HP + row] = v;
       }
-      __syncthreads();
-      gemm_pass(accA, Lm, Rm, 1, MT, w, lr, q);
+    __syncthreads();
+    if (tid < HP) {
+      float a = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < FTHREADS / 64; ++ww) a += redA[ww * HP + tid];
+      // slab position of element (row 0, column tid) of the [16][HP] product: tile tid/16, register 0, lane tid%16
+      g.slab[((size_t)(4 * (tid >> 4)) * nslab + blockIdx.x) * 64 + (tid & 15)] = a;
     }
-    store_pass(accA, g.slab, nslab, 0, 1, MT, w, l);
   }
   // ---- dz2, dh1 = W2^T dz2, dz1
   f32x4 dz2[MT];
@@ -430,7 +477,8 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     }
     store_pass(accB, g.slab, nslab, MT, MT, MT, w, l);
   }
-  // ---- pass C: dW1/db1 = dz1 x [x0; 1]^T
+  // ---- pass C: dW1/db1 = dz1 x [x0; 1]^T (its own staging round: merging it into pass B costs ~50 more live
+  // registers and spills)
   STAMP(8);
   {
     f32x4 accC[(MT + 7) / 8];

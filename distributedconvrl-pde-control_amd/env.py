@@ -25,7 +25,7 @@ def _stream_ptr(stream):
 
 
 class PDEenv:
-    def __init__(self, setup, B=1, dtype=torch.float32, device="cuda:0", y0=None, action0=None, stream=None):
+    def __init__(self, setup, B=1, dtype=torch.float32, device="cuda:0", y0=None, action0=None, stream=None, history=1):
         self.setup = setup
         self.B = int(B)
         self.dtype = dtype
@@ -63,11 +63,12 @@ class PDEenv:
         self.action0 = (torch.zeros(self._ashape, **kw) if action0 is None else self._as_batch(action0, self._ashape))
         self.y = self.y0.clone()
         self._y_next = torch.empty_like(self.y)
-        # rings: the previous transition (s_t, a_t, r_t, done_t, s_{t+1}) stays valid while the NEXT
-        # step is in flight, so an update on another stream can read it without a copy
-        self._state_ring = [torch.empty(self._sshape, **kw) for _ in range(3)]
-        self._reward_ring = [torch.zeros((self.B, setup.reward_len), **kw) for _ in range(2)]
-        self._flag_ring = [torch.zeros(self.B, dtype=torch.int32, device=self.device) for _ in range(2)]
+        # rings: the last `history` transitions (s_t, a_t, r_t, done_t, s_{t+1}) stay valid while the NEXT
+        # step is in flight, so an update on another stream can read them without a copy
+        self.history = max(1, int(history))
+        self._state_ring = [torch.empty(self._sshape, **kw) for _ in range(self.history + 2)]
+        self._reward_ring = [torch.zeros((self.B, setup.reward_len), **kw) for _ in range(self.history + 1)]
+        self._flag_ring = [torch.zeros(self.B, dtype=torch.int32, device=self.device) for _ in range(self.history + 1)]
         self._si = self._ri = 0
         self.state = self._state_ring[0]
         self.action = self.action0.clone()
@@ -194,8 +195,8 @@ class PDEenv:
             self.action.copy_(action)
         if adopt:
             self._adopted.add(action.data_ptr())
-        self._si = (self._si + 1) % 3
-        self._ri ^= 1
+        self._si = (self._si + 1) % len(self._state_ring)
+        self._ri = (self._ri + 1) % len(self._reward_ring)
         state_next = self._state_ring[self._si]
         self.reward, self._done_flags = self._reward_ring[self._ri], self._flag_ring[self._ri]
         _lib.check(self.lib.pdec_env_step(
