@@ -668,6 +668,109 @@ __global__ void kseg_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
   }
 }
 
+// ------------------------------------------------------------------ KS, RK4 + periodic 5-point finite differences
+// The north-star variant u_t = -u u_x - u_xx - u_xxxx + p (+ the disturbance of KSSetup.jl:155) on the stencil table
+// the reference defines but never uses (scripts/KS/setup/KSSetup.jl:55-59): d/dx = [0,-1/2,0,1/2,0]/dx,
+// d2/dx2 = [0,1,-2,1,0]/dx^2, d4/dx4 = [1,-4,6,-4,1]/dx^4, classical RK4 (src/fluid_rk4.jl:122-132 form) with K
+// sub-steps.  It is a DIFFERENT discretisation from the reference's CNAB2 step, so it is pinned by
+// its own oracle (oracle/ks.py: rhs_fd / do_step_rk4_fd), not by the golden trajectories.
+// One workgroup per trajectory, one cell per thread; neighbours through an LDS line with a periodic halo of 2.
+template <class T>
+__device__ __forceinline__ T ksfd_rhs(T u, T force, T* su, int n, int N, T i2dx, T idx2, T idx4, bool live) {
+  __syncthreads();
+  if (live) {
+    su[n + 2] = u;
+    if (n < 2) su[N + 2 + n] = u;        // right halo = cells 0, 1
+    if (n >= N - 2) su[n - (N - 2)] = u; // left halo  = cells N-2, N-1
+  }
+  __syncthreads();
+  T f = 0;
+  if (live) {
+    const T m2 = su[n], m1 = su[n + 1], p1 = su[n + 3], p2 = su[n + 4];
+    const T ux = i2dx * (p1 - m1);
+    const T uxx = idx2 * (m1 - (T)2 * u + p1);
+    const T uxxxx = idx4 * (m2 - (T)4 * m1 + (T)6 * u - (T)4 * p1 + p2);
+    f = -u * ux - uxx - uxxxx + force;
+  }
+  return f;
+}
+
+template <class T, int MODE>  // MODE 0: fused env step, 1: integrate only, 2: rhs only
+__global__ void ksfd_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
+                                     const T* __restrict__ action, const T* __restrict__ action_prev,
+                                     const T* __restrict__ state_prev, T* __restrict__ y_out, T* __restrict__ p_out,
+                                     T* __restrict__ state_out, T* __restrict__ reward_out, int32_t* __restrict__ done) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = e.N, tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+  T* su = reinterpret_cast<T*>(smem_raw);  // [2][N] (first N+4 used as the halo line; reused as sensing image)
+  T* act = su + 2 * N + 4;                 // [A]
+  T* actp = act + e.A;                     // [A]
+  T* dots = actp + e.A;                    // [2][S]
+  T* part = dots + 2 * e.S;                // [8][2][S]
+  T* red = part + 16 * e.S;                // [16]
+  const int n = tid;
+  const bool live = n < N;
+  const size_t yo = (size_t)b * N;
+  T u = live ? y_in[yo + n] : (T)0;
+  T p = 0;
+  if (MODE == 0) {
+    for (int a = tid; a < e.A; a += nt) {
+      act[a] = action[(size_t)b * e.A + a];
+      actp[a] = action_prev[(size_t)b * e.A + a];
+    }
+    __syncthreads();
+    if (live) {
+      p = actuate_cell<T>(e, act, n);
+      if (p_out) p_out[yo + n] = p;
+    }
+  } else if (live) {
+    p = p_in[yo + n];
+  }
+  // forcing = actuation + disturbance mu cos(2 + pi + x/(Lx/2)), x = dx (n+1)   (KSSetup.jl:36,155)
+  const T force = p + (live ? e.dist_mu * (T)cos(2.0 + 3.14159265358979323846 + (double)e.dx * (n + 1) / ((double)e.dx * N / 2)) : (T)0);
+  const T i2dx = (T)0.5 / e.dx, idx2 = (T)1 / (e.dx * e.dx), idx4 = idx2 * idx2;
+  if (MODE == 2) {
+    const T f = ksfd_rhs<T>(u, force, su, n, N, i2dx, idx2, idx4, live);
+    if (live) y_out[yo + n] = f;
+    return;
+  }
+  const T h = e.hstep;
+  for (int it = 0; it < e.K; ++it) {
+    const T k1 = ksfd_rhs<T>(u, force, su, n, N, i2dx, idx2, idx4, live);
+    const T k2 = ksfd_rhs<T>(u + (T)0.5 * h * k1, force, su, n, N, i2dx, idx2, idx4, live);
+    const T k3 = ksfd_rhs<T>(u + (T)0.5 * h * k2, force, su, n, N, i2dx, idx2, idx4, live);
+    const T k4 = ksfd_rhs<T>(u + h * k3, force, su, n, N, i2dx, idx2, idx4, live);
+    u = u + h / (T)6 * (k1 + (T)2 * (k2 + k3) + k4);
+  }
+  if (live) y_out[yo + n] = u;
+  if (done) {
+    T m = (live && !(fabs(u) <= e.max_value)) ? (T)1 : (T)0;
+    m = block_max<T>(m, red, tid, nt);
+    if (tid == 0) done[b] = (e.check_max == 1 && m > 0) ? 1 : 0;
+  }
+  if (MODE != 0) return;
+  __syncthreads();
+  if (live) {
+    su[n] = u;
+    su[N + n] = 0;
+  }
+  __syncthreads();
+  sense_dots<T>(e, [&](int r, int nn) { return su[r * N + nn]; }, dots, part, tid, nt);
+  const int rw = e.mono ? 1 : e.A;
+  const size_t sw = e.mono ? (size_t)e.S : (size_t)e.A * e.ns;
+  reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b * rw, tid, nt);
+  featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, state_out + b * sw, tid, nt);
+  if (done && e.check_max == 2) {
+    __syncthreads();
+    if (tid == 0) {
+      T m = 0;
+      for (int a = 0; a < rw; ++a)
+        if (!(fabs(reward_out[(size_t)b * rw + a]) <= e.max_value)) m = 1;
+      done[b] = m > 0 ? 1 : 0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ stand-alone closures
 // MODE 0: prepare_action, 1: featurize, 2: reward
 template <class T, int MODE>
@@ -725,6 +828,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.max_value = (T)c.max_value;
   e.dx = (T)(c.Lx / c.N);
   e.hstep = (T)(c.dt / c.K);
+  e.dist_mu = (T)c.mu;
   e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
   e.Wd = E.Wd; e.Cnt = E.Cnt;
   e.gsum = E.gsum.as<T>(); e.a2s = E.a2s.as<int>();
@@ -741,6 +845,10 @@ static size_t ks_lds_bytes(const pdec_env_cfg& c, int r4_log) {
 static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
   return (2 * ((size_t)c.N + 2) + 2 * c.A + 2 * c.S + 16 * c.S + 16) * ts;
+}
+static size_t ksfd_lds_bytes(const pdec_env_cfg& c) {
+  const size_t ts = dtype_size(c.dtype);
+  return (2 * (size_t)c.N + 4 + 2 * c.A + 2 * c.S + 16 * c.S + 16) * ts;
 }
 static size_t sense_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
@@ -779,6 +887,17 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
     else if (mode == 1) KSEG_LAUNCH(1);
     else KSEG_LAUNCH(2);
 #undef KSEG_LAUNCH
+  } else if (c.pde_kind == PDEC_PDE_KS_RK4_FD) {
+    dim3 grid(c.B), block(E.nthreads);
+    ProfScope ps(&E, mode == 0 ? "ksfd_env_step" : (mode == 1 ? "ksfd_pde_step" : "ksfd_rhs"));
+#define KSFD_LAUNCH(M)                                                                                        \
+  hipLaunchKernelGGL((ksfd_env_step_kernel<T, M>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,      \
+                     (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,   \
+                     (T*)p_out, (T*)state_out, (T*)reward_out, done)
+    if (mode == 0) KSFD_LAUNCH(0);
+    else if (mode == 1) KSFD_LAUNCH(1);
+    else KSFD_LAUNCH(2);
+#undef KSFD_LAUNCH
   } else {
     set_error("pde_kind %d not implemented", c.pde_kind);
     return PDEC_E_INVALID;
@@ -873,6 +992,12 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
     if ((rc = upload_converted(E->g, g.data(), N, c.dtype))) return rc;
     if ((rc = upload_converted(E->dhat, dh.data(), 2 * N, c.dtype))) return rc;
     if ((rc = upload_converted(E->tw, tw.data(), 2 * N, c.dtype))) return rc;
+  } else if (c.pde_kind == PDEC_PDE_KS_RK4_FD) {
+    PDEC_REQUIRE(c.n_species == 1, "KS has one species");
+    int nt = (N + 63) / 64 * 64;
+    PDEC_REQUIRE(nt <= 1024, "N=%d too large for the one-cell-per-thread KS finite-difference kernel (max 1024)", N);
+    E->nthreads = nt;
+    E->lds_bytes = ksfd_lds_bytes(c);
   } else if (c.pde_kind == PDEC_PDE_KSEG_RK4) {
     PDEC_REQUIRE(c.n_species == 2, "Keller-Segel has two species");
     PDEC_REQUIRE(!c.mono, "Keller-Segel has no mono variant");
@@ -983,7 +1108,8 @@ int pdec_rhs_eval(pdec_handle h, const void* y, const void* p, void* out) {
   GET_ENV(E, h);
   PDEC_REQUIRE(y && p && out, "pdec_rhs_eval: null");
   if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_rhs_eval(*E, y, p, out);
-  PDEC_REQUIRE(E->cfg.pde_kind == PDEC_PDE_KSEG_RK4, "pdec_rhs_eval: only RK4-type PDE kinds expose an RHS");
+  PDEC_REQUIRE(E->cfg.pde_kind == PDEC_PDE_KSEG_RK4 || E->cfg.pde_kind == PDEC_PDE_KS_RK4_FD,
+               "pdec_rhs_eval: only RK4-type PDE kinds expose an RHS");
   return E->cfg.dtype == PDEC_F64
              ? launch_step<double>(*E, false, 2, y, p, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr)
              : launch_step<float>(*E, false, 2, y, p, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr);

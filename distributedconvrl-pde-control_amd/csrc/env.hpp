@@ -10,7 +10,7 @@ template <class T>
 struct EnvDev {
   int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species;
   T sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
-  T dx, hstep;           // K-S: cell size, RK4 sub-step
+  T dx, hstep, dist_mu;  // cell size, RK4 sub-step, KS disturbance amplitude (RK4-FD variant)
   // sensor / actuator kernels as circular BAND tables (exact: every non-zero entry of the dense
   // [S][N] / [A][N] matrices is kept; a kernel whose support is the whole domain gives Wd = N)
   const T* Gs;           // [Wd][S]   Gs[j][s] = g_s[(sn0[s] + j) mod N]     (coalesced over s)

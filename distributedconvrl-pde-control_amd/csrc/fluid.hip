@@ -31,8 +31,10 @@
 
 namespace pdec {
 
-#define FL_NTH 256
-#define FL_MAXE 12   // elements per thread of one tile: TL * p <= 3072
+#ifndef FL_NTH
+#define FL_NTH 1024
+#endif
+#define FL_MAXE (3072 / FL_NTH)   // elements per thread of one tile: TL * p <= 3072
 
 __host__ __device__ inline int fl_unpad(int ip, int n, int p) {   // chop(): padded index -> kept index or -1
   if (ip <= n / 2) return ip;

@@ -34,9 +34,11 @@ class KSSetup:
                  nna_scale=0.6, nna_scale_critic=7.0, drop_middle_layer=True,
                  gamma=0.99, rho=0.995, batch_size=3, start_steps=6, update_after=10, update_freq=1,
                  update_loops=20, learning_rate=0.0005, learning_rate_critic=0.001, act_limit=1.0,
-                 act_noise=1.2, trajectory_length=150_000):
+                 act_noise=1.2, trajectory_length=150_000, integrator="cnab2"):
         self.nx, self.Lx = int(nx), float(Lx)
         self.dx = self.Lx / self.nx
+        # "cnab2": the reference's spectral CNAB2 step (KSSetup.jl:130-160); "rk4_fd": RK4 + periodic 5-point FD variant
+        self.integrator = integrator
         self.sensor_positions = np.asarray(sensor_positions, dtype=np.int64)
         self.actuator_positions = (self.sensor_positions if actuator_positions is None
                                    else np.asarray(actuator_positions, dtype=np.int64))
@@ -105,7 +107,8 @@ class KSSetup:
 
     def env_cfg(self, B, dtype_code):
         c = _lib.EnvCfg()
-        c.pde_kind, c.dtype, c.B, c.N, c.n_species = _lib.PDE_KS_CNAB2, dtype_code, B, self.nx, 1
+        kind = _lib.PDE_KS_RK4_FD if self.integrator == "rk4_fd" else _lib.PDE_KS_CNAB2
+        c.pde_kind, c.dtype, c.B, c.N, c.n_species = kind, dtype_code, B, self.nx, 1
         c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, 1, int(self.mono)
         c.K = self.oversampling
         c.check_max_value = {"y": 1, "reward": 2}.get(self.check_max_value, 0)

@@ -102,6 +102,34 @@ def do_step(cfg, y, p, ctype=np.complex128):
     return np.real(ifft(u)).astype(rtype)                                     # :158-159
 
 
+def rhs_fd(cfg, u, p):
+    """The north-star's RK4 + periodic finite-difference KS variant, u_t = -u u_x - u_xx - u_xxxx + p + disturbance, on
+    the 5-point stencil rows the reference defines but never uses (scripts/KS/setup/KSSetup.jl:55-59).  NOT the
+    reference's integrator (that is the CNAB2 spectral do_step above): own known-answer tests only."""
+    u = np.asarray(u, dtype=np.float64)
+    dx = cfg.dx
+    m2, m1, p1, p2 = np.roll(u, 2), np.roll(u, 1), np.roll(u, -1), np.roll(u, -2)
+    ux = (p1 - m1) * (0.5 / dx)
+    uxx = (m1 - 2 * u + p1) * (1.0 / (dx * dx))
+    uxxxx = (m2 - 4 * m1 + 6 * u - 4 * p1 + p2) * (1.0 / (dx * dx)) ** 2
+    dist = cfg.mu * np.cos(2 + np.pi + cfg.xx / (cfg.Lx / 2)) if cfg.disturbance_in_step else 0.0
+    return -u * ux - uxx - uxxxx + np.asarray(p, dtype=np.float64) + dist
+
+
+def do_step_rk4_fd(cfg, y, p, K=None):
+    """K classical RK4 sub-steps (src/fluid_rk4.jl:122-132 form) of rhs_fd over one control interval dt"""
+    K = cfg.oversampling if K is None else K
+    h = cfg.dt / K
+    u = np.asarray(y, dtype=np.float64)
+    for _ in range(K):
+        k1 = rhs_fd(cfg, u, p)
+        k2 = rhs_fd(cfg, u + 0.5 * h * k1, p)
+        k3 = rhs_fd(cfg, u + 0.5 * h * k2, p)
+        k4 = rhs_fd(cfg, u + h * k3, p)
+        u = u + h / 6 * (k1 + 2 * (k2 + k3) + k4)
+    return u
+
+
 def sensor_dots(cfg, y):
     return cfg.gaussians @ np.asarray(y, dtype=np.float64)
 

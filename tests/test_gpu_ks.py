@@ -129,3 +129,38 @@ def test_host_pointer_wrapper(pkg):
     lib = pkg._lib.load()
     pkg._lib.check(lib.pdec_pde_step_host(env.handle, y.ctypes.data, p.ctypes.data, out.ctypes.data, done.ctypes.data))
     assert np.abs(out - g["y"][4]).max() <= 1e-12 and done[0] == 0
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 2e-4)])
+def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol):
+    """north-star variant: RK4 + periodic 5-point FD (stencils of KSSetup.jl:55-59); rhs, do_step and the fused
+    (env)(action) against oracle/ks.py rhs_fd / do_step_rk4_fd (relative to max|value|)"""
+    from oracle import ks
+    nx, Lx, K, dtc = 240, 200.0, 30, 0.1
+    pos = np.arange(1, nx + 1, 3)
+    setup = pkg.KSSetup(nx, Lx, pos, integrator="rk4_fd", mu=0.02, dt=dtc, oversampling=K, window_size=3)
+    cfg = ks.KSConfig(nx, Lx, pos, mu=0.02, dt=dtc, oversampling=K, window_size=3)
+    dt = torch.float64 if prec == "f64" else torch.float32
+    rng = np.random.default_rng(4)
+    B = 7
+    y = setup.generate_random_init(rng, B) * 0.1
+    a0 = rng.uniform(-1, 1, (B, len(pos)))
+    a1 = rng.uniform(-1, 1, (B, len(pos)))
+    env = pkg.PDEenv(setup, B=B, dtype=dt, y0=y)
+    p = np.stack([ks.prepare_action(cfg, a1[b][None]) for b in range(B)])
+    f = env.rhs(to_dev(y, dt), to_dev(p, dt)).cpu().numpy()
+    for b in range(B):
+        ref = ks.rhs_fd(cfg, y[b], p[b])
+        assert np.abs(f[b] - ref).max() <= tol * np.abs(ref).max()
+    out, flags = env.do_step(to_dev(y, dt), to_dev(p, dt))
+    env.action.copy_(to_dev(a0, dt).reshape(env._ashape))
+    env(to_dev(a1, dt).reshape(env._ashape))
+    for b in range(B):
+        ref = ks.do_step_rk4_fd(cfg, y[b], p[b])
+        assert np.abs(out[b].cpu().numpy() - ref).max() <= tol * np.abs(ref).max()
+        assert np.abs(env.y[b].cpu().numpy() - ref).max() <= tol * np.abs(ref).max()
+        st = ks.featurize(cfg, ref)
+        assert np.abs(env.state[b].cpu().numpy().T - st).max() <= 10 * tol
+        r = ks.reward_function(cfg, ref, a1[b][None], (a1[b] - a0[b])[None])
+        assert np.abs(env.reward[b].cpu().numpy() - r).max() <= 10 * tol
+    assert int(flags.sum()) == 0

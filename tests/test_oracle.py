@@ -187,3 +187,27 @@ def test_adam_one_step_known_answer():
     P2 = opt.step([p.copy() for p in P], G)
     assert np.allclose(P2[0], P[0] - 1e-3 * np.sign(G[0]), atol=1e-9)
     assert np.allclose(P2[1], P[1] - 1e-3 * np.sign(G[1]), atol=1e-9)
+
+
+def test_ks_fd_rk4_variant_converges_to_the_spectral_step():
+    """The RK4 + 5-point-FD KS variant (oracle/ks.py: rhs_fd, do_step_rk4_fd; stencils of KSSetup.jl:55-59) is a different
+    discretisation from the reference's CNAB2 step, so it gets its own known answers: (i) the stencils are exact on
+    low-order trigonometric data up to O(dx^2); (ii) one short control step approaches the spectral CNAB2 step at
+    second order in dx (error ratio ~4 per grid doubling)."""
+    from oracle import ks
+    errs = []
+    for nx in (64, 128, 256):
+        cfg = ks.KSConfig(nx, 22.0, np.arange(1, nx + 1, nx // 8), dt=2e-4, oversampling=20)
+        x = cfg.xx
+        y = 2.0 * np.sin(2 * np.pi * x / 22.0) + 0.5 * np.cos(4 * np.pi * x / 22.0)
+        p = 0.3 * np.sin(6 * np.pi * x / 22.0)
+        k = 2 * np.pi / 22.0
+        exact = (-(y * (2.0 * k * np.cos(k * x) - 0.5 * 2 * k * np.sin(2 * k * x)))
+                 - (-(k ** 2) * 2.0 * np.sin(k * x) - 0.5 * (2 * k) ** 2 * np.cos(2 * k * x))
+                 - ((k ** 4) * 2.0 * np.sin(k * x) + 0.5 * (2 * k) ** 4 * np.cos(2 * k * x)) + p)
+        assert np.abs(ks.rhs_fd(cfg, y, p) - exact).max() <= 3.0 * cfg.dx ** 2
+        a = ks.do_step_rk4_fd(cfg, y, p)
+        b = ks.do_step(cfg, y, p)
+        errs.append(np.abs(a - b).max())
+    assert errs[0] / errs[1] > 3.0 and errs[1] / errs[2] > 3.0, errs
+    assert errs[2] < 1e-5
