@@ -14,4 +14,4 @@ from .agent import (Agent, CustomDDPGPolicy, CircularArraySARTTrajectory, ZeroPo
                     POST_EPISODE_STAGE, POST_EXPERIMENT_STAGE)
 from .hook import PDEhook  # noqa: F401
 from .run import run, StopAfterEpisode, StopAfterEpisodeWithMinSteps  # noqa: F401
-from . import julia_compat, distributed  # noqa: F401
+from . import julia_compat, distributed, checkpoint  # noqa: F401

@@ -1,0 +1,85 @@
+"""Checkpoint I/O.
+
+* `read_hook(path)`: read a reference `saves/hook.jld2` (written by `FileIO.save(..., "hook", hook)`,
+  scripts/KS/setup/KSSetup.jl:391-402): the best / current actor weights (`hook.bestNNA`,
+  `hook.currentNNA`, src/PDEhook.jl:68-75), the per-episode rewards and, when the hook collected it,
+  the best episode's `bestDF` trajectory (src/PDEhook.jl:54-62).  Pure Python (jld2.py).
+* `load_actor(nna_or_model, params)`: `copyto!(actor, hook.bestNNA)` (src/plotting.jl:29).
+* `save_agent` / `load_agent`: native `.npz` checkpoint of the four networks plus their ADAM state
+  (moments and beta powers), i.e. what `FileIO.save(".../agent.jld2", "agent", agent)` keeps of the
+  learner; writing JLD2 itself is not provided (the reference's `load()` would need Julia types)."""
+import numpy as np
+
+from . import _lib
+from .jld2 import JLD2File
+
+
+def read_hook(path):
+    f = JLD2File(path)
+    out = {}
+    f32 = [f.array(o) for o in f.numeric(1, 4) if o.dims]
+    half = len(f32) // 2
+    for pi, pref in enumerate(("best", "current")):          # file order: bestNNA then currentNNA, W,b,W,b...
+        out[pref] = [np.ascontiguousarray(a) for a in f32[pi * half:(pi + 1) * half]]
+    rew = [f.array(o) for o in f.numeric(1, 8) if o.dims and len(o.dims) == 1]
+    refs = [o for o in f.ref_arrays() if o.dims and o.dims[0] > 5]
+    if refs:                                                   # bestDF columns in insertion order (PDEhook.jl:56-60)
+        n = refs[0].dims[0]
+        cols = [np.stack([f.array(f.deref(r)) for r in f.array(o)]).astype(np.float64)
+                for o in [o for o in refs if o.dims[0] == n][:4]]
+        out["bestDF"] = dict(zip(("action", "p", "y", "reward"), cols))
+        widths = {c.shape[1] for c in cols if c.ndim == 2}
+        rew = [r for r in rew if r.size not in widths]
+    out["rewards"] = max(rew, key=lambda r: r.size) if rew else np.zeros(0)
+    return out
+
+
+def load_actor(nna, params):
+    """params: [W1, b1, W2, b2, ...] with W[out, in] (Flux.params order)"""
+    model = getattr(nna, "model", nna)
+    model.set_params([np.asarray(p) for p in params])
+    return nna
+
+
+def _adam_state(model):
+    import ctypes as C
+    n = model.num_params
+    m = np.empty(n, dtype=model.np_dtype)
+    v = np.empty(n, dtype=model.np_dtype)
+    bp = (C.c_double * 2)()
+    _lib.check(model.lib.pdec_adam_get_state(model.handle, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), bp))
+    return m, v, np.array([bp[0], bp[1]])
+
+
+def save_agent(path, agent):
+    p = agent.policy
+    kw = {}
+    for name in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        model = getattr(p, name).model
+        for i, a in enumerate(model.params()):
+            kw[f"{name}/p{i}"] = a
+        m, v, bp = _adam_state(model)
+        kw[f"{name}/adam_m"], kw[f"{name}/adam_v"], kw[f"{name}/adam_beta_pow"] = m, v, bp
+        kw[f"{name}/dims"] = np.array(model.dims)
+    kw["update_step"] = np.array(p.update_step)
+    kw["act_noise"] = np.array(p.act_noise)
+    np.savez_compressed(path, **kw)
+
+
+def load_agent(path, agent):
+    import ctypes as C
+    z = np.load(path)
+    p = agent.policy
+    for name in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        model = getattr(p, name).model
+        if list(z[f"{name}/dims"]) != list(model.dims):
+            raise _lib.PdecError(f"checkpoint {path}: {name} has dims {list(z[f'{name}/dims'])}, agent has {model.dims}")
+        n = len(model.dims) - 1
+        model.set_params([z[f"{name}/p{i}"] for i in range(2 * n)])
+        m = np.ascontiguousarray(z[f"{name}/adam_m"], dtype=model.np_dtype)
+        v = np.ascontiguousarray(z[f"{name}/adam_v"], dtype=model.np_dtype)
+        bp = (C.c_double * 2)(*z[f"{name}/adam_beta_pow"])
+        _lib.check(model.lib.pdec_adam_set_state(model.handle, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), bp))
+    p.update_step = int(z["update_step"])
+    p.act_noise = float(z["act_noise"])
+    return agent

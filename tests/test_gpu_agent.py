@@ -91,3 +91,66 @@ def test_native_rccl_comm_single_rank(pkg):
     flat = np.concatenate([g0[0].ravel(), g0[1], g0[2].ravel(), g0[3]])      # internal layout: W row-major
     assert np.allclose(red, flat, atol=1e-6)
     pkg._lib.check(lib.pdec_destroy(h))
+
+
+def test_reference_trained_actor_controls_ks22_on_this_path(pkg):
+    """End-to-end control quality: the actor the reference trained (hook.bestNNA, fixture
+    extracted from scripts/KS/KS22/saves/hook.jld2), run noise-free through PDEenv + the policy on this path from the
+    golden initial state, reproduces the oracle's closed-loop rollout step for step and suppresses the KS
+    instability (return -0.125 vs -4.35 uncontrolled; the reference's best training episode logged -0.73 with
+    exploration noise)."""
+    import numpy as np
+    import torch
+    from oracle import ks, nn
+    from util import ks_pair
+    setup, cfg, g = ks_pair(pkg, "ks22")
+    env = pkg.PDEenv(setup, B=1, dtype=torch.float64, y0=g["y"][0])
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), dtype=torch.float32)
+    best = [g["best_W1"], g["best_b1"], g["best_W2"], g["best_b2"]]
+    pkg.checkpoint.load_actor(agent.policy.behavior_actor, best)
+    agent.policy.start_steps = -1
+    P = [b.astype(np.float64) for b in best]
+    y, a_prev, t, ret_o, ret_g = g["y"][0].copy(), np.zeros((1, 8)), 0.0, 0.0, 0.0
+    for k in range(50):
+        a = np.clip(nn.forward(P, [nn.RELU, nn.TANH], ks.featurize(cfg, y)), -1, 1)
+        o = ks.env_step(cfg, y, a_prev, a, t)
+        y, a_prev, t = o["y"], a, o["time"]
+        ret_o += o["reward"].mean()
+        act = agent.policy(env, learning=False)
+        env(act)
+        ret_g += float(env.reward.mean().item())
+        assert np.abs(env.action_julia() - a).max() <= 1e-9
+        assert np.abs(env.y_julia() - y).max() <= 1e-8
+    assert abs(ret_g - ret_o) <= 1e-8 and -0.3 < ret_g < -0.05
+    # the uncontrolled run from the same state is an order of magnitude worse
+    env0 = pkg.PDEenv(setup, B=1, dtype=torch.float64, y0=g["y"][0])
+    ret0 = 0.0
+    for k in range(50):
+        env0(torch.zeros(env0._ashape, dtype=torch.float64, device="cuda:0"))
+        ret0 += float(env0.reward.mean().item())
+    assert ret0 < 10 * ret_g
+
+
+def test_agent_checkpoint_roundtrip(pkg, tmp_path):
+    """save_agent / load_agent (.npz): weights, ADAM moments and beta powers survive; a resumed agent takes the
+    same next update step bit for bit"""
+    import numpy as np
+    import torch
+    setup = pkg.KSSetup.bench_C2(256)
+    mk = lambda: pkg.create_agent(setup=setup, B=2, rng=np.random.default_rng(3), dtype=torch.float32, max_update_cols=512)
+    a1, a2 = mk(), pkg.create_agent(setup=setup, B=2, rng=np.random.default_rng(99), dtype=torch.float32, max_update_cols=512)
+    rng = np.random.default_rng(0)
+    def batch():
+        f = lambda *s: torch.as_tensor(rng.standard_normal(s).astype(np.float32), device="cuda:0")
+        return dict(state=f(512, 3), action=f(512, 1).clamp(-1, 1), reward=-f(512).abs(), terminal=torch.zeros(512, device="cuda:0"),
+                    next_state=f(512, 3))
+    a1.policy.update(batch())
+    path = str(tmp_path / "agent.npz")
+    pkg.checkpoint.save_agent(path, a1)
+    pkg.checkpoint.load_agent(path, a2)
+    b = batch()
+    a1.policy.update(b)
+    a2.policy.update(b)
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        for x, y in zip(getattr(a1.policy, n).model.params(), getattr(a2.policy, n).model.params()):
+            assert np.array_equal(x, y)

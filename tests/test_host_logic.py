@@ -162,3 +162,21 @@ def test_fluid_setup_box_tables_reproduce_dense_kernels(pkg):
     assert setup.oversampling == int(np.floor(16 * n * 0.02)) and setup.state_shape == (9, 16)
     c = setup.env_cfg(2, 1)
     assert (c.ifpad, c.sensors_per_axis, c.N, c.S, c.A) == (1, spa, n, 16, 16)
+
+
+def test_read_hook_matches_committed_golden(pkg):
+    """checkpoint.read_hook on the reference's own saves/hook.jld2 (row F3) reproduces the committed fixture;
+    runs only where the reference tree is mounted (the build container)."""
+    import os
+    import numpy as np
+    import pytest
+    ref = "/root/reference/scripts/KS/KS22/saves/hook.jld2"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not mounted")
+    from util import load_golden
+    g = load_golden("ks22_hook.npz")
+    h = pkg.checkpoint.read_hook(ref)
+    for a, b in zip(h["best"], (g["best_W1"], g["best_b1"], g["best_W2"], g["best_b2"])):
+        assert np.array_equal(a, b)
+    assert np.array_equal(h["bestDF"]["y"], g["y"]) and np.array_equal(h["bestDF"]["action"], g["action"])
+    assert np.array_equal(h["rewards"], g["episode_rewards"])
