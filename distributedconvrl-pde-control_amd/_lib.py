@@ -53,6 +53,7 @@ SIGNATURES = {
     "pdec_reward": [Handle, _vp, _vp, _vp, _vp],
     "pdec_env_step": [Handle] + [_vp] * 9,
     "pdec_rhs_eval": [Handle, _vp, _vp, _vp],
+    "pdec_env_set_terminal_out": [Handle, _vp],
     "pdec_pde_step_host": [Handle, _vp, _vp, _vp, _vp],
     "pdec_env_step_host": [Handle] + [_vp] * 9,
     "pdec_mlp_create": [C.POINTER(Handle), _i, _i, _pi32, _pi32, _vp, _i],

@@ -160,6 +160,14 @@ __device__ __forceinline__ T block_max(T v, T* red, int tid, int nt) {
   return r;
 }
 
+// per-column terminal flags for the DDPG batch (every actuator column of a blown-up trajectory is terminal)
+template <class T>
+__device__ __forceinline__ void write_terminal(const EnvDev<T>& e, int b, bool flag, int tid, int nt) {
+  if (!e.term_out) return;
+  const int cpt = e.mono ? 1 : e.A;
+  for (int a = tid; a < cpt; a += nt) e.term_out[(size_t)b * cpt + a] = flag ? (T)1 : (T)0;
+}
+
 // ------------------------------------------------------------------ KS CNAB2 kernel
 #define KS_MPT 4  // modes / cells owned per thread: k = tid + j*nt
 
@@ -524,6 +532,10 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
       done[b0] = (chk && mx0 > 0) ? 1 : 0;
       if (has1) done[b1] = (chk && mx1 > 0) ? 1 : 0;
     }
+    if (FUSED && e.check_max != 2) {
+      write_terminal<T>(e, b0, e.check_max == 1 && mx0 > 0, tid, nt);
+      if (has1) write_terminal<T>(e, b1, e.check_max == 1 && mx1 > 0, tid, nt);
+    }
   }
   if (!FUSED) return;
   const T* Rt = reinterpret_cast<const T*>(eng.publish(U));
@@ -547,6 +559,7 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
         for (int a = 0; a < rw; ++a)
           if (!(fabs(r[a]) <= e.max_value)) m = 1;
         done[b0 + t] = m > 0 ? 1 : 0;
+        write_terminal<T>(e, b0 + t, m > 0, 0, 1);
       }
     }
   }
@@ -645,6 +658,7 @@ __global__ void kseg_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
     T m = (live && !(fabs(u) <= e.max_value && fabs(v) <= e.max_value)) ? (T)1 : (T)0;
     m = block_max<T>(m, red, tid, nt);
     if (tid == 0) done[b] = (e.check_max == 1 && m > 0) ? 1 : 0;
+    if (MODE == 0 && e.check_max != 2) write_terminal<T>(e, b, e.check_max == 1 && m > 0, tid, nt);
   }
   if (MODE != 0) return;
   __syncthreads();
@@ -664,6 +678,7 @@ __global__ void kseg_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
       for (int a = 0; a < e.A; ++a)
         if (!(fabs(reward_out[(size_t)b * e.A + a]) <= e.max_value)) m = 1;
       done[b] = m > 0 ? 1 : 0;
+      write_terminal<T>(e, b, m > 0, 0, 1);
     }
   }
 }
@@ -747,6 +762,7 @@ __global__ void ksfd_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
     T m = (live && !(fabs(u) <= e.max_value)) ? (T)1 : (T)0;
     m = block_max<T>(m, red, tid, nt);
     if (tid == 0) done[b] = (e.check_max == 1 && m > 0) ? 1 : 0;
+    if (MODE == 0 && e.check_max != 2) write_terminal<T>(e, b, e.check_max == 1 && m > 0, tid, nt);
   }
   if (MODE != 0) return;
   __syncthreads();
@@ -767,6 +783,7 @@ __global__ void ksfd_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
       for (int a = 0; a < rw; ++a)
         if (!(fabs(reward_out[(size_t)b * rw + a]) <= e.max_value)) m = 1;
       done[b] = m > 0 ? 1 : 0;
+      write_terminal<T>(e, b, m > 0, 0, 1);
     }
   }
 }
@@ -832,6 +849,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
   e.Wd = E.Wd; e.Cnt = E.Cnt;
   e.gsum = E.gsum.as<T>(); e.a2s = E.a2s.as<int>();
+  e.term_out = static_cast<T*>(E.term_out);
   e.c1 = E.c1.as<T>(); e.c2 = E.c2.as<T>(); e.c3 = E.c3.as<T>(); e.c4 = E.c4.as<T>(); e.g = E.g.as<T>();
   e.dhat = E.dhat.as<C2<T>>(); e.tw = E.tw.as<C2<T>>();
   e.fft = E.fft;
@@ -1069,6 +1087,14 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
     set_error("%s: not an env handle", __func__);  \
     return PDEC_E_HANDLE;                          \
   }
+
+int pdec_env_set_terminal_out(pdec_handle h, void* terminal_per_column) {
+  GET_ENV(E, h);
+  PDEC_REQUIRE(E->cfg.pde_kind != PDEC_PDE_FLUID_RK4 || !terminal_per_column,
+               "pdec_env_set_terminal_out: not provided for the fluid environment (expand its done[B] flags)");
+  E->term_out = terminal_per_column;
+  return PDEC_OK;
+}
 
 int pdec_actuate(pdec_handle h, const void* action, void* p_out) {
   GET_ENV(E, h);

@@ -18,6 +18,7 @@ struct EnvDev {
   const T* GaC;          // [Cnt][N]  GaC[i][n] = ga_{(an0[n]+i) mod A}[n]   (coalesced over n)
   const int* an0;        // [N]       first actuator reaching cell n
   int Wd, Cnt;
+  T* term_out;           // optional [B][cols per trajectory]: 1.0 where the trajectory blew up (pdec_env_set_terminal_out)
   const T* gsum;         // [S]     sum of each sensor kernel (reward offset term)
   const int* a2s;        // [A]
   // KS CNAB2 per-mode constants
@@ -32,6 +33,7 @@ struct Env : Object {
   DevBuf Gs, sn0, GaC, an0, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
   int Wd = 0, Cnt = 0;
   DevBuf stage;  // staging for the _host wrappers
+  void* term_out = nullptr;
   FftPlan fft;
   int nthreads = 64;
   int r4_log = 0;        // 4 / 5: N = 256 / 1024 use the register-resident radix-4 FFT engine

@@ -23,6 +23,8 @@ struct Mlp : Object {
   DevBuf stamps;                     // diagnostic phase stamps (PDEC_STAMPS=1)
   DevBuf noise;                      // internal exploration-noise buffer (pdec_policy_act_rng fallback)
   bool fw_dirty = true;
+  DevBuf fw_pub[2];                  // published copies of the image for concurrent acting kernels
+  int pub = 0;
 
   Mlp() : Object(Kind::Mlp) {}
   int init(int dtype, int L, const int32_t* dims, const int32_t* acts, int max_cols);

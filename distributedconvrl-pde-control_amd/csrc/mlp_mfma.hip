@@ -645,6 +645,8 @@ struct FinishArgs {
   float* loss_out;
   int apply;                   // != 0: ADAM step on p, Polyak into pt, refresh the padded images
   float *p, *m, *v, *pt, *fw, *fwt;
+  float* fwp;                  // published copy of the updated image (double-buffered: a concurrent acting kernel
+                               // keeps reading the other copy), may be null
   FNet lay;
   double eta, b1, b2, eps, omb1p, omb2p;
   float rho, omr;
@@ -674,6 +676,7 @@ __device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float g
   else if ((j -= H) < H) o1 = g.lay.ow3 + j;
   else o1 = g.lay.ob3;
   if (g.fw) { g.fw[o1] = pn; if (o2 >= 0) g.fw[o2] = pn; }
+  if (g.fwp) { g.fwp[o1] = pn; if (o2 >= 0) g.fwp[o2] = pn; }
   if (g.pt) {
     const float tn = g.rho * pt0 + g.omr * pn;
     g.pt[i] = tn;
@@ -857,8 +860,11 @@ bool fused_supported(const Mlp* A, const Mlp* C) {
 
 static int ensure_prepped(Mlp* M) {
   const FNet f = make_fnet_layout(M->dims[0], M->dims[1]);
-  if (M->fw.bytes < (size_t)f.total * 4) {
-    PDEC_HIP(M->fw.alloc((size_t)f.total * 4));
+  const size_t bytes = (size_t)f.total * 4;
+  if (M->fw.bytes < bytes) {
+    PDEC_HIP(M->fw.alloc(bytes));
+    PDEC_HIP(M->fw_pub[0].alloc(bytes));
+    PDEC_HIP(M->fw_pub[1].alloc(bytes));
     M->fw_dirty = true;
   }
   if (M->fw_dirty) {
@@ -866,6 +872,9 @@ static int ensure_prepped(Mlp* M) {
     hipLaunchKernelGGL(prep_fused_kernel, dim3((f.total + 255) / 256), dim3(256), 0, M->stream, M->params.as<float>(),
                        M->fw.as<float>(), f);
     PDEC_HIP(hipGetLastError());
+    // both published copies (the images the acting kernel reads, see fused_policy_act) restart from the fresh image
+    PDEC_HIP(hipMemcpyAsync(M->fw_pub[0].p, M->fw.p, bytes, hipMemcpyDeviceToDevice, M->stream));
+    PDEC_HIP(hipMemcpyAsync(M->fw_pub[1].p, M->fw.p, bytes, hipMemcpyDeviceToDevice, M->stream));
     M->fw_dirty = false;
   }
   return PDEC_OK;
@@ -962,6 +971,7 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
     if (M->bp[0] < 0) { M->bp[0] = ap->b1; M->bp[1] = ap->b2; }
     g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
     g.fw = M->fw.as<float>();
+    g.fwp = M->fw_pub[M->pub ^ 1].as<float>();       // written now, read by acting kernels enqueued after this launch
     g.lay = make_fnet_layout(M->dims[0], M->dims[1]);
     g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps; g.omb1p = 1.0 - M->bp[0]; g.omb2p = 1.0 - M->bp[1];
     if (Mt) {
@@ -980,6 +990,7 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   if (ap) {
     M->bp[0] *= ap->b1;
     M->bp[1] *= ap->b2;
+    M->pub ^= 1;
   }
   return PDEC_OK;
 }
@@ -988,7 +999,12 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
                      uint64_t offset, void* actions_out) {
   int rc = ensure_prepped(A);
   if (rc) return rc;
-  const FNet f = fnet_of(A);
+  FNet f = fnet_of(A);
+  // Read the PUBLISHED copy of the image: the update's finish kernel writes the other copy (and the in-place image
+  // of the update passes), so an acting kernel may run beside the actor half of the following update.  A copy is
+  // rewritten two updates later; callers that overlap acting and updating on different streams must order update
+  // t+1 behind the acting kernel of step t-1 (bench.py waits on that event at the start of each update).
+  f.w = A->fw_pub[A->pub].as<float>();
   const int mta = mt_of(A->dims[1]);
   const int HPa = 16 * mta;
   const size_t lds = ((size_t)small_floats(HPa) + (size_t)HPa * (HPa + 4)) * 4;

@@ -79,7 +79,8 @@ class PDEenv:
         self.reward = self._reward_ring[0]
         self._done_flags = self._flag_ring[0]
         self.prev_state = None
-        self.done = torch.zeros(self.B, dtype=torch.bool, device=self.device)
+        self._done = torch.zeros(self.B, dtype=torch.bool, device=self.device)
+        self._done_stale = False
         self.steps, self.time = 0, 0.0
         self.reset()
 
@@ -112,6 +113,23 @@ class PDEenv:
     @property
     def handle(self):
         return self._h
+
+    @property
+    def done(self):
+        """per-trajectory episode-end flags (src/PDEenv.jl:224-240), materialised on demand so that a control step
+        issues no kernel besides the fused env step"""
+        if self._done_stale:
+            if self.time >= self.te:
+                self._done.fill_(True)
+            else:
+                torch.ne(self._done_flags, 0, out=self._done)
+            self._done_stale = False
+        return self._done
+
+    def set_terminal_out(self, buf):
+        """have every later step also write per-column terminal flags ([B, A] of the env dtype) for the DDPG batch"""
+        self._terminal_out = buf
+        _lib.check(self.lib.pdec_env_set_terminal_out(self._h, _lib.ptr(buf)))
 
     @property
     def delta_action(self):
@@ -176,7 +194,8 @@ class PDEenv:
         self.p = self.prepare_action(self.action0)
         self.steps, self.time = 0, 0.0
         self.reward.zero_()
-        self.done.zero_()
+        self._done.zero_()
+        self._done_stale = False
 
     # ---- (env::PDEenv)(action), src/PDEenv.jl:195-241
     def __call__(self, action, adopt=False):
@@ -207,10 +226,7 @@ class PDEenv:
         self.prev_state, self.state = self.state, state_next
         self.steps += 1
         self.time += self.dt
-        if self.time >= self.te:
-            self.done.fill_(True)
-        else:
-            torch.ne(self._done_flags, 0, out=self.done)
+        self._done_stale = True
 
     # ---- Julia-shaped host views for B == 1 (what PDEhook logs, src/PDEhook.jl:54-62)
     def y_julia(self, b=0):

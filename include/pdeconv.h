@@ -151,6 +151,11 @@ int pdec_reward(pdec_handle h, const void* y, const void* action, const void* ac
 int pdec_env_step(pdec_handle h, const void* y_in, const void* action, const void* action_prev,
                   const void* state_prev, void* y_out, void* p_out, void* state_out,
                   void* reward_out, int32_t* done);
+/* Optional extra output of pdec_env_step for the batched DDPG update: terminal_per_column
+ * [B][A] (mono: [B][1]) of the plan's dtype, 1.0 on every actuator column of a trajectory that
+ * blew up in this step (the `terminal` trace RL.jl fills per actuator, src/PDEagent.jl:284-288),
+ * 0.0 otherwise.  NULL (default) disables it.  The pointer is read at each later pdec_env_step. */
+int pdec_env_set_terminal_out(pdec_handle h, void* terminal_per_column);
 /* RHS evaluation for known-answer tests: out = f(y, p)    (KellerSegelSetup.jl:213-232) */
 int pdec_rhs_eval(pdec_handle h, const void* y, const void* p, void* out);
 
