@@ -29,7 +29,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FCOLS 128          // columns per workgroup
 #define FTHREADS 512
-#define LDP 68             // leading dim of the 64-column LDS transposition images
+// Leading dimensions chosen so that the ds_read_b128 operand reads (lane (lr, q) reads row lr at column offset 4q)
+// are bank-conflict free: with a row stride of 8 (mod 16) floats the 16-byte slot index is (2 lr + q) mod 16,
+// which is distinct over each 16-lane service group of ds_read_b128 (MI355X_MICROARCH.md, LDS table).
+#define LDP 72             // leading dim of the 64-column LDS transposition images
+#define LDWPAD 8           // weight-image row stride = HP + 8
 #define KXP 16             // padded input rows (ns+na+1 <= 16)
 #define LDW1 20            // LDS leading dim of W1 images
 
@@ -48,7 +52,7 @@ static FNet make_fnet_layout(int K0, int H) {
   FNet f{};
   f.K0 = K0; f.H = H;
   f.HP = (H + 1 + 15) / 16 * 16;
-  f.LDW = f.HP + 4;
+  f.LDW = f.HP + LDWPAD;
   int o = 0;
   f.oW1 = o; o += f.HP * KXP;
   f.ob1 = o; o += f.HP;
@@ -92,7 +96,7 @@ static inline int small_floats(int HP) { return HP * LDW1 + 3 * HP + 4; }
 // floats of the big region: the padded W2 image, or the staging images that later overlay it
 __host__ __device__ constexpr int wreg_floats(int MT, int MTA) {
   const int HP = 16 * MT, HPa = 16 * MTA;
-  int a = HP * (HP + 4), b = 2 * HP * LDP, c = (32 + 4 * HPa) * LDP;
+  int a = HP * (HP + LDWPAD), b = 2 * HP * LDP, c = (32 + 4 * HPa) * LDP;
   int m = a > b ? a : b;
   return m > c ? m : c;
 }
@@ -331,7 +335,7 @@ template <int MT, int MTA>
 __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
-  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + 4, LDWa = HPa + 4;
+  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD;
   float* Wreg = smem;                                   // [HP][LDW] big weight image / staging images
   float* sc = Wreg + wreg_floats(MT, MTA);              // critic small image
   float* sa = sc + (HP * LDW1 + 3 * HP + 4);            // actor small image
@@ -525,7 +529,7 @@ template <int MT, int MTA>
 __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
-  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + 4, LDWa = HPa + 4;
+  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD;
   float* Wreg = smem;
   float* sc = Wreg + wreg_floats(MT, MTA);
   float* sa = sc + (HP * LDW1 + 3 * HP + 4);
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(ACT_THREADS) void policy_act_fused_kernel(FNet f, c
   // short latency-critical kernel (the PDE step waits for it): outrank the update passes it may share CUs with
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
-  const int HPa = 16 * MTA, LDWa = HPa + 4;
+  const int HPa = 16 * MTA, LDWa = HPa + LDWPAD;
   float* sa = smem;                                  // small image
   float* saW2 = sa + (HPa * LDW1 + 3 * HPa + 4);     // W2 [HPa][LDWa]
   const SmallLds SA = carve_small(sa, HPa);
@@ -888,7 +892,7 @@ static FNet fnet_of(const Mlp* M) {
 
 template <int MT, int MTA>
 static size_t lds_bytes(bool actor_pass) {
-  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + 4, LDWa = HPa + 4;
+  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD;
   (void)LDW;
   size_t f = (size_t)wreg_floats(MT, MTA) + small_floats(HP) + small_floats(HPa) + (size_t)HPa * LDWa * (actor_pass ? 2 : 1) + 8;
   return f * 4;
@@ -1007,7 +1011,7 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
   f.w = A->fw_pub[A->pub].as<float>();
   const int mta = mt_of(A->dims[1]);
   const int HPa = 16 * mta;
-  const size_t lds = ((size_t)small_floats(HPa) + (size_t)HPa * (HPa + 4)) * 4;
+  const size_t lds = ((size_t)small_floats(HPa) + (size_t)HPa * (HPa + LDWPAD)) * 4;
   const int tanh_out = A->acts[2] == PDEC_ACT_TANH;
   PDEC_REQUIRE(A->acts[2] == PDEC_ACT_TANH || A->acts[2] == PDEC_ACT_IDENTITY, "fused act: unsupported output activation");
   PDEC_REQUIRE(mta <= 2 && lds <= 64 * 1024, "fused act: hidden width %d too large", A->dims[1]);
