@@ -193,6 +193,19 @@ __device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MT
   }
 }
 
+// Asynchronous global -> LDS copy (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR round trip).
+// nfl floats, src and dst 16-byte aligned.  The data may be read after dma_wait() + a workgroup barrier.
+__device__ __forceinline__ void dma_copy(float* dst_lds, const float* src, int nfl, int tid) {
+  const int w = tid >> 6, l = tid & 63;
+  const int nchunk = nfl >> 8;
+  for (int c = w; c < nchunk; c += FTHREADS / 64)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 256 + l * 4),
+                                     (__attribute__((address_space(3))) void*)(dst_lds + (size_t)c * 256), 16, 0, 0);
+  const int done = nchunk << 8;
+  if (tid < nfl - done) dst_lds[done + tid] = src[done + tid];
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int MT>
 __device__ __forceinline__ void relu_(f32x4 (&h)[MT]) {
 #pragma unroll
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
 
   // ---- phase T: target actor + target critic
   STAMP(0);
-  load_big(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
+  dma_copy(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
   load_small(SC, g.Ct, tid);
   load_small(SA, g.At, tid);
   load_big(saW2, g.At.w + g.At.oW2, HPa * LDWa, tid);
@@ -369,6 +382,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     for (; i < n4; i += FTHREADS) { const f32x4 v = r4[i]; rsum += (v[0] + v[1]) + (v[2] + v[3]); }
     for (int k = 4 * n4 + tid; k < g.Bu; k += FTHREADS) rsum += g.r[k];
   }
+  dma_wait();
   const float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads
   STAMP(1);
 
@@ -399,8 +413,9 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   __syncthreads();
   STAMP(2);
   // ---- phase Q: behaviour critic forward
-  load_big(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
+  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
   load_small(SC, g.C, tid);
+  dma_wait();
   __syncthreads();
   STAMP(3);
 #pragma unroll
@@ -456,7 +471,8 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   head_bwd<MT>(dz2, h2, SC.w3, dq, q);
   __syncthreads();
   STAMP(5);
-  load_big(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
+  dma_copy(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
+  dma_wait();
   __syncthreads();
   STAMP(6);
   f32x4 dz1[MT];
@@ -541,11 +557,12 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   const int col = blockIdx.x * FCOLS + w * 16 + lr;
   const bool valid = col < g.Bu;
 
-  load_big(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
+  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
   load_small(SC, g.C, tid);
   load_small(SA, g.A, tid);
   load_big(saW2, g.A.w + g.A.oW2, HPa * LDWa, tid);
   load_big(saW2T, g.A.w + g.A.oW2T, HPa * LDWa, tid);
+  dma_wait();
   __syncthreads();
   float xs[4];
 #pragma unroll
@@ -571,7 +588,8 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   f32x4 dz2[MT];
   head_bwd<MT>(dz2, h2, SC.w3, dq, q);
   __syncthreads();
-  load_big(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
+  dma_copy(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
+  dma_wait();
   __syncthreads();
   f32x4 dz1[MT];
   layer_hh<MT, MT, false>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
