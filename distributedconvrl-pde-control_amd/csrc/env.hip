@@ -345,6 +345,59 @@ __device__ __forceinline__ void xch_complex(C2<T> (&a)[4], bool b1, bool b0) {
   }
 }
 
+// ---- fp32 fast path: the same exchanges written in place (inline asm), one instruction per moved word.
+// One binary step of a digit exchange on register pairs (P_k, Q_k), k = 0..3 (two components x two pairs):
+//   newQ = bit ? Q : perm(P),  newP = bit ? perm(Q) : P        (bit = the lane-id bit being exchanged)
+// as v_cndmask_b32_dpp (DPP permutes src0; VCC = lane mask of the bit, then its complement).  The builtin form
+// above costs ~2.5x the instructions in register copies and separate selects.
+#define PDEC_XSTEP(CA, CB, MASK, P0, Q0, P1, Q1, P2, Q2, P3, Q3)                                           \
+  {                                                                                                        \
+    float n0_, n1_, n2_, n3_;                                                                              \
+    asm("s_nop 1\n\t"                                                                                      \
+        "s_mov_b64 vcc, %12\n\t"                                                                           \
+        "v_cndmask_b32_dpp %8, %0, %1, vcc " CA " row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_cndmask_b32_dpp %9, %2, %3, vcc " CA " row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_cndmask_b32_dpp %10, %4, %5, vcc " CA " row_mask:0xf bank_mask:0xf\n\t"                          \
+        "v_cndmask_b32_dpp %11, %6, %7, vcc " CA " row_mask:0xf bank_mask:0xf\n\t"                          \
+        "s_mov_b64 vcc, %13\n\t"                                                                           \
+        "v_cndmask_b32_dpp %0, %1, %0, vcc " CB " row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_cndmask_b32_dpp %2, %3, %2, vcc " CB " row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_cndmask_b32_dpp %4, %5, %4, vcc " CB " row_mask:0xf bank_mask:0xf\n\t"                           \
+        "v_cndmask_b32_dpp %6, %7, %6, vcc " CB " row_mask:0xf bank_mask:0xf"                                \
+        : "+v"(P0), "+v"(Q0), "+v"(P1), "+v"(Q1), "+v"(P2), "+v"(Q2), "+v"(P3), "+v"(Q3), "=&v"(n0_), "=&v"(n1_), \
+          "=&v"(n2_), "=&v"(n3_)                                                                           \
+        : "s"(MASK), "s"(~(MASK))                                                                          \
+        : "vcc");                                                                                          \
+    Q0 = n0_; Q1 = n1_; Q2 = n2_; Q3 = n3_;                                                                \
+  }
+// digit = lane bits 3:2 (WHICH 1) or 1:0 (WHICH 0); bits 5:4 (WHICH 2) use the permlane swaps
+template <int WHICH>
+__device__ __forceinline__ void xch_complex_f32(C2<float> (&a)[4]) {
+  if (WHICH == 2) {
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\t"
+        "v_permlane32_swap_b32 %4, %6\n\t"
+        "v_permlane32_swap_b32 %1, %3\n\t"
+        "v_permlane32_swap_b32 %5, %7\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\t"
+        "v_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %6, %7"
+        : "+v"(a[0].x), "+v"(a[1].x), "+v"(a[2].x), "+v"(a[3].x), "+v"(a[0].y), "+v"(a[1].y), "+v"(a[2].y), "+v"(a[3].y));
+  } else if (WHICH == 1) {
+    // bit 3 (lane ^ 8 = row_ror:8), register pairs (0,2), (1,3)
+    PDEC_XSTEP("row_ror:8", "row_ror:8", 0xFF00FF00FF00FF00ull, a[0].x, a[2].x, a[1].x, a[3].x, a[0].y, a[2].y, a[1].y, a[3].y)
+    // bit 2: lanes with the bit clear read lane + 4 (row_ror:12), lanes with it set read lane - 4 (row_ror:4); pairs (0,1), (2,3)
+    PDEC_XSTEP("row_ror:12", "row_ror:4", 0xF0F0F0F0F0F0F0F0ull, a[0].x, a[1].x, a[2].x, a[3].x, a[0].y, a[1].y, a[2].y, a[3].y)
+  } else {
+    PDEC_XSTEP("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]", 0xCCCCCCCCCCCCCCCCull, a[0].x, a[2].x, a[1].x, a[3].x, a[0].y, a[2].y,
+               a[1].y, a[3].y)
+    PDEC_XSTEP("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]", 0xAAAAAAAAAAAAAAAAull, a[0].x, a[1].x, a[2].x, a[3].x, a[0].y, a[1].y,
+               a[2].y, a[3].y)
+  }
+}
+
 template <class T>
 struct FftWave256 {
   C2<T>* buf;
@@ -368,9 +421,13 @@ struct FftWave256 {
   }
   template <int ST>
   __device__ __forceinline__ void exchange(C2<T> (&a)[4]) {
-    if (ST == 0) xch_complex<2, T>(a, b1, b0);
-    else if (ST == 1) xch_complex<1, T>(a, b1, b0);
-    else xch_complex<0, T>(a, b1, b0);
+    if constexpr (sizeof(T) == 4) {
+      xch_complex_f32<2 - ST>(reinterpret_cast<C2<float>(&)[4]>(a));
+    } else {
+      if (ST == 0) xch_complex<2, T>(a, b1, b0);
+      else if (ST == 1) xch_complex<1, T>(a, b1, b0);
+      else xch_complex<0, T>(a, b1, b0);
+    }
   }
   template <int ST, int SGN>
   __device__ __forceinline__ void twiddle(C2<T> (&a)[4]) {
