@@ -398,6 +398,42 @@ __device__ __forceinline__ void xch_complex_f32(C2<float> (&a)[4]) {
   }
 }
 
+// ---- fp32 packed-math butterflies: VOP3P op_sel / neg modifiers give the multiplication by +-i and the complex
+// product without any register shuffling (the compiler scalarises these and adds ~60 moves per transform).
+typedef float pkf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pkf2 pk_add_mi(pkf2 a, pkf2 b) {   // a + (-i) b = (a.x + b.y, a.y - b.x)
+  pkf2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ pkf2 pk_add_pi(pkf2 a, pkf2 b) {   // a + i b = (a.x - b.y, a.y + b.x)
+  pkf2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int SGN>   // a * w (SGN < 0) or a * conj(w) (SGN > 0)
+__device__ __forceinline__ pkf2 pk_cmul(pkf2 a, pkf2 w) {
+  pkf2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                 // (a.x w.x, a.y w.x)
+  if (SGN < 0)   // (t.x - a.y w.y, t.y + a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  else           // (t.x + a.y w.y, t.y - a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+template <int SGN>
+__device__ __forceinline__ void pk_dft4(C2<float> (&a)[4]) {
+  pkf2 v0 = __builtin_bit_cast(pkf2, a[0]), v1 = __builtin_bit_cast(pkf2, a[1]), v2 = __builtin_bit_cast(pkf2, a[2]),
+       v3 = __builtin_bit_cast(pkf2, a[3]);
+  const pkf2 s02 = v0 + v2, d02 = v0 - v2, s13 = v1 + v3, d13 = v1 - v3;
+  v0 = s02 + s13;
+  v2 = s02 - s13;
+  v1 = SGN < 0 ? pk_add_mi(d02, d13) : pk_add_pi(d02, d13);   // d02 + (-+i) d13
+  v3 = SGN < 0 ? pk_add_pi(d02, d13) : pk_add_mi(d02, d13);   // d02 - (-+i) d13
+  a[0] = __builtin_bit_cast(C2<float>, v0); a[1] = __builtin_bit_cast(C2<float>, v1);
+  a[2] = __builtin_bit_cast(C2<float>, v2); a[3] = __builtin_bit_cast(C2<float>, v3);
+}
+
 template <class T>
 struct FftWave256 {
   C2<T>* buf;
@@ -433,23 +469,32 @@ struct FftWave256 {
   __device__ __forceinline__ void twiddle(C2<T> (&a)[4]) {
 #pragma unroll
     for (int k = 1; k < 4; ++k) {
-      C2<T> tw = w[ST][k - 1];
-      if (SGN > 0) tw.y = -tw.y;
-      a[k] = cmul(a[k], tw);
+      if constexpr (sizeof(T) == 4) {
+        a[k] = __builtin_bit_cast(C2<T>, pk_cmul<SGN>(__builtin_bit_cast(pkf2, a[k]), __builtin_bit_cast(pkf2, w[ST][k - 1])));
+      } else {
+        C2<T> tw = w[ST][k - 1];
+        if (SGN > 0) tw.y = -tw.y;
+        a[k] = cmul(a[k], tw);
+      }
     }
+  }
+  template <int SGN>
+  __device__ __forceinline__ void dft4(C2<T> (&a)[4]) {
+    if constexpr (sizeof(T) == 4) pk_dft4<SGN>(reinterpret_cast<C2<float>(&)[4]>(a));
+    else dft_small<4, SGN, T>(a);
   }
   template <int SGN>
   __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
     if (SGN < 0) {   // forward: natural -> digit-reversed
-      dft_small<4, -1, T>(a); twiddle<0, -1>(a); exchange<0>(a);
-      dft_small<4, -1, T>(a); twiddle<1, -1>(a); exchange<1>(a);
-      dft_small<4, -1, T>(a); twiddle<2, -1>(a); exchange<2>(a);
-      dft_small<4, -1, T>(a);
+      dft4<-1>(a); twiddle<0, -1>(a); exchange<0>(a);
+      dft4<-1>(a); twiddle<1, -1>(a); exchange<1>(a);
+      dft4<-1>(a); twiddle<2, -1>(a); exchange<2>(a);
+      dft4<-1>(a);
     } else {         // inverse: digit-reversed -> natural (unnormalised)
-      dft_small<4, +1, T>(a);
-      exchange<2>(a); twiddle<2, +1>(a); dft_small<4, +1, T>(a);
-      exchange<1>(a); twiddle<1, +1>(a); dft_small<4, +1, T>(a);
-      exchange<0>(a); twiddle<0, +1>(a); dft_small<4, +1, T>(a);
+      dft4<+1>(a);
+      exchange<2>(a); twiddle<2, +1>(a); dft4<+1>(a);
+      exchange<1>(a); twiddle<1, +1>(a); dft4<+1>(a);
+      exchange<0>(a); twiddle<0, +1>(a); dft4<+1>(a);
     }
   }
   __device__ __forceinline__ C2<T>* publish(const C2<T> (&a)[KS_MPT]) {
