@@ -77,11 +77,14 @@ __device__ __forceinline__ void tile_stage(const C2<T>* __restrict__ x, C2<T>* _
     dft_small<R, SGN, T>(a);
     const int base = q + s * R * pp, ps = pp * s;
     y[base] = a[0];
+    // one twiddle read per butterfly; w^2, w^3 by multiplication (the LDS, not the fp64 VALU, is the busy unit here)
+    C2<T> w1 = tw[ps];
+    if (SGN > 0) w1.y = -w1.y;
+    C2<T> w = w1;
 #pragma unroll
     for (int k = 1; k < R; ++k) {
-      C2<T> w = tw[ps * k];
-      if (SGN > 0) w.y = -w.y;
       y[base + s * k] = cmul(a[k], w);
+      if (k + 1 < R) w = cmul(w, w1);
     }
   }
 }
