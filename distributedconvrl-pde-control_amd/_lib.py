@@ -69,6 +69,7 @@ SIGNATURES = {
     "pdec_adam_polyak_step": [Handle, Handle, _d, _d, _d, _d, _d],
     "pdec_policy_act_rng": [Handle, _vp, _i, _d, _d, _i, _u64, _u64, _vp],
     "pdec_ddpg_update_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _vp],
+    "pdec_ddpg_update_small": [Handle] * 4 + [_vp] * 7 + [_i, _i, _d, _d, _i, _d, _d, _vp],
     "pdec_ddpg_update_critic_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _vp],
     "pdec_ddpg_update_actor_async": [Handle] * 4 + [_vp, _i, _d, _d, _vp],
     "pdec_policy_act": [Handle, _vp, _vp, _i, _d, _d, _vp],

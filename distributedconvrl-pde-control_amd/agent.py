@@ -77,16 +77,20 @@ class CircularArraySARTTrajectory:
         self.terminal.index_copy_(0, idx, t.to(torch.float32))
         self.n_rt += n
 
-    def sample(self, rng, batch_size):
-        """pde_sample / pde_fetch! (src/PDEagent.jl:317-340): inds in 1:length(t)-stride"""
+    def sample_slots(self, rng, batch_size):
+        """pde_sample (src/PDEagent.jl:317-321): inds in 1:length(t)-stride -> slots (i_s, i_rt, i_sn) of the (s, a),
+        (r, t) and s' entries (host numpy int64)"""
         L = len(self)
         hi = L - self.stride
-        inds = torch.as_tensor(rng.integers(0, hi, batch_size), device=self.device)
+        inds = rng.integers(0, hi, batch_size)
         base = max(0, self.n_rt - self.capacity)          # logical index of the oldest entry
         lg = base + inds
-        i_rt = lg % self.capacity
-        i_s = lg % (self.capacity + self.stride)
-        i_sn = (lg + self.stride) % (self.capacity + self.stride)
+        return (lg % (self.capacity + self.stride), lg % self.capacity,
+                (lg + self.stride) % (self.capacity + self.stride))
+
+    def sample(self, rng, batch_size):
+        """pde_sample / pde_fetch! (src/PDEagent.jl:317-340)"""
+        i_s, i_rt, i_sn = (torch.as_tensor(v, device=self.device) for v in self.sample_slots(rng, batch_size))
         return dict(state=self.state[i_s], action=self.action[i_s], reward=self.reward[i_rt],
                     terminal=self.terminal[i_rt], next_state=self.state[i_sn])
 
@@ -110,6 +114,7 @@ class CustomDDPGPolicy:
         self.update_step = 0
         self.actor_loss = self.critic_loss = 0.0
         self.reducer = reducer                            # data-parallel gradient all-reduce (or None)
+        self.use_small_update = True                      # minibatch updates of <= 16 transitions: one launch for all loops
         self._noise_seed, self._noise_off = int(noise_seed), 0
         m = behavior_actor.model
         self.lib, self.device = m.lib, m.device
@@ -199,6 +204,26 @@ class CustomDDPGPolicy:
         _lib.check(self.lib.pdec_adam_polyak_step(A.handle, At.handle, float(oa.eta), oa.beta[0], oa.beta[1],
                                                   oa.epsilon, float(self.p)))                  # :412, :415-417
 
+    def small_update_ok(self):
+        A, Cn = self.behavior_actor.model, self.behavior_critic.model
+        return (self.use_small_update and (self.reducer is None or self.reducer.world_size == 1) and self.batch_size <= 16
+                and A.dtype == torch.float32 and Cn.dtype == torch.float32 and len(A.acts) <= 4 and len(Cn.acts) <= 4)
+
+    def update_small(self, tr, slots):
+        """update_loops x update!(policy, batch) (src/PDEagent.jl:357-418) in one launch, sampling straight from the
+        device-resident trajectory `tr`; slots = int array [3, loops, Bu] (rows: s/a, r/t, s' slots)"""
+        A, Cn, At, Ct = (self.behavior_actor.model, self.behavior_critic.model, self.target_actor.model,
+                         self.target_critic.model)
+        d = torch.as_tensor(np.ascontiguousarray(slots, dtype=np.int32), device=self.device)
+        oc, oa = self.behavior_critic.optimizer, self.behavior_actor.optimizer
+        L = self._losses
+        _lib.check(self.lib.pdec_ddpg_update_small(
+            A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(tr.state), _lib.ptr(tr.action), _lib.ptr(tr.reward),
+            _lib.ptr(tr.terminal), C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()), C.c_void_p(d[2].data_ptr()),
+            int(slots.shape[1]), int(slots.shape[2]), float(self.y), float(self.p), int(self.quirk), float(oa.eta),
+            float(oc.eta), C.c_void_p(L.data_ptr())))
+        self._slots_keepalive = d
+
     def losses(self):
         """(actor_loss, critic_loss) of the last update (synchronises)"""
         v = self._losses.cpu().numpy()
@@ -244,6 +269,12 @@ class Agent:
         if not (len(tr) > p.update_after * tr.stride):        # :354
             return
         if p.update_step % p.update_freq != 0:                # :355
+            return
+        if p.small_update_ok():
+            # all update_loops minibatch updates in ONE launch (pdec_ddpg_update_small); the slots are drawn here, loop
+            # by loop, exactly as the per-loop path draws them
+            slots = np.stack([np.stack(tr.sample_slots(p.rng, p.batch_size)) for _ in range(p.update_loops)], axis=1)
+            p.update_small(tr, slots)                         # slots: [3, loops, Bu]
             return
         for _ in range(p.update_loops):                       # :357-360
             p.update(tr.sample(p.rng, p.batch_size))

@@ -1,0 +1,294 @@
+// mlp_small.hip -- the reference's ACTUAL update shape (minibatch of `batch_size = 3` transitions, `update_loops = 20`
+// updates per control step, src/PDEagent.jl:342-418, scripts/KS/setup/KSSetup.jl:66-71) in ONE launch.
+//
+// At Bu = 3 every GEMM of the update is a few hundred multiply-adds; run as separate launches (the generic path) an
+// update costs ~35 launches and a control step ~700, i.e. the step is pure launch latency (7 ms).  Here a single
+// workgroup walks through all `loops` updates back to back: gather the minibatch from the device-resident replay traces
+// (pde_fetch!, src/PDEagent.jl:323-340, indices drawn on the host exactly like pde_sample :317-321), target forward,
+// critic forward/backward + ADAM, actor forward/backward through the updated critic + ADAM, Polyak -- with workgroup
+// barriers between dependent layers.  Parameters, moments and gradients stay in global memory (L2-hot; a workgroup's
+// waves share the CU's L1, so a barrier orders them), activations in LDS.  fp32 like the reference's networks, ADAM
+// arithmetic in fp64 like Flux (see finish_param in mlp_mfma.hip).
+#include "common.hpp"
+#include "mlp.hpp"
+
+namespace pdec {
+
+#define SM_THREADS 256
+#define SM_MAXL 4
+
+struct SmallNet {
+  float *p, *g, *m, *v;     // flat parameters / gradients / ADAM moments (internal layout: W_l row-major [out][in], b_l)
+  float* pt;                // target parameters (Polyak destination) or null
+  int L, nparams;
+  int dims[SM_MAXL + 1], acts[SM_MAXL], woff[SM_MAXL], boff[SM_MAXL];
+};
+
+struct SmallArgs {
+  SmallNet A, C;            // behaviour actor / critic (pt = target networks' parameters)
+  const float *state, *action, *reward, *terminal;   // replay traces: [slot][ns], [slot][na], [slot], [slot]
+  const int *i_s, *i_rt, *i_sn;                      // [loops][Bu] slots of s/a, r/t and s'
+  int loops, Bu, ns, na, quirk, maxw;
+  float gamma, rho;
+  double eta_a, eta_c, b1, b2, eps, bp_a0, bp_a1, bp_c0, bp_c1;
+  float* losses;            // [2]: critic loss, actor loss of the last loop
+};
+
+__device__ __forceinline__ float sm_act(float z, int act) {
+  return act == PDEC_ACT_RELU ? fmaxf(z, 0.f) : (act == PDEC_ACT_TANH ? tanhf(z) : z);
+}
+__device__ __forceinline__ float sm_dact(float a, int act) {   // derivative expressed through the activation value
+  return act == PDEC_ACT_RELU ? (a > 0.f ? 1.f : 0.f) : (act == PDEC_ACT_TANH ? 1.f - a * a : 1.f);
+}
+
+// forward of one net: acts[0] = input [dims[0]][Bu] (already in LDS), acts[l] = layer outputs (feature-major)
+__device__ void sm_forward(const SmallNet& n, const float* p, float* const* a, int Bu, int tid) {
+  for (int l = 0; l < n.L; ++l) {
+    const int in = n.dims[l], out = n.dims[l + 1];
+    const float* W = p + n.woff[l];
+    const float* b = p + n.boff[l];
+    for (int idx = tid; idx < out * Bu; idx += SM_THREADS) {
+      const int f = idx / Bu, c = idx - f * Bu;
+      float z = b[f];
+      for (int k = 0; k < in; ++k) z = fmaf(W[f * in + k], a[l][k * Bu + c], z);
+      a[l + 1][idx] = sm_act(z, n.acts[l]);
+    }
+    __syncthreads();
+  }
+}
+
+// backward: dz0 holds dL/d(output activation) [dims[L]][Bu] on entry; writes gradients to n.g when want_dw;
+// on return the buffer `*dx_out` holds dL/d(input) [dims[0]][Bu] when want_dx
+__device__ void sm_backward(const SmallNet& n, const float* p, float* const* a, float* dz0, float* dz1, int Bu, int tid,
+                            bool want_dw, bool want_dx, float** dx_out) {
+  float *cur = dz0, *nxt = dz1;
+  for (int l = n.L - 1; l >= 0; --l) {
+    const int in = n.dims[l], out = n.dims[l + 1];
+    // dz = dL/da * act'(a)
+    for (int idx = tid; idx < out * Bu; idx += SM_THREADS) cur[idx] *= sm_dact(a[l + 1][idx], n.acts[l]);
+    __syncthreads();
+    if (want_dw) {
+      float* gW = n.g + n.woff[l];
+      float* gb = n.g + n.boff[l];
+      for (int idx = tid; idx < out * in; idx += SM_THREADS) {
+        const int f = idx / in, k = idx - f * in;
+        float acc = 0.f;
+        for (int c = 0; c < Bu; ++c) acc = fmaf(cur[f * Bu + c], a[l][k * Bu + c], acc);
+        gW[idx] = acc;
+      }
+      for (int f = tid; f < out; f += SM_THREADS) {
+        float acc = 0.f;
+        for (int c = 0; c < Bu; ++c) acc += cur[f * Bu + c];
+        gb[f] = acc;
+      }
+    }
+    if (l > 0 || want_dx) {
+      const float* W = p + n.woff[l];
+      for (int idx = tid; idx < in * Bu; idx += SM_THREADS) {
+        const int k = idx / Bu, c = idx - k * Bu;
+        float acc = 0.f;
+        for (int f = 0; f < out; ++f) acc = fmaf(W[f * in + k], cur[f * Bu + c], acc);
+        nxt[idx] = acc;
+      }
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  if (dx_out) *dx_out = cur;
+}
+
+// Flux ADAM (fp64 arithmetic, no FMA contraction) + Polyak into the target
+__device__ void sm_adam_polyak(const SmallNet& n, double eta, double b1, double b2, double eps, double omb1p, double omb2p,
+                               float rho, float omr, int tid) {
+#pragma clang fp contract(off)
+  for (int i = tid; i < n.nparams; i += SM_THREADS) {
+    const double gd = (double)n.g[i];
+    const float mt = (float)(b1 * (double)n.m[i] + (1.0 - b1) * gd);
+    const float vt = (float)(b2 * (double)n.v[i] + (1.0 - b2) * gd * gd);
+    n.m[i] = mt;
+    n.v[i] = vt;
+    const float delta = (float)((double)mt / omb1p / (sqrt((double)vt / omb2p) + eps) * eta);
+    n.p[i] = n.p[i] - delta;
+  }
+  __syncthreads();
+}
+__device__ void sm_polyak(const SmallNet& n, float rho, float omr, int tid) {
+#pragma clang fp contract(off)
+  for (int i = tid; i < n.nparams; i += SM_THREADS) n.pt[i] = rho * n.pt[i] + omr * n.p[i];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g) {
+  extern __shared__ __align__(16) float sm[];
+  const int tid = threadIdx.x, Bu = g.Bu, ns = g.ns, na = g.na, K0 = ns + na;
+  const int W = g.maxw * Bu;             // floats per activation buffer
+  // LDS carve: actor activations aA[0..L], critic activations aC[0..L], two dz buffers, batch scalars
+  float* aA[SM_MAXL + 1];
+  float* aC[SM_MAXL + 1];
+  float* q = sm;
+  for (int l = 0; l <= g.A.L; ++l) { aA[l] = q; q += W; }
+  for (int l = 0; l <= g.C.L; ++l) { aC[l] = q; q += W; }
+  float* dz0 = q; q += W;
+  float* dz1 = q; q += W;
+  float* r = q; q += Bu;
+  float* t = q; q += Bu;
+  float* qt = q; q += Bu;
+  float* red = q;                         // [4]
+  double bpa0 = g.bp_a0, bpa1 = g.bp_a1, bpc0 = g.bp_c0, bpc1 = g.bp_c1;
+  const float omr = 1.0f - g.rho;
+  for (int it = 0; it < g.loops; ++it) {
+    const int* is = g.i_s + it * Bu;
+    const int* irt = g.i_rt + it * Bu;
+    const int* isn = g.i_sn + it * Bu;
+    // ---- a' = At(s'), qt = Ct([s'; a'])                                        src/PDEagent.jl:385-386
+    for (int idx = tid; idx < ns * Bu; idx += SM_THREADS) {
+      const int k = idx / Bu, c = idx - k * Bu;
+      const float v = g.state[(size_t)isn[c] * ns + k];
+      aA[0][idx] = v;
+      aC[0][idx] = v;
+    }
+    for (int c = tid; c < Bu; c += SM_THREADS) {
+      r[c] = g.reward[irt[c]];
+      t[c] = g.terminal[irt[c]];
+    }
+    __syncthreads();
+    sm_forward(g.A, g.A.pt, aA, Bu, tid);
+    for (int idx = tid; idx < na * Bu; idx += SM_THREADS) aC[0][ns * Bu + idx] = aA[g.A.L][idx];
+    __syncthreads();
+    sm_forward(g.C, g.C.pt, aC, Bu, tid);
+    for (int c = tid; c < Bu; c += SM_THREADS) qt[c] = aC[g.C.L][c];
+    __syncthreads();
+    // ---- q = C([s; a])                                                           :392
+    for (int idx = tid; idx < K0 * Bu; idx += SM_THREADS) {
+      const int k = idx / Bu, c = idx - k * Bu;
+      aC[0][idx] = k < ns ? g.state[(size_t)is[c] * ns + k] : g.action[(size_t)is[c] * na + (k - ns)];
+    }
+    __syncthreads();
+    sm_forward(g.C, g.C.p, aC, Bu, tid);
+    if (tid == 0) {   // loss and dq (tiny: Bu <= 16); quirk: r arrives 1 x Bu and broadcasts against the Bu-vector
+      float rbar = 0.f;
+      for (int c = 0; c < Bu; ++c) rbar += r[c];
+      rbar /= (float)Bu;
+      float loss = 0.f;
+      for (int c = 0; c < Bu; ++c) {
+        const float cc = g.gamma * (1.f - t[c]) * qt[c] - aC[g.C.L][c];
+        if (g.quirk) {
+          for (int j = 0; j < Bu; ++j) loss += (r[j] + cc) * (r[j] + cc);
+        } else {
+          loss += (r[c] + cc) * (r[c] + cc);
+        }
+        dz0[c] = -(2.f / (float)Bu) * ((g.quirk ? rbar : r[c]) + cc);
+      }
+      red[0] = g.quirk ? loss / (float)(Bu * Bu) : loss / (float)Bu;
+    }
+    __syncthreads();
+    sm_backward(g.C, g.C.p, aC, dz0, dz1, Bu, tid, true, false, nullptr);         // :391-398
+    sm_adam_polyak(g.C, g.eta_c, g.b1, g.b2, g.eps, 1.0 - bpc0, 1.0 - bpc1, g.rho, omr, tid);   // :400
+    bpc0 *= g.b1;
+    bpc1 *= g.b2;
+    // ---- actor: -mean(C([s; A(s)])) with the updated critic                      :402-412
+    for (int idx = tid; idx < ns * Bu; idx += SM_THREADS) {
+      const int k = idx / Bu, c = idx - k * Bu;
+      aA[0][idx] = g.state[(size_t)is[c] * ns + k];
+    }
+    __syncthreads();
+    sm_forward(g.A, g.A.p, aA, Bu, tid);
+    for (int idx = tid; idx < na * Bu; idx += SM_THREADS) aC[0][ns * Bu + idx] = aA[g.A.L][idx];
+    __syncthreads();
+    sm_forward(g.C, g.C.p, aC, Bu, tid);
+    if (tid == 0) {
+      float s = 0.f;
+      for (int c = 0; c < Bu; ++c) s += aC[g.C.L][c];
+      red[1] = -s / (float)Bu;
+    }
+    for (int c = tid; c < Bu; c += SM_THREADS) dz0[c] = -1.f / (float)Bu;
+    __syncthreads();
+    float* dx = nullptr;
+    sm_backward(g.C, g.C.p, aC, dz0, dz1, Bu, tid, false, true, &dx);
+    float* dA = dx == dz0 ? dz1 : dz0;    // the buffer not holding dx
+    for (int idx = tid; idx < na * Bu; idx += SM_THREADS) dA[idx] = dx[ns * Bu + idx];
+    __syncthreads();
+    sm_backward(g.A, g.A.p, aA, dA, dx, Bu, tid, true, false, nullptr);
+    sm_adam_polyak(g.A, g.eta_a, g.b1, g.b2, g.eps, 1.0 - bpa0, 1.0 - bpa1, g.rho, omr, tid);
+    bpa0 *= g.b1;
+    bpa1 *= g.b2;
+    sm_polyak(g.A, g.rho, omr, tid);                                               // :415-417
+    sm_polyak(g.C, g.rho, omr, tid);
+  }
+  if (tid == 0 && g.losses) {
+    g.losses[0] = red[0];
+    g.losses[1] = red[1];
+  }
+}
+
+static int fill_net(SmallNet& n, Mlp* M, Mlp* T) {
+  PDEC_REQUIRE(M->L <= SM_MAXL, "small update: at most %d layers", SM_MAXL);
+  n.p = M->params.as<float>(); n.g = M->grads.as<float>(); n.m = M->m.as<float>(); n.v = M->v.as<float>();
+  n.pt = T->params.as<float>();
+  n.L = M->L; n.nparams = M->nparams;
+  for (int l = 0; l <= M->L; ++l) n.dims[l] = M->dims[l];
+  for (int l = 0; l < M->L; ++l) { n.acts[l] = M->acts[l]; n.woff[l] = (int)M->w_off[l]; n.boff[l] = (int)M->b_off[l]; }
+  return PDEC_OK;
+}
+
+}  // namespace pdec
+
+using namespace pdec;
+
+extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* state_trace,
+                                      const void* action_trace, const void* reward_trace, const void* terminal_trace,
+                                      const int32_t* idx_s, const int32_t* idx_rt, const int32_t* idx_sn, int loops, int Bu,
+                                      double gamma, double rho, int quirk, double eta_actor, double eta_critic,
+                                      void* losses_dev) {
+  Mlp* A = lookup_as<Mlp>(hA, Kind::Mlp);
+  Mlp* C = lookup_as<Mlp>(hC, Kind::Mlp);
+  Mlp* At = lookup_as<Mlp>(hAt, Kind::Mlp);
+  Mlp* Ct = lookup_as<Mlp>(hCt, Kind::Mlp);
+  if (!A || !C || !At || !Ct) { set_error("pdec_ddpg_update_small: bad network handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(state_trace && action_trace && reward_trace && terminal_trace && idx_s && idx_rt && idx_sn,
+               "pdec_ddpg_update_small: null argument");
+  PDEC_REQUIRE(loops >= 1 && Bu >= 1 && Bu <= 16, "pdec_ddpg_update_small: needs 1 <= Bu <= 16 (got %d)", Bu);
+  PDEC_REQUIRE(A->dtype == PDEC_F32 && C->dtype == PDEC_F32 && At->dtype == PDEC_F32 && Ct->dtype == PDEC_F32,
+               "pdec_ddpg_update_small: fp32 networks only (the reference's network dtype)");
+  PDEC_REQUIRE(At->dims == A->dims && Ct->dims == C->dims, "ddpg: target networks must have the behaviour networks' shapes");
+  const int ns = A->dims[0], na = A->dims[A->L];
+  PDEC_REQUIRE(C->dims[0] == ns + na && C->dims[C->L] == 1, "ddpg: critic must map ns+na -> 1");
+  PDEC_REQUIRE(A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream,
+               "pdec_ddpg_update_small: the four networks must share one stream");
+  SmallArgs g{};
+  int rc;
+  if ((rc = fill_net(g.A, A, At)) || (rc = fill_net(g.C, C, Ct))) return rc;
+  int maxw = 1;
+  for (int l = 0; l <= A->L; ++l) maxw = std::max(maxw, A->dims[l]);
+  for (int l = 0; l <= C->L; ++l) maxw = std::max(maxw, C->dims[l]);
+  g.maxw = maxw;
+  const size_t lds = ((size_t)(A->L + 1 + C->L + 1 + 2) * maxw * Bu + 3 * Bu + 4) * 4;
+  PDEC_REQUIRE(lds <= 160 * 1024, "pdec_ddpg_update_small: layers too wide for the in-LDS activations (%zu B)", lds);
+  g.state = (const float*)state_trace; g.action = (const float*)action_trace;
+  g.reward = (const float*)reward_trace; g.terminal = (const float*)terminal_trace;
+  g.i_s = idx_s; g.i_rt = idx_rt; g.i_sn = idx_sn;
+  g.loops = loops; g.Bu = Bu; g.ns = ns; g.na = na; g.quirk = quirk;
+  g.gamma = (float)gamma; g.rho = (float)rho;      // Float32 in the reference (y = 0.99f0, p = 0.995f0)
+  g.eta_a = eta_actor; g.eta_c = eta_critic; g.b1 = 0.9; g.b2 = 0.999; g.eps = 1e-8;
+  if (A->bp[0] < 0) { A->bp[0] = g.b1; A->bp[1] = g.b2; }
+  if (C->bp[0] < 0) { C->bp[0] = g.b1; C->bp[1] = g.b2; }
+  g.bp_a0 = A->bp[0]; g.bp_a1 = A->bp[1]; g.bp_c0 = C->bp[0]; g.bp_c1 = C->bp[1];
+  g.losses = (float*)losses_dev;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ddpg_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
+    attr_set = true;
+  }
+  {
+    ProfScope ps(C, "ddpg_small");
+    hipLaunchKernelGGL(ddpg_small_kernel, dim3(1), dim3(SM_THREADS), lds, C->stream, g);
+  }
+  PDEC_HIP(hipGetLastError());
+  for (int it = 0; it < loops; ++it) {
+    A->bp[0] *= g.b1; A->bp[1] *= g.b2;
+    C->bp[0] *= g.b1; C->bp[1] *= g.b2;
+  }
+  A->fw_dirty = C->fw_dirty = At->fw_dirty = Ct->fw_dirty = true;
+  return PDEC_OK;
+}

@@ -240,6 +240,19 @@ int pdec_ddpg_update_async(pdec_handle A, pdec_handle C, pdec_handle At, pdec_ha
                            int Bu, double gamma, double rho, int quirk, double eta_actor, double eta_critic,
                            void* losses_dev);
 
+/* The reference's actual update shape -- `update_loops` updates per control step on minibatches of `batch_size`
+ * transitions (src/PDEagent.jl:342-418; KSSetup.jl:66-71: 20 x 3) -- in ONE launch: minibatch gather from the
+ * device-resident replay traces (pde_fetch!, :323-340), the whole update, repeated `loops` times by one workgroup.
+ * Traces (fp32, as RL.jl keeps them, :112-117): state [slots][ns], action [slots][na], reward [slots],
+ * terminal [slots] (0/1).  idx_s / idx_rt / idx_sn: device int32 [loops][Bu] slots of (s,a), (r,t) and s',
+ * drawn by the host as pde_sample does (:317-321).  fp32 networks of up to 4 layers, 1 <= Bu <= 16.
+ * losses_dev (may be NULL): [critic, actor] loss of the last loop.  No host synchronisation. */
+int pdec_ddpg_update_small(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
+                           const void* state_trace, const void* action_trace, const void* reward_trace,
+                           const void* terminal_trace, const int32_t* idx_s, const int32_t* idx_rt,
+                           const int32_t* idx_sn, int loops, int Bu, double gamma, double rho, int quirk,
+                           double eta_actor, double eta_critic, void* losses_dev);
+
 /* the two halves of pdec_ddpg_update_async as separate calls (critic half: critic pass + ADAM(C) + Polyak(Ct);
  * actor half: actor pass with the updated critic + ADAM(A) + Polyak(At)), so that a caller can order the
  * actor half behind a concurrent reader of the actor's weights on another stream.  losses_dev as above. */

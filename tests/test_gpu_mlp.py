@@ -230,3 +230,52 @@ def test_update_async_and_split_sequence_agree(pkg, quirk):
             for x, y, z in zip(nets[0][i][0].params(), nets[1][i][0].params(), P):
                 assert np.array_equal(x, y)
                 assert relerr(x, z) <= 2e-4
+
+
+@pytest.mark.parametrize("quirk", [1, 0])
+@pytest.mark.parametrize("ns,na,sa,sc,drop", [(1, 1, 0.6, 7.0, True), (12, 1, 2.0, 17.0, True), (3, 1, 1.6, 7.0, False), (8, 8, 4.8, 56.0, True)])
+def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop):
+    """pdec_ddpg_update_small: the reference's update shape (update_loops x minibatch of batch_size = 3 drawn from the
+    replay traces, src/PDEagent.jl:317-418) in one launch == the oracle's update applied loop by loop on the same slots"""
+    from oracle import nn
+    rng = np.random.default_rng(31 + quirk)
+    da, aa = nn.layer_sizes(ns, na, sa, True, drop)
+    dc, ac = nn.layer_sizes(ns, na, sc, False, drop)
+    dtype, npdt = torch.float32, np.float32
+    A, PA = make_net(pkg, rng, da, aa, dtype, 16)
+    Cn, PC = make_net(pkg, rng, dc, ac, dtype, 16)
+    At, PAt = make_net(pkg, rng, da, aa, dtype, 16)
+    Ct, PCt = make_net(pkg, rng, dc, ac, dtype, 16)
+    optA, optC = nn.Adam(PA, 5e-4), nn.Adam(PC, 1e-3)
+    slots_n, loops, Bu = 500, 4, 3
+    S = rng.standard_normal((slots_n, ns)).astype(npdt)
+    Aa = rng.uniform(-1, 1, (slots_n, na)).astype(npdt)
+    R = -rng.uniform(0, 1, slots_n).astype(npdt)
+    T = (rng.uniform(0, 1, slots_n) < 0.1).astype(npdt)
+    i_s = rng.integers(0, slots_n, (loops, Bu))
+    i_rt = rng.integers(0, slots_n, (loops, Bu))
+    i_sn = rng.integers(0, slots_n, (loops, Bu))
+    out = None
+    for it in range(loops):
+        out = nn.ddpg_update(PA, PC, PAt, PCt, optA, optC, aa, ac, S[i_s[it]].T, Aa[i_s[it]].T, R[i_rt[it]], T[i_rt[it]],
+                             S[i_sn[it]].T, npdt(np.float32(0.99)), np.float32(0.995), bool(quirk))
+    L = pkg._lib
+    dS, dA, dR, dT = to_dev(S, dtype), to_dev(Aa, dtype), to_dev(R, dtype), to_dev(T, dtype)
+    idx = torch.as_tensor(np.stack([i_s, i_rt, i_sn]).astype(np.int32), device="cuda:0")
+    losses = torch.zeros(2, dtype=dtype, device="cuda:0")
+    import ctypes as C_
+    L.check(A.lib.pdec_ddpg_update_small(A.handle, Cn.handle, At.handle, Ct.handle, L.ptr(dS), L.ptr(dA), L.ptr(dR), L.ptr(dT),
+                                         C_.c_void_p(idx[0].data_ptr()), C_.c_void_p(idx[1].data_ptr()),
+                                         C_.c_void_p(idx[2].data_ptr()), loops, Bu, 0.99, 0.995, quirk, 5e-4, 1e-3, L.ptr(losses)))
+    lv = losses.cpu().numpy()
+    assert abs(lv[0] - out["critic_loss"]) <= 2e-4 * max(1.0, abs(out["critic_loss"]))
+    assert abs(lv[1] - out["actor_loss"]) <= 2e-4 * max(1.0, abs(out["actor_loss"]))
+    # four chained fp32 updates: ADAM's m / (sqrt(v) + eps) amplifies rounding differences of near-zero gradients, so
+    # the chained tolerance is looser than the single-update one used above (2e-4)
+    for net, P in ((A, PA), (Cn, PC), (At, PAt), (Ct, PCt)):
+        for x, y in zip(net.params(), P):
+            assert relerr(x, y) <= 2e-3
+    # the ADAM step counters advanced by `loops`: a following generic update continues the same optimiser state
+    m = np.empty(A.num_params, dtype=np.float32); v = np.empty_like(m); bp = (C_.c_double * 2)()
+    L.check(A.lib.pdec_adam_get_state(A.handle, m.ctypes.data_as(C_.c_void_p), v.ctypes.data_as(C_.c_void_p), bp))
+    assert abs(bp[0] - 0.9 ** (loops + 1)) <= 1e-12
