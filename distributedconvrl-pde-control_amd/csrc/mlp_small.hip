@@ -29,6 +29,8 @@ struct SmallArgs {
   const float *state, *action, *reward, *terminal;   // replay traces: [slot][ns], [slot][na], [slot], [slot]
   const int *i_s, *i_rt, *i_sn;                      // [loops][Bu] slots of s/a, r/t and s'
   int loops, Bu, ns, na, quirk, maxw;
+  int lds_params;           // != 0: parameters, moments and gradients of all four networks are staged in LDS for the whole
+                            // launch (the layer-to-layer dependency chain then pays LDS, not L2, latency)
   float gamma, rho;
   double eta_a, eta_c, b1, b2, eps, bp_a0, bp_a1, bp_c0, bp_c1;
   float* losses;            // [2]: critic loss, actor loss of the last loop
@@ -41,18 +43,39 @@ __device__ __forceinline__ float sm_dact(float a, int act) {   // derivative exp
   return act == PDEC_ACT_RELU ? (a > 0.f ? 1.f : 0.f) : (act == PDEC_ACT_TANH ? 1.f - a * a : 1.f);
 }
 
+// items x (sum over `len` terms): narrow reductions run one item per thread, wide ones (len >= 32, e.g. the critic's
+// 140/340/1120-wide output layer) one item per wave with the terms spread over the lanes + a shuffle reduction, so no
+// thread walks a long dependent chain of loads
+template <class TermF, class StoreF>
+__device__ __forceinline__ void sm_reduce(int items, int len, int tid, TermF term, StoreF store) {
+  if (len >= 32) {
+    const int wv = tid >> 6, lane = tid & 63;
+    for (int it = wv; it < items; it += SM_THREADS / 64) {
+      float acc = 0.f;
+      for (int r = lane; r < len; r += 64) acc += term(it, r);
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+      if (lane == 0) store(it, acc);
+    }
+  } else {
+    for (int it = tid; it < items; it += SM_THREADS) {
+      float acc = 0.f;
+      for (int r = 0; r < len; ++r) acc += term(it, r);
+      store(it, acc);
+    }
+  }
+}
+
 // forward of one net: acts[0] = input [dims[0]][Bu] (already in LDS), acts[l] = layer outputs (feature-major)
 __device__ void sm_forward(const SmallNet& n, const float* p, float* const* a, int Bu, int tid) {
   for (int l = 0; l < n.L; ++l) {
-    const int in = n.dims[l], out = n.dims[l + 1];
+    const int in = n.dims[l], out = n.dims[l + 1], act = n.acts[l];
     const float* W = p + n.woff[l];
     const float* b = p + n.boff[l];
-    for (int idx = tid; idx < out * Bu; idx += SM_THREADS) {
-      const int f = idx / Bu, c = idx - f * Bu;
-      float z = b[f];
-      for (int k = 0; k < in; ++k) z = fmaf(W[f * in + k], a[l][k * Bu + c], z);
-      a[l + 1][idx] = sm_act(z, n.acts[l]);
-    }
+    const float* ain = a[l];
+    float* aout = a[l + 1];
+    sm_reduce(out * Bu, in, tid,
+              [&](int idx, int k) { const int f = idx / Bu, c = idx - f * Bu; return W[f * in + k] * ain[k * Bu + c]; },
+              [&](int idx, float z) { aout[idx] = sm_act(z + b[idx / Bu], act); });
     __syncthreads();
   }
 }
@@ -84,12 +107,11 @@ __device__ void sm_backward(const SmallNet& n, const float* p, float* const* a, 
     }
     if (l > 0 || want_dx) {
       const float* W = p + n.woff[l];
-      for (int idx = tid; idx < in * Bu; idx += SM_THREADS) {
-        const int k = idx / Bu, c = idx - k * Bu;
-        float acc = 0.f;
-        for (int f = 0; f < out; ++f) acc = fmaf(W[f * in + k], cur[f * Bu + c], acc);
-        nxt[idx] = acc;
-      }
+      const float* dzc = cur;
+      float* dxn = nxt;
+      sm_reduce(in * Bu, out, tid,
+                [&](int idx, int f) { const int k = idx / Bu, c = idx - k * Bu; return W[f * in + k] * dzc[f * Bu + c]; },
+                [&](int idx, float v) { dxn[idx] = v; });
     }
     __syncthreads();
     float* t = cur; cur = nxt; nxt = t;
@@ -118,7 +140,8 @@ __device__ void sm_polyak(const SmallNet& n, float rho, float omr, int tid) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g) {
+__global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g_in) {
+  SmallArgs g = g_in;
   extern __shared__ __align__(16) float sm[];
   const int tid = threadIdx.x, Bu = g.Bu, ns = g.ns, na = g.na, K0 = ns + na;
   const int W = g.maxw * Bu;             // floats per activation buffer
@@ -136,6 +159,23 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g) {
   float* red = q;                         // [4]
   double bpa0 = g.bp_a0, bpa1 = g.bp_a1, bpc0 = g.bp_c0, bpc1 = g.bp_c1;
   const float omr = 1.0f - g.rho;
+  // optional LDS residency of the learner state: [A.p | A.pt | A.m | A.v | A.g | C.p | C.pt | C.m | C.v | C.g]
+  SmallNet gA = g.A, gC = g.C;     // global-memory views (written back at the end)
+  if (g.lds_params) {
+    float* base = red + 4;
+    float* lp[10];
+    const float* src[10] = {gA.p, gA.pt, gA.m, gA.v, nullptr, gC.p, gC.pt, gC.m, gC.v, nullptr};
+    for (int k = 0; k < 10; ++k) {
+      const int n = k < 5 ? gA.nparams : gC.nparams;
+      lp[k] = base;
+      base += (n + 3) & ~3;
+      if (src[k])
+        for (int i = tid; i < n; i += SM_THREADS) lp[k][i] = src[k][i];
+    }
+    g.A.p = lp[0]; g.A.pt = lp[1]; g.A.m = lp[2]; g.A.v = lp[3]; g.A.g = lp[4];
+    g.C.p = lp[5]; g.C.pt = lp[6]; g.C.m = lp[7]; g.C.v = lp[8]; g.C.g = lp[9];
+    __syncthreads();
+  }
   for (int it = 0; it < g.loops; ++it) {
     const int* is = g.i_s + it * Bu;
     const int* irt = g.i_rt + it * Bu;
@@ -219,6 +259,10 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g) {
     g.losses[0] = red[0];
     g.losses[1] = red[1];
   }
+  if (g.lds_params) {
+    for (int i = tid; i < gA.nparams; i += SM_THREADS) { gA.p[i] = g.A.p[i]; gA.pt[i] = g.A.pt[i]; gA.m[i] = g.A.m[i]; gA.v[i] = g.A.v[i]; }
+    for (int i = tid; i < gC.nparams; i += SM_THREADS) { gC.p[i] = g.C.p[i]; gC.pt[i] = g.C.pt[i]; gC.m[i] = g.C.m[i]; gC.v[i] = g.C.v[i]; }
+  }
 }
 
 static int fill_net(SmallNet& n, Mlp* M, Mlp* T) {
@@ -262,8 +306,11 @@ extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handl
   for (int l = 0; l <= A->L; ++l) maxw = std::max(maxw, A->dims[l]);
   for (int l = 0; l <= C->L; ++l) maxw = std::max(maxw, C->dims[l]);
   g.maxw = maxw;
-  const size_t lds = ((size_t)(A->L + 1 + C->L + 1 + 2) * maxw * Bu + 3 * Bu + 4) * 4;
+  size_t lds = ((size_t)(A->L + 1 + C->L + 1 + 2) * maxw * Bu + 3 * Bu + 4) * 4;
   PDEC_REQUIRE(lds <= 160 * 1024, "pdec_ddpg_update_small: layers too wide for the in-LDS activations (%zu B)", lds);
+  const size_t lds_state = (size_t)5 * (((A->nparams + 3) & ~3) + ((C->nparams + 3) & ~3)) * 4;
+  g.lds_params = lds + lds_state <= 150 * 1024;
+  if (g.lds_params) lds += lds_state;
   g.state = (const float*)state_trace; g.action = (const float*)action_trace;
   g.reward = (const float*)reward_trace; g.terminal = (const float*)terminal_trace;
   g.i_s = idx_s; g.i_rt = idx_rt; g.i_sn = idx_sn;

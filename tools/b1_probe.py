@@ -1,14 +1,46 @@
-import importlib, sys, time
-sys.path.insert(0, '/root/repo')
-import numpy as np, torch
+#!/usr/bin/env python3
+"""Diagnostic: speed of the reference-shaped single-trajectory run loop (KS22, B = 1, 2-layer nets, batch_size 3,
+update_loops 20) through the host mirror; optional cProfile of the host side."""
+import cProfile
+import importlib
+import os
+import pstats
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("distributedconvrl-pde-control_amd")
 setup = pkg.KSSetup.KS22()
 env = pkg.PDEenv(setup, B=1, dtype=torch.float64)
 agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0))
 hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, collect_bestDF=False)
+pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(60), hook)          # warm-up
+torch.cuda.synchronize()
+n0 = len(hook.rewards)
+pr = cProfile.Profile() if "--profile" in sys.argv else None
 t0 = time.perf_counter()
-pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(200), hook)
+if pr:
+    pr.enable()
+pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(400), hook)
+if pr:
+    pr.disable()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-steps = sum(1 for _ in range(1))
-print("episodes", len(hook.rewards), "time", dt, "s ; steps/s ~", (len(hook.rewards) * 51) / dt, "rewards", hook.rewards[-3:])
+eps = len(hook.rewards) - n0
+print(f"episodes {eps}, {eps * 51 / dt:.0f} env-steps/s ({dt / (eps * 51) * 1e3:.2f} ms/step)")
+if pr:
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+import ctypes as C
+L = pkg._lib
+cm = agent.policy.behavior_critic.model
+L.check(cm.lib.pdec_prof_reset(cm.handle)); L.check(cm.lib.pdec_prof_enable(cm.handle, 1))
+L.check(env.lib.pdec_prof_reset(env.handle)); L.check(env.lib.pdec_prof_enable(env.handle, 1))
+pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(100), hook)
+torch.cuda.synchronize()
+for h, lab in ((cm.handle, b"ddpg_small"), (env.handle, b"ks_env_step")):
+    ms, n = C.c_double(), C.c_int()
+    L.check(cm.lib.pdec_prof_get(h, lab, C.byref(ms), C.byref(n)))
+    print(lab.decode(), f"{ms.value * 1e3:.1f} us/launch (events, incl. ~10 us event overhead), {n.value} launches")
