@@ -23,6 +23,22 @@ class PDEhook:
         self.history, self.errored_episodes = [], []
         self.error_detection = error_detection or (lambda y: False)
         self.init_rng = init_rng or np.random.default_rng(0)
+        self._reward_dev, self._rows_dev = None, []
+
+    def _flush(self, env):
+        """bring the episode's device-side accumulators to the host (one synchronisation per episode)"""
+        if self._reward_dev is not None:
+            self.reward += float(self._reward_dev.item())
+            self._reward_dev = None
+        for steps, a, p, y, r in self._rows_dev:
+            a, p, y = (t.cpu().numpy().astype(np.float64) for t in (a, p, y))
+            if env.is_fluid:
+                y, p = (y[..., 0] + 1j * y[..., 1]).T, (p[..., 0] + 1j * p[..., 1]).T
+            elif y.ndim == 2:
+                y = y.T
+            self.currentDF.append(dict(timestep=steps, action=a.T.reshape(-1) if a.ndim == 2 else a.reshape(-1), p=p, y=y,
+                                       reward=r.cpu().numpy().astype(np.float64)))
+        self._rows_dev = []
 
     def __call__(self, stage, agent, env):
         if stage == PRE_EXPERIMENT_STAGE:                       # PDEhook.jl:35-40
@@ -38,12 +54,15 @@ class PDEhook:
                 env.y.copy_(env.y0)
                 env.state.copy_(env.featurize(env.y, env.state if env.setup.temporal_steps > 1 else None))
         elif stage == POST_ACT_STAGE:                           # :51-63
-            self.reward += float(env.reward.mean().item())
+            # accumulated and logged ON THE DEVICE (row F4): no device->host copy or sync per control step; the host
+            # values are materialised once per episode in POST_EPISODE_STAGE (send_to_host, PDEhook.jl:58-59)
+            r = env.reward.mean()
+            self._reward_dev = r if self._reward_dev is None else self._reward_dev + r
             if self.collect_bestDF:
-                self.currentDF.append(dict(timestep=env.steps, action=env.action_julia().reshape(-1),
-                                           p=env.p[0].cpu().numpy().astype(np.float64), y=env.y_julia(),
-                                           reward=env.reward[0].cpu().numpy().astype(np.float64)))
+                self._rows_dev.append((env.steps, env.action[0].clone(), env.p[0].clone(), env.y[0].clone(),
+                                       env.reward[0].clone()))
         elif stage == POST_EPISODE_STAGE:                       # :65-97
+            self._flush(env)
             if env.time >= env.te and self.ep >= self.min_best_episode:
                 self.rewards_compare.append(self.reward)
                 if self.collect_NNA and self.reward >= max(self.rewards_compare):
