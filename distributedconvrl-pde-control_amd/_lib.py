@@ -47,6 +47,7 @@ SIGNATURES = {
     "pdec_prof_get": [Handle, C.c_char_p, _pd, C.POINTER(_i)],
     "pdec_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _pd, _pd, _pi32],
     "pdec_fluid_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _pd, _pi32, _pd, _pi32, _pi32],
+    "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
     "pdec_featurize": [Handle, _vp, _vp, _vp],

@@ -28,6 +28,7 @@
 // Layout: Julia ComplexF64[ny, nx] column-major = memory [nx][ny] (y fastest); square box (nx = ny = n,
 // Lx = Ly) as in every shipped script.  "fast axis" = y, "slow axis" = x.
 #include "env.hpp"
+#include "wave_fft.hpp"
 
 namespace pdec {
 
@@ -483,6 +484,33 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
   preal[((size_t)b * n + j) * n + i] = acc;
 }
 
+// ------------------------------------------------------------------ wave FFT unit-test entry (pdec_debug_wave_fft)
+template <int E, int Q>
+__global__ __launch_bounds__(256) void wave_fft_debug_kernel(const C2<double>* __restrict__ in, C2<double>* __restrict__ out,
+                                                            const C2<double>* __restrict__ tw, int nlines, int sgn) {
+  typedef WaveFftD<E, Q> F;
+  const int lane = threadIdx.x & 63, line = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (line >= nlines) return;
+  F f;
+  f.init(tw, lane);
+  C2<double> a[F::R];
+  const C2<double>* x = in + (size_t)line * F::N;
+  C2<double>* y = out + (size_t)line * F::N;
+  if (sgn < 0) {
+#pragma unroll
+    for (int j = 0; j < F::R; ++j) a[j] = x[lane + 64 * j];
+    f.forward(a);
+#pragma unroll
+    for (int j = 0; j < F::R; ++j) y[f.mode_index(j)] = a[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < F::R; ++j) a[j] = x[f.mode_index(j)];
+    f.inverse(a);
+#pragma unroll
+    for (int j = 0; j < F::R; ++j) y[lane + 64 * j] = a[j];
+  }
+}
+
 // ------------------------------------------------------------------ host side
 struct FluidEnv : Env {
   int n = 0, p = 0, nl = 0, TL = 0, TLn = 0, BH = 0, BW = 0, nb1 = 0;
@@ -781,5 +809,30 @@ extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, in
   PDEC_HIP(E->dots.alloc(Bz * c.S * 8));
   if ((rc = fluid_set_attrs(*E))) return rc;
   *h = register_object(std::move(E));
+  return PDEC_OK;
+}
+
+// Unit-test entry for the register-resident wave FFT (wave_fft.hpp): nlines lines of `len` complex doubles, natural
+// order in and out, unnormalised forward (sgn < 0) or inverse (sgn > 0).  len in {128, 256, 384, 512, 768}.
+extern "C" int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, int nlines, int sgn) {
+  PDEC_REQUIRE(in_dev && out_dev && nlines >= 1, "pdec_debug_wave_fft: null/empty");
+  std::vector<double> tw(2 * (size_t)len);
+  for (int m = 0; m < len; ++m) { tw[2 * m] = cos(2 * M_PI * m / len); tw[2 * m + 1] = -sin(2 * M_PI * m / len); }
+  DevBuf d;
+  int rc = upload_converted(d, tw.data(), tw.size(), PDEC_F64);
+  if (rc) return rc;
+  const dim3 grid((nlines + 3) / 4), block(256);
+  typedef const C2<double>* CI;
+  typedef C2<double>* CO;
+#define WFD(E, Q) hipLaunchKernelGGL((wave_fft_debug_kernel<E, Q>), grid, block, 0, 0, (CI)in_dev, (CO)out_dev, d.as<C2<double>>(), nlines, sgn)
+  if (len == 768) WFD(4, 3);
+  else if (len == 512) WFD(4, 2);
+  else if (len == 256) WFD(4, 1);
+  else if (len == 384) WFD(2, 3);
+  else if (len == 128) WFD(2, 1);
+  else { set_error("pdec_debug_wave_fft: unsupported length %d", len); return PDEC_E_INVALID; }
+#undef WFD
+  PDEC_HIP(hipGetLastError());
+  PDEC_HIP(hipDeviceSynchronize());
   return PDEC_OK;
 }

@@ -165,6 +165,11 @@ int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, cons
                        const void* state_prev, void* y_out, void* p_out, void* state_out,
                        void* reward_out, int32_t* done);
 
+/* Unit-test entry of the register-resident wave FFT the fluid kernels are built on (csrc/wave_fft.hpp): nlines
+ * lines of `len` complex doubles (device), natural order in and out, unnormalised forward (sgn < 0) / inverse
+ * (sgn > 0) with FFTW's conventions (src/fluid_rk4.jl uses FFTW's fft / ifft).  len in {128,256,384,512,768}. */
+int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, int nlines, int sgn);
+
 /* ---------------------------------------------------------------- networks ----------- */
 /* Chain(Dense...) with weights shared across columns (src/PDEagent.jl:14-56).
  * dims[n_layers+1], acts[n_layers].  params_host: Flux.params order W1,b1,W2,b2,... each W

@@ -152,3 +152,24 @@ def test_padded_equals_unpadded_for_band_limited_data(pkg):
         env = pkg.PDEenv(setup, B=1, dtype=F64)
         outs.append(_jul(env.rhs(to_dev(_mem(fh[None]), F64), torch.zeros_like(env.y)))[0])
     assert np.abs(outs[0] - outs[1]).max() <= 1e-11 * np.abs(outs[0]).max()
+
+
+@pytest.mark.parametrize("n", [128, 256, 384, 512, 768])
+def test_wave_fft_engine_matches_numpy(pkg, n):
+    """the register-resident one-line-per-wave FFT (csrc/wave_fft.hpp) the fluid kernels are built on: forward and
+    unnormalised inverse against numpy.fft (= FFTW's conventions), fp64 <= 1e-13 relative"""
+    rng = np.random.default_rng(n)
+    L = pkg._lib
+    lib = L.init(0)
+    nl = 9
+    x = rng.standard_normal((nl, n)) + 1j * rng.standard_normal((nl, n))
+    xin = to_dev(np.stack([x.real, x.imag], axis=-1), F64)
+    out = torch.empty_like(xin)
+    L.check(lib.pdec_debug_wave_fft(L.ptr(xin), L.ptr(out), n, nl, -1))
+    got = out.cpu().numpy()
+    ref = np.fft.fft(x, axis=1)
+    assert np.abs(got[..., 0] + 1j * got[..., 1] - ref).max() <= 1e-13 * np.abs(ref).max()
+    L.check(lib.pdec_debug_wave_fft(L.ptr(xin), L.ptr(out), n, nl, +1))
+    got = out.cpu().numpy()
+    ref = np.fft.ifft(x, axis=1) * n
+    assert np.abs(got[..., 0] + 1j * got[..., 1] - ref).max() <= 1e-13 * np.abs(ref).max()
