@@ -484,6 +484,156 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
   preal[((size_t)b * n + j) * n + i] = acc;
 }
 
+// ------------------------------------------------------------------ wave-FFT variants of K1 / K2 / K3
+// Same three passes, but every line transform runs in the registers of ONE wave (wave_fft.hpp): no LDS stage
+// round trips, no barriers inside a transform.  LDS is only used to turn coalesced global accesses into the
+// permuted (digit-reversed) element order the transforms consume / produce, and for K2's column transposition.
+// Used when the padded length p is one of 128/256/384/512/768 (otherwise the LDS-tile kernels above).
+
+// K1w: one wave per carried line s.  LDS: per wave the two spectrum lines j and mirror(j) (2 n complex).
+template <int E, int Q>
+__global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, const C2<double>* __restrict__ omg,
+                                                        C2<double>* __restrict__ W) {
+  typedef WaveFftD<E, Q> F;
+  typedef C2<double> Z;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = d.n, p = d.p;
+  Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)wv * 2 * n;
+  Z* Lm = Lj + n;
+  const int s = blockIdx.x * 4 + wv, b = blockIdx.y;
+  if (s >= d.nl) return;                                  // whole wave; the kernel has no workgroup barrier
+  const int jp = fl_line_jp(s, n, p, d.nl);
+  const int j = fl_unpad(jp, n, p), jm = fl_unpad((p - jp) % p, n, p);
+  const Z zero = mk<double>(0, 0);
+  for (int i = lane; i < n; i += 64) {
+    Lj[i] = j >= 0 ? omg[((size_t)b * n + j) * n + i] : zero;
+    Lm[i] = jm >= 0 ? omg[((size_t)b * n + jm) * n + i] : zero;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const double kj = j >= 0 ? d.k[j] : 0.0, kjm = jm >= 0 ? d.k[jm] : 0.0;
+  F f;
+  f.init(d.twp, lane);
+#pragma unroll 1
+  for (int fld = 0; fld < 2; ++fld) {
+    Z a[F::R];
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) {
+      const int ip = f.mode_index(jj);
+      const int i = fl_unpad(ip, n, p), im = fl_unpad((p - ip) % p, n, p);
+      Z au = zero, av = zero, ax = zero, ay = zero, mu = zero, mv = zero, mx = zero, my = zero;
+      if (j >= 0 && i >= 0) fl_spec<double>(Lj[i], kj, d.k[i], i == 0 && j == 0, au, av, ax, ay);
+      if (jm >= 0 && im >= 0) fl_spec<double>(Lm[im], kjm, d.k[im], im == 0 && jm == 0, mu, mv, mx, my);
+      if (fld == 0) {   // Z1 = Herm(u) + i Herm(v)
+        const Z hu = mk<double>(0.5 * (au.x + mu.x), 0.5 * (au.y - mu.y)), hv = mk<double>(0.5 * (av.x + mv.x), 0.5 * (av.y - mv.y));
+        a[jj] = mk<double>(hu.x - hv.y, hu.y + hv.x);
+      } else {          // Z2 = Herm(wx) + i Herm(wy)
+        const Z hx = mk<double>(0.5 * (ax.x + mx.x), 0.5 * (ax.y - mx.y)), hy = mk<double>(0.5 * (ay.x + my.x), 0.5 * (ay.y - my.y));
+        a[jj] = mk<double>(hx.x - hy.y, hx.y + hy.x);
+      }
+    }
+    f.inverse(a);
+    Z* w = W + (((size_t)b * 2 + fld) * d.nl + s) * p;
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) w[lane + 64 * jj] = a[jj];
+  }
+}
+
+// K2w: 8 columns per workgroup, one wave per column.  LDS: the [8][p] column tile (transposition + permuted access).
+template <int E, int Q>
+__global__ __launch_bounds__(512) void fluid_k2w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W,
+                                                        C2<double>* __restrict__ W2) {
+  typedef WaveFftD<E, Q> F;
+  typedef C2<double> Z;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  Z* tile = reinterpret_cast<Z*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = d.n, p = d.p, LS = p + 1;
+  const int ip0 = blockIdx.x * 8, b = blockIdx.y;
+  F f;
+  f.init(d.twp, lane);
+  Z r0[F::R], a[F::R];
+#pragma unroll 1
+  for (int fld = 0; fld < 2; ++fld) {
+    if (fld) __syncthreads();
+    const Z* Wf = W + (((size_t)b * 2 + fld) * d.nl) * p;
+    for (int idx = tid; idx < 8 * p; idx += 512) {          // transposed load, zero fill = pad() along x
+      const int t = idx & 7, jp = idx >> 3;
+      const int s = fl_line_of(jp, n, p, d.nl), ip = ip0 + t;
+      Z v = mk<double>(0, 0);
+      if (s >= 0 && ip < p) v = Wf[(size_t)s * p + ip];
+      tile[t * LS + jp] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) a[jj] = tile[wv * LS + f.mode_index(jj)];
+    f.inverse(a);
+    if (fld == 0) {
+#pragma unroll
+      for (int jj = 0; jj < F::R; ++jj) r0[jj] = a[jj];
+    }
+  }
+  // -(u wx + v wy), both ifft scalings; forward transform of the real product (one column per wave)
+#pragma unroll
+  for (int jj = 0; jj < F::R; ++jj) a[jj] = mk<double>(-(r0[jj].x * a[jj].x + r0[jj].y * a[jj].y) * d.inv2, 0.0);
+  f.forward(a);
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < F::R; ++jj) tile[wv * LS + f.mode_index(jj)] = a[jj];
+  __syncthreads();
+  for (int idx = tid; idx < 8 * n; idx += 512) {            // chop() along x + coalesced store
+    const int t = idx & 7, jj = idx >> 3, ip = ip0 + t;
+    if (ip < p) W2[((size_t)b * n + jj) * p + ip] = tile[t * LS + fl_pad(jj, n, p)];
+  }
+}
+
+// K3w: one wave per kept line j.  LDS: per wave one n-complex line (digit-reversed -> natural for coalesced global access).
+template <int E, int Q>
+__global__ __launch_bounds__(256) void fluid_k3w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W2,
+                                                        const C2<double>* omg_s, const C2<double>* __restrict__ phat,
+                                                        const C2<double>* f0, C2<double>* acc, C2<double>* out, int mode,
+                                                        double ca, double cb) {
+  typedef WaveFftD<E, Q> F;
+  typedef C2<double> Z;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = d.n, p = d.p;
+  Z* Ln = reinterpret_cast<Z*>(smem_raw) + (size_t)wv * n;
+  const int j = blockIdx.x * 4 + wv, b = blockIdx.y;
+  if (j >= n) return;
+  F f;
+  f.init(d.twp, lane);
+  Z a[F::R];
+  const Z* w2 = W2 + ((size_t)b * n + j) * p;
+#pragma unroll
+  for (int jj = 0; jj < F::R; ++jj) a[jj] = w2[lane + 64 * jj];
+  f.forward(a);
+#pragma unroll
+  for (int jj = 0; jj < F::R; ++jj) {
+    const int i = fl_unpad(f.mode_index(jj), n, p);          // chop() along y
+    if (i >= 0) Ln[i] = a[jj];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const double kj = d.k[j];
+  for (int i = lane; i < n; i += 64) {
+    const size_t off = ((size_t)b * n + j) * n + i;
+    const double ki = d.k[i], lin = -d.nu * (kj * kj + ki * ki);
+    const Z o = omg_s[off], nlv = Ln[i], ph = phat[off];
+    const Z k = mk<double>(lin * o.x + d.scale_out * nlv.x + ph.x, lin * o.y + d.scale_out * nlv.y + ph.y);
+    if (mode == 0) {
+      out[off] = k;
+    } else if (mode == 4) {
+      const Z ac = acc[off];
+      out[off] = mk<double>(ac.x + cb * k.x, ac.y + cb * k.y);
+    } else {
+      const Z fv = f0[off];
+      out[off] = mk<double>(fv.x + ca * k.x, fv.y + ca * k.y);
+      if (mode == 1) acc[off] = mk<double>(fv.x + cb * k.x, fv.y + cb * k.y);
+      else {
+        const Z ac = acc[off];
+        acc[off] = mk<double>(ac.x + cb * k.x, ac.y + cb * k.y);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wave FFT unit-test entry (pdec_debug_wave_fft)
 template <int E, int Q>
 __global__ __launch_bounds__(256) void wave_fft_debug_kernel(const C2<double>* __restrict__ in, C2<double>* __restrict__ out,
@@ -518,6 +668,7 @@ struct FluidEnv : Env {
   DevBuf k, twp, twn, sbox, sorg, abox, aorg, a2s_d, blkptr, blkidx;
   DevBuf W, W2, fs, acc, yreal, tmpc, dots, phat;
   size_t lds_p = 0, lds_n = 0;
+  int wave_E = 0, wave_Q = 0;     // != 0: the one-line-per-wave transforms serve the padded length p
 };
 
 static FluidDev<double> fluid_dev(const FluidEnv& E) {
@@ -559,11 +710,50 @@ static int fluid_set_attrs(const FluidEnv& E) {
 }
 
 // one rhs evaluation fused with an RK4 stage update (mode as in fluid_k3_kernel)
+template <int E, int Q>
+static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const void* omg_s, const void* phat, const void* f0,
+                                 void* acc, void* out, int mode, double ca, double cb) {
+  typedef C2<double> Z;
+  const int B = Ev.cfg.B, n = Ev.n, p = Ev.p;
+  static bool attr = false;
+  if (!attr) {
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k1w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k2w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k3w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  {
+    ProfScope ps(&Ev, "fluid_k1", true);
+    for (int r = 0; r < ps.reps; ++r)
+      hipLaunchKernelGGL((fluid_k1w_kernel<E, Q>), dim3((Ev.nl + 3) / 4, B), dim3(256), (size_t)4 * 2 * n * 16, Ev.stream, d,
+                         (const Z*)omg_s, Ev.W.as<Z>());
+  }
+  {
+    ProfScope ps(&Ev, "fluid_k2", true);
+    for (int r = 0; r < ps.reps; ++r)
+      hipLaunchKernelGGL((fluid_k2w_kernel<E, Q>), dim3((p + 7) / 8, B), dim3(512), (size_t)8 * (p + 1) * 16, Ev.stream, d,
+                         Ev.W.as<Z>(), Ev.W2.as<Z>());
+  }
+  {
+    ProfScope ps(&Ev, "fluid_k3", mode == 0);
+    for (int r = 0; r < ps.reps; ++r)
+      hipLaunchKernelGGL((fluid_k3w_kernel<E, Q>), dim3((n + 3) / 4, B), dim3(256), (size_t)4 * n * 16, Ev.stream, d,
+                         Ev.W2.as<Z>(), (const Z*)omg_s, (const Z*)phat, (const Z*)f0, (Z*)acc, (Z*)out, mode, ca, cb);
+  }
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
 static int fluid_rhs_launch(FluidEnv& E, const void* omg_s, const void* phat, const void* f0, void* acc, void* out,
                             int mode, double ca, double cb) {
   typedef C2<double> Z;
   const FluidDev<double> d = fluid_dev(E);
   const int B = E.cfg.B;
+  if (E.wave_E == 4 && E.wave_Q == 3) return fluid_rhs_launch_wave<4, 3>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 4 && E.wave_Q == 2) return fluid_rhs_launch_wave<4, 2>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 4 && E.wave_Q == 1) return fluid_rhs_launch_wave<4, 1>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 2 && E.wave_Q == 3) return fluid_rhs_launch_wave<2, 3>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 2 && E.wave_Q == 1) return fluid_rhs_launch_wave<2, 1>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
   {
     ProfScope ps(&E, "fluid_k1", true);
     for (int r = 0; r < ps.reps; ++r)
@@ -755,6 +945,16 @@ extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, in
   E->BH = BH; E->BW = BW;
   PDEC_REQUIRE(E->p <= 1536, "N=%d too large for the in-LDS line FFTs (max 1024 padded / 1536 un-padded)", n);
   PDEC_REQUIRE(make_fft_plan(E->p, E->plp) && make_fft_plan(n, E->pln), "N=%d: sizes must factor into 2,3,5", n);
+  if (!getenv("PDEC_FLUID_LDS_FFT")) {     // one-line-per-wave register transforms for the supported padded lengths
+    switch (E->p) {
+      case 768: E->wave_E = 4; E->wave_Q = 3; break;
+      case 512: E->wave_E = 4; E->wave_Q = 2; break;
+      case 256: E->wave_E = 4; E->wave_Q = 1; break;
+      case 384: E->wave_E = 2; E->wave_Q = 3; break;
+      case 128: E->wave_E = 2; E->wave_Q = 1; break;
+      default: break;
+    }
+  }
   E->TL = pick_tile(E->p);
   E->TLn = pick_tile(n);
   PDEC_REQUIRE(E->TL >= 2, "internal: tile too small");

@@ -40,11 +40,14 @@ def _fields(cfg, B, seed, hermitian=True):
 
 
 @pytest.mark.parametrize("n,ifpad,herm", [(16, 1, True), (16, 1, False), (16, 0, False), (32, 1, False), (24, 1, True),
-                                          (64, 1, True), (64, 0, True), (128, 1, True)])
+                                          (64, 1, True), (64, 0, True), (128, 1, True),
+                                          # padded / un-padded lengths served by the one-line-per-wave transforms
+                                          (128, 0, False), (256, 0, False), (256, 1, False), (256, 1, True), (512, 0, True),
+                                          (512, 1, False)])
 def test_rhs_matches_oracle(pkg, n, ifpad, herm):
     from oracle import fluid
-    setup, cfg = _pair(pkg, n, ifpad)
-    B = 3
+    setup, cfg = _pair(pkg, n, ifpad, spa=8 if n >= 256 else 4, variance=0.04 if n >= 256 else 0.08)
+    B = 3 if n < 256 else 2
     y, p = _fields(cfg, B, seed=n + ifpad, hermitian=herm)
     env = pkg.PDEenv(setup, B=B, dtype=F64)
     out = _jul(env.rhs(to_dev(_mem(y), F64), to_dev(_mem(p), F64)))
@@ -53,11 +56,11 @@ def test_rhs_matches_oracle(pkg, n, ifpad, herm):
         assert np.abs(out[b] - ref).max() <= 1e-11 * np.abs(ref).max(), (b, np.abs(out[b] - ref).max(), np.abs(ref).max())
 
 
-@pytest.mark.parametrize("n,ifpad", [(16, 1), (32, 1), (32, 0)])
+@pytest.mark.parametrize("n,ifpad", [(16, 1), (32, 1), (32, 0), (256, 1), (128, 0)])
 def test_do_step_rk4_matches_oracle(pkg, n, ifpad):
     from oracle import fluid
-    K = 3
-    setup, cfg = _pair(pkg, n, ifpad, K=K)
+    K = 3 if n < 128 else 2
+    setup, cfg = _pair(pkg, n, ifpad, K=K, spa=8 if n >= 128 else 4, variance=0.04 if n >= 128 else 0.08)
     B = 2
     y, p = _fields(cfg, B, seed=7)
     env = pkg.PDEenv(setup, B=B, dtype=F64)
