@@ -484,6 +484,9 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
   preal[((size_t)b * n + j) * n + i] = acc;
 }
 
+#ifndef FL_K2_TC
+#define FL_K2_TC 4
+#endif
 // ------------------------------------------------------------------ wave-FFT variants of K1 / K2 / K3
 // Same three passes, but every line transform runs in the registers of ONE wave (wave_fft.hpp): no LDS stage
 // round trips, no barriers inside a transform.  LDS is only used to turn coalesced global accesses into the
@@ -538,16 +541,18 @@ __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, cons
   }
 }
 
-// K2w: 8 columns per workgroup, one wave per column.  LDS: the [8][p] column tile (transposition + permuted access).
-template <int E, int Q>
-__global__ __launch_bounds__(512) void fluid_k2w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W,
-                                                        C2<double>* __restrict__ W2) {
+// K2w: TC columns per workgroup, one wave per column.  LDS: the [TC][p] column tile (transposition + permuted access).
+// TC = 4 keeps the tile at 48 KB so that several workgroups share a CU and one's global loads / stores overlap the
+// others' transforms (with TC = 8 a CU holds a single workgroup and load -> transform -> store serialise).
+template <int E, int Q, int TC>
+__global__ __launch_bounds__(64 * TC) void fluid_k2w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W,
+                                                            C2<double>* __restrict__ W2) {
   typedef WaveFftD<E, Q> F;
   typedef C2<double> Z;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   Z* tile = reinterpret_cast<Z*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = d.n, p = d.p, LS = p + 1;
-  const int ip0 = blockIdx.x * 8, b = blockIdx.y;
+  const int ip0 = blockIdx.x * TC, b = blockIdx.y;
   F f;
   f.init(d.twp, lane);
   Z r0[F::R], a[F::R];
@@ -555,8 +560,8 @@ __global__ __launch_bounds__(512) void fluid_k2w_kernel(FluidDev<double> d, cons
   for (int fld = 0; fld < 2; ++fld) {
     if (fld) __syncthreads();
     const Z* Wf = W + (((size_t)b * 2 + fld) * d.nl) * p;
-    for (int idx = tid; idx < 8 * p; idx += 512) {          // transposed load, zero fill = pad() along x
-      const int t = idx & 7, jp = idx >> 3;
+    for (int idx = tid; idx < TC * p; idx += 64 * TC) {      // transposed load, zero fill = pad() along x
+      const int t = idx % TC, jp = idx / TC;
       const int s = fl_line_of(jp, n, p, d.nl), ip = ip0 + t;
       Z v = mk<double>(0, 0);
       if (s >= 0 && ip < p) v = Wf[(size_t)s * p + ip];
@@ -579,8 +584,8 @@ __global__ __launch_bounds__(512) void fluid_k2w_kernel(FluidDev<double> d, cons
 #pragma unroll
   for (int jj = 0; jj < F::R; ++jj) tile[wv * LS + f.mode_index(jj)] = a[jj];
   __syncthreads();
-  for (int idx = tid; idx < 8 * n; idx += 512) {            // chop() along x + coalesced store
-    const int t = idx & 7, jj = idx >> 3, ip = ip0 + t;
+  for (int idx = tid; idx < TC * n; idx += 64 * TC) {        // chop() along x + coalesced store
+    const int t = idx % TC, jj = idx / TC, ip = ip0 + t;
     if (ip < p) W2[((size_t)b * n + jj) * p + ip] = tile[t * LS + fl_pad(jj, n, p)];
   }
 }
@@ -718,7 +723,7 @@ static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const 
   static bool attr = false;
   if (!attr) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k1w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k2w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k2w_kernel<E, Q, FL_K2_TC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k3w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
@@ -731,8 +736,8 @@ static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const 
   {
     ProfScope ps(&Ev, "fluid_k2", true);
     for (int r = 0; r < ps.reps; ++r)
-      hipLaunchKernelGGL((fluid_k2w_kernel<E, Q>), dim3((p + 7) / 8, B), dim3(512), (size_t)8 * (p + 1) * 16, Ev.stream, d,
-                         Ev.W.as<Z>(), Ev.W2.as<Z>());
+      hipLaunchKernelGGL((fluid_k2w_kernel<E, Q, FL_K2_TC>), dim3((p + FL_K2_TC - 1) / FL_K2_TC, B), dim3(64 * FL_K2_TC),
+                         (size_t)FL_K2_TC * (p + 1) * 16, Ev.stream, d, Ev.W.as<Z>(), Ev.W2.as<Z>());
   }
   {
     ProfScope ps(&Ev, "fluid_k3", mode == 0);
