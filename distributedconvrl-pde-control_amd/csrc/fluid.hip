@@ -556,26 +556,35 @@ __global__ __launch_bounds__(64 * TC) void fluid_k2w_kernel(FluidDev<double> d, 
   F f;
   f.init(d.twp, lane);
   Z r0[F::R], a[F::R];
-#pragma unroll 1
-  for (int fld = 0; fld < 2; ++fld) {
-    if (fld) __syncthreads();
-    const Z* Wf = W + (((size_t)b * 2 + fld) * d.nl) * p;
-    for (int idx = tid; idx < TC * p; idx += 64 * TC) {      // transposed load, zero fill = pad() along x
-      const int t = idx % TC, jp = idx / TC;
-      const int s = fl_line_of(jp, n, p, d.nl), ip = ip0 + t;
-      Z v = mk<double>(0, 0);
-      if (s >= 0 && ip < p) v = Wf[(size_t)s * p + ip];
-      tile[t * LS + jp] = v;
-    }
-    __syncthreads();
+  // tile element (t, jp) of a field: W[fld][s(jp)][ip0 + t] or 0 (pad() along x); thread-strided over the TC x p tile
+  constexpr int NPF = (F::N + 63) / 64;                     // elements per thread (TC * p / (64 TC))
+  auto tile_src = [&](int fld, int idx) -> Z {
+    const int t = idx % TC, jp = idx / TC;
+    const int s = fl_line_of(jp, n, p, d.nl), ip = ip0 + t;
+    if (s >= 0 && ip < p) return W[(((size_t)b * 2 + fld) * d.nl + s) * p + ip];
+    return mk<double>(0, 0);
+  };
+  for (int idx = tid; idx < TC * p; idx += 64 * TC) tile[(idx % TC) * LS + idx / TC] = tile_src(0, idx);
+  Z pre[NPF];                                               // field 1 is fetched while field 0 is transformed
 #pragma unroll
-    for (int jj = 0; jj < F::R; ++jj) a[jj] = tile[wv * LS + f.mode_index(jj)];
-    f.inverse(a);
-    if (fld == 0) {
-#pragma unroll
-      for (int jj = 0; jj < F::R; ++jj) r0[jj] = a[jj];
-    }
+  for (int u = 0; u < NPF; ++u) {
+    const int idx = tid + u * 64 * TC;
+    pre[u] = idx < TC * p ? tile_src(1, idx) : mk<double>(0, 0);
   }
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < F::R; ++jj) r0[jj] = tile[wv * LS + f.mode_index(jj)];
+  f.inverse(r0);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NPF; ++u) {
+    const int idx = tid + u * 64 * TC;
+    if (idx < TC * p) tile[(idx % TC) * LS + idx / TC] = pre[u];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int jj = 0; jj < F::R; ++jj) a[jj] = tile[wv * LS + f.mode_index(jj)];
+  f.inverse(a);
   // -(u wx + v wy), both ifft scalings; forward transform of the real product (one column per wave)
 #pragma unroll
   for (int jj = 0; jj < F::R; ++jj) a[jj] = mk<double>(-(r0[jj].x * a[jj].x + r0[jj].y * a[jj].y) * d.inv2, 0.0);
