@@ -5,7 +5,7 @@ include/pdeconv.h); this package is the host-side mirror of the reference's inte
 Import as:  pkg = importlib.import_module("distributedconvrl-pde-control_amd")"""
 from . import _lib  # noqa: F401
 from ._lib import PdecError  # noqa: F401
-from .setups import KSSetup, KellerSegelSetup, FluidSetup  # noqa: F401
+from .setups import KSSetup, KellerSegelSetup, KellerSegel2DSetup, FluidSetup  # noqa: F401
 from .env import PDEenv  # noqa: F401
 from .nna import (HipMLP, ADAM, CustomNeuralNetworkApproximator, create_NNA, create_chain,  # noqa: F401
                   glorot_uniform, layer_spec)

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpdeconv.so")
 
 PDEC_F32, PDEC_F64 = 0, 1
-PDE_KS_CNAB2, PDE_KSEG_RK4, PDE_KS_RK4_FD, PDE_FLUID_RK4 = 0, 1, 2, 3
+PDE_KS_CNAB2, PDE_KSEG_RK4, PDE_KS_RK4_FD, PDE_FLUID_RK4, PDE_KSEG2D_RK4 = 0, 1, 2, 3, 4
 ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
 
 Handle = C.c_uint64
@@ -30,6 +30,7 @@ class EnvCfg(C.Structure):
         ("reward_offset", C.c_double), ("reward_power", C.c_double), ("reward_denom", C.c_double),
         ("action_punish", C.c_double), ("delta_action_punish", C.c_double),
         ("ifpad", C.c_int), ("sensors_per_axis", C.c_int), ("nu", C.c_double),
+        ("Ny", C.c_int),
     ]
 
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     "pdec_prof_get": [Handle, C.c_char_p, _pd, C.POINTER(_i)],
     "pdec_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _pd, _pd, _pi32],
     "pdec_fluid_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _pd, _pi32, _pd, _pi32, _pi32],
+    "pdec_kseg2d_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _i, _pi32, _pi32, _i, _pi32],
     "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],

@@ -1202,6 +1202,7 @@ int pdec_actuate(pdec_handle h, const void* action, void* p_out) {
   GET_ENV(E, h);
   PDEC_REQUIRE(action && p_out, "pdec_actuate: null");
   if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_actuate(*E, action, p_out);
+  if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4) return kseg2d_actuate(*E, action, p_out);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 0, nullptr, action, nullptr, nullptr, p_out)
                                   : launch_sense<float>(*E, 0, nullptr, action, nullptr, nullptr, p_out);
 }
@@ -1211,6 +1212,7 @@ int pdec_featurize(pdec_handle h, const void* y, const void* prev_state, void* s
   PDEC_REQUIRE(y && state_out, "pdec_featurize: null");
   PDEC_REQUIRE(prev_state != state_out, "pdec_featurize: state_out must not alias prev_state");
   if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_featurize(*E, y, prev_state, state_out);
+  if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4) return kseg2d_featurize(*E, y, prev_state, state_out);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 1, y, nullptr, nullptr, prev_state, state_out)
                                   : launch_sense<float>(*E, 1, y, nullptr, nullptr, prev_state, state_out);
 }
@@ -1219,6 +1221,7 @@ int pdec_reward(pdec_handle h, const void* y, const void* action, const void* ac
   GET_ENV(E, h);
   PDEC_REQUIRE(y && action && action_prev && r_out, "pdec_reward: null");
   if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_reward(*E, y, action, action_prev, r_out);
+  if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4) return kseg2d_reward(*E, y, action, action_prev, r_out);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 2, y, action, action_prev, nullptr, r_out)
                                   : launch_sense<float>(*E, 2, y, action, action_prev, nullptr, r_out);
 }
@@ -1227,6 +1230,7 @@ int pdec_pde_step(pdec_handle h, const void* y_in, const void* p, void* y_out, i
   GET_ENV(E, h);
   PDEC_REQUIRE(y_in && p && y_out, "pdec_pde_step: null");
   if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_pde_step(*E, y_in, p, y_out, done);
+  if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4) return kseg2d_pde_step(*E, y_in, p, y_out, done);
   return E->cfg.dtype == PDEC_F64
              ? launch_step<double>(*E, false, 1, y_in, p, nullptr, nullptr, nullptr, y_out, nullptr, nullptr, nullptr, done)
              : launch_step<float>(*E, false, 1, y_in, p, nullptr, nullptr, nullptr, y_out, nullptr, nullptr, nullptr, done);
@@ -1236,6 +1240,7 @@ int pdec_rhs_eval(pdec_handle h, const void* y, const void* p, void* out) {
   GET_ENV(E, h);
   PDEC_REQUIRE(y && p && out, "pdec_rhs_eval: null");
   if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_rhs_eval(*E, y, p, out);
+  if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4) return kseg2d_rhs_eval(*E, y, p, out);
   PDEC_REQUIRE(E->cfg.pde_kind == PDEC_PDE_KSEG_RK4 || E->cfg.pde_kind == PDEC_PDE_KS_RK4_FD,
                "pdec_rhs_eval: only RK4-type PDE kinds expose an RHS");
   return E->cfg.dtype == PDEC_F64
@@ -1252,6 +1257,8 @@ int pdec_env_step(pdec_handle h, const void* y_in, const void* action, const voi
                "pdec_env_step: state_out must not alias state_prev when temporal_steps > 1");
   if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4)
     return fluid_env_step(*E, y_in, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
+  if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4)
+    return kseg2d_env_step(*E, y_in, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
   return E->cfg.dtype == PDEC_F64
              ? launch_step<double>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done)
              : launch_step<float>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
@@ -1267,10 +1274,8 @@ int pdec_pde_step_host(pdec_handle h, const void* y_in, const void* p, void* y_o
   GET_ENV(E, h);
   PDEC_REQUIRE(y_in && p && y_out, "pdec_pde_step_host: null");
   const pdec_env_cfg& c = E->cfg;
-  const bool fl = c.pde_kind == PDEC_PDE_FLUID_RK4;   // fluid: y and p are complex [N][N] spectra
   const size_t ts = dtype_size(c.dtype);
-  const size_t ny = fl ? (size_t)c.B * c.N * c.N * 2 * ts : (size_t)c.B * c.n_species * c.N * ts;
-  const size_t np = fl ? ny : (size_t)c.B * c.N * ts;
+  const size_t ny = (size_t)c.B * env_y_count(c) * ts, np = (size_t)c.B * env_p_count(c) * ts;
   int rc = env_stage(E, 2 * ny + np + c.B * sizeof(int32_t) + 64);
   if (rc) return rc;
   char* base = E->stage.as<char>();
@@ -1292,10 +1297,8 @@ int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, cons
   PDEC_REQUIRE(y_in && action && action_prev && y_out && state_out && reward_out, "pdec_env_step_host: null");
   const pdec_env_cfg& c = E->cfg;
   const size_t ts = dtype_size(c.dtype);
-  const bool fl = c.pde_kind == PDEC_PDE_FLUID_RK4;
-  const int ns = c.mono ? c.S : (fl ? c.window * c.window : c.window * c.n_species) * c.temporal_steps;
-  const size_t ny = fl ? (size_t)c.B * c.N * c.N * 2 * ts : (size_t)c.B * c.n_species * c.N * ts;
-  const size_t np = fl ? ny : (size_t)c.B * c.N * ts, na = (size_t)c.B * c.A * ts;
+  const int ns = env_ns(c);
+  const size_t ny = (size_t)c.B * env_y_count(c) * ts, np = (size_t)c.B * env_p_count(c) * ts, na = (size_t)c.B * c.A * ts;
   const size_t nst = (size_t)c.B * (c.mono ? c.S : c.A * ns) * ts, nr = (size_t)c.B * (c.mono ? 1 : c.A) * ts;
   auto al = [](size_t x) { return (x + 63) / 64 * 64; };
   int rc = env_stage(E, 2 * al(ny) + al(np) + 2 * al(na) + 2 * al(nst) + al(nr) + al(c.B * sizeof(int32_t)));

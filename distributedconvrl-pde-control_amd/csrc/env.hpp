@@ -51,4 +51,31 @@ int fluid_actuate(Env& E, const void* action, void* p_out);
 int fluid_featurize(Env& E, const void* y, const void* state_prev, void* state_out);
 int fluid_reward(Env& E, const void* y, const void* action, const void* action_prev, void* r_out);
 
+// kseg2d.hip: Keller-Segel on a 2-D grid (BASELINE.json configs[3]; the reference's 1-D rules along both axes)
+int kseg2d_env_step(Env& E, const void* y_in, const void* action, const void* action_prev, const void* state_prev,
+                    void* y_out, void* p_out, void* state_out, void* reward_out, int32_t* done);
+int kseg2d_pde_step(Env& E, const void* y_in, const void* p, void* y_out, int32_t* done);
+int kseg2d_rhs_eval(Env& E, const void* y, const void* p, void* out);
+int kseg2d_actuate(Env& E, const void* action, void* p_out);
+int kseg2d_featurize(Env& E, const void* y, const void* state_prev, void* state_out);
+int kseg2d_reward(Env& E, const void* y, const void* action, const void* action_prev, void* r_out);
+
+// element counts per trajectory of the arrays that cross the C ABI
+inline size_t env_y_count(const pdec_env_cfg& c) {
+  if (c.pde_kind == PDEC_PDE_FLUID_RK4) return (size_t)c.N * c.N * 2;
+  if (c.pde_kind == PDEC_PDE_KSEG2D_RK4) return (size_t)c.N * c.Ny * 2;
+  return (size_t)c.n_species * c.N;
+}
+inline size_t env_p_count(const pdec_env_cfg& c) {
+  if (c.pde_kind == PDEC_PDE_FLUID_RK4) return (size_t)c.N * c.N * 2;
+  if (c.pde_kind == PDEC_PDE_KSEG2D_RK4) return (size_t)c.N * c.Ny;
+  return (size_t)c.N;
+}
+inline int env_ns(const pdec_env_cfg& c) {
+  if (c.mono) return c.S;
+  if (c.pde_kind == PDEC_PDE_FLUID_RK4) return c.window * c.window * c.temporal_steps;
+  if (c.pde_kind == PDEC_PDE_KSEG2D_RK4) return 2 * c.window * c.window * c.temporal_steps;
+  return c.window * c.n_species * c.temporal_steps;
+}
+
 }  // namespace pdec

@@ -1,0 +1,461 @@
+// kseg2d.hip -- Keller-Segel on a 2-D ny x nx grid (BASELINE.json configs[3]).
+//
+// The reference's Keller-Segel is 1-D (scripts/Keller-Segel/setup/KellerSegelSetup.jl); the 2-D extension keeps each
+// of its rules along both axes (stated and pinned in oracle/keller_segel2d.py):
+//   RHS  :213-232  v' = Lap v - v + u + p;  u' = Lap u + u - 5.6 grad u . grad v - 5.6 u Lap v - u^2, central
+//                  differences (:63-64 weights along x and along y), zero-flux edges by ghost = edge cell (:220-223)
+//   step :234-239  classical RK4 (src/fluid_rk4.jl:122-132 tableau), K fixed sub-steps, forcing frozen
+//   sensing :112-126, :241-316, prepare_action :318-332 with 5x5 boxes of ones on a tensor grid of positions
+//
+// Data layout in HBM: y [B][ny][nx][2] (u,v interleaved: one 8/16-byte load gives both species of a cell; x is the
+// fast axis), p [B][ny][nx], state [B][A][ns], reward/action [B][A].
+//
+// The integrator is HBM-bound if every RK4 stage goes through memory (4 stages x (read 3 + write 2) fields).  Here
+// one launch advances a 64x64 tile by NSUB whole RK4 sub-steps out of LDS: the tile is loaded with a halo of 4*NSUB
+// cells (each stage consumes one ring of the halo), y0 / the running sum / the stage value of a thread's cells stay in
+// registers, and only the stage value is exchanged through LDS.  Each thread owns strips of 4 consecutive cells of a
+// row: the west/east neighbours inside a strip come from registers, the north/south rows are 128-bit LDS reads.
+// HBM traffic per sub-step: (1 + 2H/64)^2 reads + 1 write of the tile instead of 4 x (5 fields).
+#include "env.hpp"
+
+namespace pdec {
+
+constexpr int K2_TX = 64, K2_TY = 64, K2_NT = 512;
+
+template <class T>
+struct K2Dev {
+  int B, nx, ny, K, Sx, Sy, S, A, hw, ns, window, temporal, check_max;
+  T idx, idx2, hstep, sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
+  const int* sx;        // [Sx] 0-based centre columns
+  const int* sy;        // [Sy] 0-based centre rows
+  const int* a2s;       // [A]
+  const int* cell_act;  // [ny][nx] actuator whose box covers the cell, -1 = none (boxes do not overlap)
+  T* term_out;          // optional [B][A]
+};
+
+template <class T>
+struct alignas(16) Quad {   // four consecutive cells of a row (u,v pairs)
+  C2<T> c[4];
+};
+template <class T>
+struct alignas(16) Quad1 {  // four consecutive scalars
+  T c[4];
+};
+
+template <class T>
+__device__ __forceinline__ T k2_pow_abs(T d, T pw) {
+  const T a = fabs(d);
+  if (pw == (T)2) return a * a;
+  if (pw == (T)1) return a;
+  return pow(a, pw);
+}
+
+// one cell of the right-hand side (same expression forms as the 1-D kernel kseg_rhs in env.hip)
+template <class T>
+__device__ __forceinline__ C2<T> k2_rhs_cell(const K2Dev<T>& e, C2<T> c, C2<T> w, C2<T> ea, C2<T> s, C2<T> n, T p) {
+  const T ux = (T)0.5 * e.idx * (ea.x - w.x), uy = (T)0.5 * e.idx * (n.x - s.x);
+  const T vx = (T)0.5 * e.idx * (ea.y - w.y), vy = (T)0.5 * e.idx * (n.y - s.y);
+  const T lu = (e.idx2 * w.x - (T)2 * e.idx2 * c.x + e.idx2 * ea.x) + (e.idx2 * s.x - (T)2 * e.idx2 * c.x + e.idx2 * n.x);
+  const T lv = (e.idx2 * w.y - (T)2 * e.idx2 * c.y + e.idx2 * ea.y) + (e.idx2 * s.y - (T)2 * e.idx2 * c.y + e.idx2 * n.y);
+  C2<T> k;
+  k.y = lv - c.y + c.x + p;
+  k.x = lu + c.x - (T)5.6 * ux * vx - (T)5.6 * uy * vy - (T)5.6 * c.x * lv - c.x * c.x;
+  return k;
+}
+
+// MODE 0: integrate NSUB sub-steps, 1: right-hand side only (KATs)
+template <class T, int NSUB, int MODE>
+__global__ __launch_bounds__(K2_NT) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<T>* __restrict__ y_in,
+                                                           const T* __restrict__ p_in, C2<T>* __restrict__ y_out,
+                                                           int32_t* __restrict__ done, int last) {
+  constexpr int H = 4 * NSUB, RX = K2_TX + 2 * H, RY = K2_TY + 2 * H, SW = RX / 4, NSTRIP = SW * RY;
+  constexpr int NS = (NSTRIP + K2_NT - 1) / K2_NT, RXP = RX + 2;
+  extern __shared__ __align__(16) unsigned char k2_smem[];
+  C2<T>* S = reinterpret_cast<C2<T>*>(k2_smem);   // [RY][RXP] stage values
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int gx0 = blockIdx.x * K2_TX - H, gy0 = blockIdx.y * K2_TY - H;
+  // part of the region that lies inside the domain (local coordinates); neighbour indices clamp to it, which IS
+  // the zero-flux rule on a domain edge and only feeds halo cells (never used) on an inner tile edge
+  const int lox = max(0, -gx0), hix = min(RX, e.nx - gx0) - 1;
+  const int loy = max(0, -gy0), hiy = min(RY, e.ny - gy0) - 1;
+  const size_t fo = (size_t)b * e.ny * e.nx;
+
+  C2<T> y0[NS][4], acc[NS][4], cur[NS][4];
+  T pp[NS][4];
+  int sr[NS], sc[NS];
+  bool act[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int id = tid + k * K2_NT;
+    sr[k] = id / SW;
+    sc[k] = 4 * (id - sr[k] * SW);
+    act[k] = id < NSTRIP && sr[k] >= loy && sr[k] <= hiy && sc[k] >= lox && sc[k] <= hix;
+    if (act[k]) {
+      const size_t g = fo + (size_t)(gy0 + sr[k]) * e.nx + (gx0 + sc[k]);
+      const Quad<T> q = *reinterpret_cast<const Quad<T>*>(y_in + g);
+      const Quad1<T> qp = *reinterpret_cast<const Quad1<T>*>(p_in + g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { y0[k][i] = q.c[i]; cur[k][i] = q.c[i]; pp[k][i] = qp.c[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { y0[k][i] = mk<T>(0, 0); cur[k][i] = mk<T>(0, 0); pp[k][i] = 0; }
+    }
+  }
+  const T h = e.hstep;
+  for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+      // publish the stage values
+      if (sub + stage > 0) __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
+        if (act[k]) {
+          Quad<T> q;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q.c[i] = cur[k][i];
+          *reinterpret_cast<Quad<T>*>(S + sr[k] * RXP + sc[k]) = q;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        if (!act[k]) continue;
+        const int r = sr[k], c0 = sc[k];
+        const C2<T> W = S[r * RXP + max(c0 - 1, lox)], E = S[r * RXP + min(c0 + 4, hix)];
+        const Quad<T> qs = *reinterpret_cast<const Quad<T>*>(S + max(r - 1, loy) * RXP + c0);
+        const Quad<T> qn = *reinterpret_cast<const Quad<T>*>(S + min(r + 1, hiy) * RXP + c0);
+        C2<T> kk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          kk[i] = k2_rhs_cell<T>(e, cur[k][i], i == 0 ? W : cur[k][i - 1], i == 3 ? E : cur[k][i + 1], qs.c[i], qn.c[i],
+                                 pp[k][i]);
+        if (MODE == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y0[k][i] = kk[i];
+          continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (stage == 0) {
+            acc[k][i] = kk[i];
+            cur[k][i] = mk<T>(y0[k][i].x + (T)0.5 * h * kk[i].x, y0[k][i].y + (T)0.5 * h * kk[i].y);
+          } else if (stage == 1) {
+            acc[k][i] = mk<T>(acc[k][i].x + (T)2 * kk[i].x, acc[k][i].y + (T)2 * kk[i].y);
+            cur[k][i] = mk<T>(y0[k][i].x + (T)0.5 * h * kk[i].x, y0[k][i].y + (T)0.5 * h * kk[i].y);
+          } else if (stage == 2) {
+            acc[k][i] = mk<T>(acc[k][i].x + (T)2 * kk[i].x, acc[k][i].y + (T)2 * kk[i].y);
+            cur[k][i] = mk<T>(y0[k][i].x + h * kk[i].x, y0[k][i].y + h * kk[i].y);
+          } else {
+            y0[k][i] = mk<T>(y0[k][i].x + h / (T)6 * (acc[k][i].x + kk[i].x), y0[k][i].y + h / (T)6 * (acc[k][i].y + kk[i].y));
+            cur[k][i] = y0[k][i];
+          }
+        }
+      }
+      if (MODE == 1) break;
+    }
+    if (MODE == 1) break;
+  }
+  // interior of the tile -> HBM
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    if (!act[k] || sr[k] < H || sr[k] >= H + K2_TY || sc[k] < H || sc[k] >= H + K2_TX) continue;
+    const size_t g = fo + (size_t)(gy0 + sr[k]) * e.nx + (gx0 + sc[k]);
+    Quad<T> q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      q.c[i] = y0[k][i];
+      // blow-up test max|y| > max_value (src/PDEenv.jl:227); NaN also raises the flag (as in the 1-D kernels)
+      bad |= !(fabs(y0[k][i].x) <= e.max_value && fabs(y0[k][i].y) <= e.max_value);
+    }
+    *reinterpret_cast<Quad<T>*>(y_out + g) = q;
+  }
+  if (MODE == 0 && last && done && e.check_max == 1) {
+    if (__any(bad) && (tid & 63) == 0) atomicOr(done + b, 1);
+  }
+}
+
+// p = sum_i agent_power * action[i] * box_i   (KellerSegelSetup.jl:318-332; boxes do not overlap)
+template <class T>
+__global__ void kseg2d_actuate_kernel(K2Dev<T> e, const T* __restrict__ action, T* __restrict__ p) {
+  const size_t cells = (size_t)e.ny * e.nx, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cells * e.B) return;
+  const size_t b = i / cells, c = i - b * cells;
+  const int a = e.cell_act[c];
+  p[i] = a >= 0 ? e.agent_power * action[b * e.A + a] : (T)0;
+}
+
+// box sums of u and v for every sensor: sums [B][2][S]
+template <class T>
+__global__ void kseg2d_boxsum_kernel(K2Dev<T> e, const C2<T>* __restrict__ y, T* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= e.B * e.S) return;
+  const int b = i / e.S, s = i - b * e.S, iy = s / e.Sx, ix = s - iy * e.Sx;
+  const int cy = e.sy[iy], cx = e.sx[ix];
+  const int r0 = max(cy - e.hw, 0), r1 = min(cy + e.hw, e.ny - 1), c0 = max(cx - e.hw, 0), c1 = min(cx + e.hw, e.nx - 1);
+  T su = 0, sv = 0;
+  const C2<T>* yb = y + (size_t)b * e.ny * e.nx;
+  for (int r = r0; r <= r1; ++r)
+    for (int c = c0; c <= c1; ++c) {
+      const C2<T> v = yb[(size_t)r * e.nx + c];
+      su += v.x;
+      sv += v.y;
+    }
+  sums[((size_t)b * 2 + 0) * e.S + s] = su;
+  sums[((size_t)b * 2 + 1) * e.S + s] = sv;
+}
+
+// reward (KellerSegelSetup.jl:241-257) and featurize (:265-316, 3x3 circular window in the
+// scripts/Fluid/setup/FluidSetup.jl:219-223 shift order) for column (b, a)
+template <class T>
+__global__ void kseg2d_feat_kernel(K2Dev<T> e, const T* __restrict__ sums, const T* __restrict__ action,
+                                   const T* __restrict__ action_prev, const T* __restrict__ state_prev,
+                                   T* __restrict__ state_out, T* __restrict__ reward_out, int32_t* __restrict__ done) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= e.B * e.A) return;
+  const int b = i / e.A, a = i - b * e.A, s = e.a2s[a], iy = s / e.Sx, ix = s - iy * e.Sx;
+  const T* sb = sums + (size_t)b * 2 * e.S;
+  if (reward_out) {
+    const int cy = e.sy[iy], cx = e.sx[ix];
+    const int nr = min(cy + e.hw, e.ny - 1) - max(cy - e.hw, 0) + 1, nc = min(cx + e.hw, e.nx - 1) - max(cx - e.hw, 0) + 1;
+    const T d = e.r_in_scale * (sb[s] + e.r_offset * (T)(nr * nc));
+    const T av = action[i], da = av - action_prev[i];
+    const T r = -k2_pow_abs<T>(d, e.r_power) / e.r_denom - e.a_pun * av * av - e.da_pun * da * da;
+    reward_out[i] = r;
+    if (done && e.check_max == 2 && !(fabs(r) <= e.max_value)) atomicOr(done + b, 1);
+  }
+  if (state_out) {
+    const int w = e.window / 2, fresh = 2 * e.window * e.window;
+    T* so = state_out + (size_t)i * e.ns;
+    for (int rr = 0; rr < e.ns; ++rr) {
+      T v;
+      if (rr < fresh || state_prev == nullptr) {
+        const int r0 = rr % fresh, sp = r0 / (e.window * e.window), q = r0 - sp * e.window * e.window;
+        const int di = q / e.window - w, dj = q - (q / e.window) * e.window - w;
+        // circshift(sensors, [di, dj])[iy, ix] = sensors[iy - di, ix - dj]
+        int jy = (iy - di) % e.Sy, jx = (ix - dj) % e.Sx;
+        if (jy < 0) jy += e.Sy;
+        if (jx < 0) jx += e.Sx;
+        v = sb[(size_t)sp * e.S + jy * e.Sx + jx] * e.sensor_scale;
+      } else {
+        v = state_prev[(size_t)i * e.ns + (rr - fresh)];
+      }
+      so[rr] = v;
+    }
+  }
+}
+
+// per-column terminal flags for the DDPG batch (runs after every kernel that may raise done[b])
+template <class T>
+__global__ void kseg2d_terminal_kernel(K2Dev<T> e, const int32_t* __restrict__ done) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= e.B * e.A) return;
+  e.term_out[i] = done[i / e.A] ? (T)1 : (T)0;
+}
+
+struct Kseg2dEnv : Env {
+  int nx = 0, ny = 0, Sx = 0, Sy = 0, hw = 0, nsub = 1;
+  DevBuf sx, sy, a2s_d, cell_act, sums, pbuf, ytmp, done_tmp;
+  size_t lds1 = 0, lds2 = 0;
+};
+
+static Kseg2dEnv& as_k2(Env& E) { return static_cast<Kseg2dEnv&>(E); }
+
+template <class T>
+static K2Dev<T> k2_dev(const Kseg2dEnv& E) {
+  const pdec_env_cfg& c = E.cfg;
+  K2Dev<T> d;
+  d.B = c.B; d.nx = E.nx; d.ny = E.ny; d.K = c.K; d.Sx = E.Sx; d.Sy = E.Sy; d.S = c.S; d.A = c.A; d.hw = E.hw;
+  d.window = c.window; d.temporal = c.temporal_steps; d.ns = 2 * c.window * c.window * c.temporal_steps;
+  d.check_max = c.check_max_value;
+  const double dx = c.Lx / E.nx;
+  d.idx = (T)(1.0 / dx); d.idx2 = (T)(1.0 / (dx * dx)); d.hstep = (T)(c.dt / c.K);
+  d.sensor_scale = (T)c.sensor_scale; d.agent_power = (T)c.agent_power; d.r_in_scale = (T)c.reward_in_scale;
+  d.r_offset = (T)c.reward_offset; d.r_power = (T)c.reward_power; d.r_denom = (T)c.reward_denom;
+  d.a_pun = (T)c.action_punish; d.da_pun = (T)c.delta_action_punish; d.max_value = (T)c.max_value;
+  d.sx = E.sx.as<int>(); d.sy = E.sy.as<int>(); d.a2s = E.a2s_d.as<int>(); d.cell_act = E.cell_act.as<int>();
+  d.term_out = (T*)E.term_out;
+  return d;
+}
+
+template <int NSUB>
+static constexpr size_t k2_lds(size_t pair_bytes) {
+  return (size_t)(K2_TY + 8 * NSUB) * (K2_TX + 8 * NSUB + 2) * pair_bytes;
+}
+
+template <class T, int NSUB, int MODE>
+static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_out, int32_t* done, int last) {
+  const dim3 grid((E.nx + K2_TX - 1) / K2_TX, (E.ny + K2_TY - 1) / K2_TY, E.cfg.B);
+  hipLaunchKernelGGL((kseg2d_rk4_kernel<T, NSUB, MODE>), grid, dim3(K2_NT), k2_lds<NSUB>(2 * sizeof(T)), E.stream, k2_dev<T>(E),
+                     (const C2<T>*)y_in, (const T*)p, (C2<T>*)y_out, done, last);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+template <class T>
+static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, void* y_out, int32_t* done) {
+  // K sub-steps, ping-pong between y_out and the scratch field so that the last launch writes y_out
+  const int K = E.cfg.K, ns = E.nsub;
+  const int launches = (K + ns - 1) / ns;
+  const size_t bytes = (size_t)E.cfg.B * E.ny * E.nx * 2 * sizeof(T);
+  if (launches > 1 && E.ytmp.bytes < bytes) PDEC_HIP(E.ytmp.alloc(bytes));
+  if (done) PDEC_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * E.cfg.B, E.stream));
+  ProfScope ps(&E, "kseg2d_rk4");
+  const void* src = y_in;
+  int left = K;
+  for (int l = 0; l < launches; ++l) {
+    void* dst = ((launches - 1 - l) & 1) ? E.ytmp.p : y_out;
+    const int last = l == launches - 1;
+    int rc;
+    if constexpr (sizeof(T) == 4) {
+      if (left >= 2 && ns == 2) { rc = k2_launch_rk4<T, 2, 0>(E, src, p, dst, done, last); left -= 2; }
+      else { rc = k2_launch_rk4<T, 1, 0>(E, src, p, dst, done, last); left -= 1; }
+    } else {
+      rc = k2_launch_rk4<T, 1, 0>(E, src, p, dst, done, last); left -= 1;
+    }
+    if (rc) return rc;
+    src = dst;
+  }
+  return PDEC_OK;
+}
+
+template <class T>
+static int k2_actuate(Kseg2dEnv& E, const void* action, void* p_out) {
+  const size_t n = (size_t)E.cfg.B * E.ny * E.nx;
+  hipLaunchKernelGGL(kseg2d_actuate_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, E.stream, k2_dev<T>(E),
+                     (const T*)action, (T*)p_out);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+template <class T>
+static int k2_sense(Kseg2dEnv& E, const void* y, const void* action, const void* action_prev, const void* state_prev,
+                    void* state_out, void* reward_out, int32_t* done) {
+  const size_t need = (size_t)E.cfg.B * 2 * E.cfg.S * sizeof(T);
+  if (E.sums.bytes < need) PDEC_HIP(E.sums.alloc(need));
+  const int nS = E.cfg.B * E.cfg.S, nA = E.cfg.B * E.cfg.A;
+  hipLaunchKernelGGL(kseg2d_boxsum_kernel<T>, dim3((nS + 127) / 128), dim3(128), 0, E.stream, k2_dev<T>(E), (const C2<T>*)y,
+                     E.sums.as<T>());
+  PDEC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(kseg2d_feat_kernel<T>, dim3((nA + 127) / 128), dim3(128), 0, E.stream, k2_dev<T>(E), E.sums.as<T>(),
+                     (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)state_out, (T*)reward_out, done);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+#define K2_DISPATCH(fn, ...) (E.cfg.dtype == PDEC_F64 ? fn<double>(E, __VA_ARGS__) : fn<float>(E, __VA_ARGS__))
+
+int kseg2d_actuate(Env& E0, const void* action, void* p_out) {
+  Kseg2dEnv& E = as_k2(E0);
+  return K2_DISPATCH(k2_actuate, action, p_out);
+}
+
+int kseg2d_featurize(Env& E0, const void* y, const void* state_prev, void* state_out) {
+  Kseg2dEnv& E = as_k2(E0);
+  return K2_DISPATCH(k2_sense, y, nullptr, nullptr, state_prev, state_out, nullptr, nullptr);
+}
+
+int kseg2d_reward(Env& E0, const void* y, const void* action, const void* action_prev, void* r_out) {
+  Kseg2dEnv& E = as_k2(E0);
+  return K2_DISPATCH(k2_sense, y, action, action_prev, nullptr, nullptr, r_out, nullptr);
+}
+
+int kseg2d_rhs_eval(Env& E0, const void* y, const void* p, void* out) {
+  Kseg2dEnv& E = as_k2(E0);
+  return E.cfg.dtype == PDEC_F64 ? k2_launch_rk4<double, 1, 1>(E, y, p, out, nullptr, 0)
+                                 : k2_launch_rk4<float, 1, 1>(E, y, p, out, nullptr, 0);
+}
+
+int kseg2d_pde_step(Env& E0, const void* y_in, const void* p, void* y_out, int32_t* done) {
+  Kseg2dEnv& E = as_k2(E0);
+  PDEC_REQUIRE(y_in != y_out, "kseg2d: y_out must not alias y_in");
+  return K2_DISPATCH(k2_integrate, y_in, p, y_out, done);
+}
+
+int kseg2d_env_step(Env& E0, const void* y_in, const void* action, const void* action_prev, const void* state_prev,
+                    void* y_out, void* p_out, void* state_out, void* reward_out, int32_t* done) {
+  Kseg2dEnv& E = as_k2(E0);
+  const size_t ts = dtype_size(E.cfg.dtype);
+  void* ph = p_out;
+  if (!ph) {
+    const size_t need = (size_t)E.cfg.B * E.ny * E.nx * ts;
+    if (E.pbuf.bytes < need) PDEC_HIP(E.pbuf.alloc(need));
+    ph = E.pbuf.p;
+  }
+  int32_t* dn = done;
+  if (!dn && E.term_out) {
+    if (E.done_tmp.bytes < sizeof(int32_t) * E.cfg.B) PDEC_HIP(E.done_tmp.alloc(sizeof(int32_t) * E.cfg.B));
+    dn = E.done_tmp.as<int32_t>();
+  }
+  int rc;
+  if ((rc = kseg2d_actuate(E0, action, ph))) return rc;                                 // src/PDEenv.jl:199
+  if ((rc = kseg2d_pde_step(E0, y_in, ph, y_out, dn))) return rc;                       // :216-218 (zeroes done)
+  if ((rc = K2_DISPATCH(k2_sense, y_out, action, action_prev, state_prev, state_out, reward_out, dn))) return rc;   // :220-222
+  if (E.term_out && dn) {
+    const int nA = E.cfg.B * E.cfg.A;
+    if (E.cfg.dtype == PDEC_F64)
+      hipLaunchKernelGGL(kseg2d_terminal_kernel<double>, dim3((nA + 255) / 256), dim3(256), 0, E.stream, k2_dev<double>(E), dn);
+    else
+      hipLaunchKernelGGL(kseg2d_terminal_kernel<float>, dim3((nA + 255) / 256), dim3(256), 0, E.stream, k2_dev<float>(E), dn);
+    PDEC_HIP(hipGetLastError());
+  }
+  return PDEC_OK;
+}
+
+}  // namespace pdec
+
+using namespace pdec;
+
+extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, int ny, int Sx, int Sy,
+                                      const int32_t* sensor_x, const int32_t* sensor_y, int half_window,
+                                      const int32_t* a2s) {
+  PDEC_REQUIRE(h && cfg && sensor_x && sensor_y && a2s, "pdec_kseg2d_env_create: null argument");
+  const pdec_env_cfg& c = *cfg;
+  PDEC_REQUIRE(c.pde_kind == PDEC_PDE_KSEG2D_RK4, "pdec_kseg2d_env_create: pde_kind must be PDEC_PDE_KSEG2D_RK4");
+  PDEC_REQUIRE(c.dtype == PDEC_F32 || c.dtype == PDEC_F64, "pdec_kseg2d_env_create: bad dtype %d", c.dtype);
+  PDEC_REQUIRE(c.B >= 1 && c.B <= 65535 && c.N >= 4 && c.N % 4 == 0 && ny >= 1 && c.K >= 1,
+               "pdec_kseg2d_env_create: bad sizes B=%d nx=%d (multiple of 4) ny=%d K=%d", c.B, c.N, ny, c.K);
+  PDEC_REQUIRE(c.n_species == 2 && !c.mono, "Keller-Segel has two species and no mono variant");
+  PDEC_REQUIRE(Sx >= 1 && Sy >= 1 && Sx * Sy == c.S && c.A >= 1 && half_window >= 0,
+               "pdec_kseg2d_env_create: S must equal Sx*Sy");
+  PDEC_REQUIRE(c.window >= 1 && (c.window & 1) && c.temporal_steps >= 1, "pdec_kseg2d_env_create: window must be odd >= 1");
+  PDEC_REQUIRE(c.Lx > 0 && c.dt > 0, "pdec_kseg2d_env_create: Lx and dt must be positive");
+  for (int i = 0; i < Sx; ++i) PDEC_REQUIRE(sensor_x[i] >= 0 && sensor_x[i] < c.N, "sensor_x[%d] out of range", i);
+  for (int i = 0; i < Sy; ++i) PDEC_REQUIRE(sensor_y[i] >= 0 && sensor_y[i] < ny, "sensor_y[%d] out of range", i);
+  for (int a = 0; a < c.A; ++a) PDEC_REQUIRE(a2s[a] >= 0 && a2s[a] < c.S, "pdec_kseg2d_env_create: a2s[%d] out of range", a);
+  auto E = std::make_unique<Kseg2dEnv>();
+  E->cfg = c;
+  E->cfg.Ny = ny;
+  E->nx = c.N; E->ny = ny; E->Sx = Sx; E->Sy = Sy; E->hw = half_window;
+  // two RK4 sub-steps per launch halve the HBM traffic; fp64 keeps one (register budget)
+  E->nsub = (c.dtype == PDEC_F32 && !getenv("PDEC_KSEG2D_NSUB1")) ? 2 : 1;
+  std::vector<int32_t> ca((size_t)ny * c.N, -1);
+  for (int a = 0; a < c.A; ++a) {
+    const int s = a2s[a], iy = s / Sx, ix = s % Sx;
+    for (int r = std::max(sensor_y[iy] - half_window, 0); r <= std::min(sensor_y[iy] + half_window, ny - 1); ++r)
+      for (int q = std::max(sensor_x[ix] - half_window, 0); q <= std::min(sensor_x[ix] + half_window, c.N - 1); ++q) {
+        PDEC_REQUIRE(ca[(size_t)r * c.N + q] < 0, "pdec_kseg2d_env_create: actuator boxes %d and %d overlap", ca[(size_t)r * c.N + q], a);
+        ca[(size_t)r * c.N + q] = a;
+      }
+  }
+  auto up_i = [](DevBuf& b, const int32_t* src, size_t cnt) -> int {
+    PDEC_HIP(b.alloc(sizeof(int32_t) * cnt));
+    PDEC_HIP(hipMemcpy(b.p, src, sizeof(int32_t) * cnt, hipMemcpyHostToDevice));
+    return PDEC_OK;
+  };
+  int rc;
+  if ((rc = up_i(E->sx, sensor_x, Sx))) return rc;
+  if ((rc = up_i(E->sy, sensor_y, Sy))) return rc;
+  if ((rc = up_i(E->a2s_d, a2s, c.A))) return rc;
+  if ((rc = up_i(E->cell_act, ca.data(), ca.size()))) return rc;
+  auto set_lds = [](const void* f, size_t bytes) -> int {
+    PDEC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PDEC_OK;
+  };
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 1, 0>, k2_lds<1>(8)))) return rc;
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 2, 0>, k2_lds<2>(8)))) return rc;
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 1, 1>, k2_lds<1>(8)))) return rc;
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<double, 1, 0>, k2_lds<1>(16)))) return rc;
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<double, 1, 1>, k2_lds<1>(16)))) return rc;
+  *h = register_object(std::move(E));
+  return PDEC_OK;
+}

@@ -361,7 +361,20 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
 
   // ---- phase T: target actor + target critic
   STAMP(0);
-  dma_copy(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
+  // per-column inputs of all phases first (they are the OLDEST vector-memory operations, so waiting for them does not
+  // wait for the weight-image DMAs issued behind them)
+  float xn[4], xq[4];                       // input rows 4t+q of s' and of [s; a]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 4 * t + q;
+    xn[t] = (valid && row < ns) ? g.sn[(size_t)col * ns + row] : 0.f;
+    float v = 0.f;
+    if (valid && row < ns) v = g.s[(size_t)col * ns + row];
+    else if (valid && row < K0) v = g.a[(size_t)col * na + (row - ns)];
+    xq[t] = v;
+  }
+  const float rv = valid ? g.r[col] : 0.f;
+  const float tv = valid ? g.t[col] : 0.f;
   load_small(SC, g.Ct, tid);
   load_small(SA, g.At, tid);
   load_big(saW2, g.At.w + g.At.oW2, HPa * LDWa, tid);
@@ -382,16 +395,14 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     for (; i < n4; i += FTHREADS) { const f32x4 v = r4[i]; rsum += (v[0] + v[1]) + (v[2] + v[3]); }
     for (int k = 4 * n4 + tid; k < g.Bu; k += FTHREADS) rsum += g.r[k];
   }
-  dma_wait();
-  const float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads
+  // the target critic's weight image lands in LDS while the target actor and the first critic layer run
+  dma_copy(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
+  const float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads (small images visible)
   STAMP(1);
 
-  float x[4];   // input rows 4t+q for t < 4 (K0 <= 15)
+  float x[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int row = 4 * t + q;
-    x[t] = (valid && row < ns) ? g.sn[(size_t)col * ns + row] : 0.f;
-  }
+  for (int t = 0; t < 4; ++t) x[t] = xn[t];
   float tgt;
   {
     f32x4 ha1[MTA], ha2[MTA];
@@ -404,34 +415,29 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
       if (4 * t + q == ns) x[t] = valid ? an : 0.f;
     f32x4 h1[MT], h2[MT];
     layer_in<MT, 4>(h1, x, SC, lr, q);
+    dma_wait();
+    __syncthreads();
     layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
     relu_<MT>(h2);
     const float qt = head<MT>(h2, SC.w3, SC.b3[0], q);
-    const float tv = valid ? g.t[col] : 0.f;
     tgt = g.gamma * (1.f - tv) * qt;
   }
   __syncthreads();
   STAMP(2);
-  // ---- phase Q: behaviour critic forward
-  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
+  // ---- phase Q: behaviour critic forward (small image first, then the big image lands behind layer 1)
   load_small(SC, g.C, tid);
-  dma_wait();
+  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
   __syncthreads();
   STAMP(3);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int row = 4 * t + q;
-    float v = 0.f;
-    if (valid && row < ns) v = g.s[(size_t)col * ns + row];
-    else if (valid && row < K0) v = g.a[(size_t)col * na + (row - ns)];
-    x[t] = v;
-  }
+  for (int t = 0; t < 4; ++t) x[t] = xq[t];
   f32x4 h1[MT], h2[MT];
   layer_in<MT, 4>(h1, x, SC, lr, q);
+  dma_wait();
+  __syncthreads();
   layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
   relu_<MT>(h2);
   const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
-  const float rv = valid ? g.r[col] : 0.f;
   const float c = valid ? tgt - qv : 0.f;
   const float dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
   // loss statistics (one lane per column contributes)
@@ -447,8 +453,9 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   // with lane shuffles, then over the 8 waves through LDS (fixed order -> deterministic); no MFMA/staging round.
   __syncthreads();
   STAMP(4);
+  dma_copy(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);     // W2^T for the backward pass lands behind pass A
   {
-    float* redA = Wreg;               // [8][HP]
+    float* redA = red + 8;            // [8][HP], its own LDS area
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -471,7 +478,6 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   head_bwd<MT>(dz2, h2, SC.w3, dq, q);
   __syncthreads();
   STAMP(5);
-  dma_copy(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
   dma_wait();
   __syncthreads();
   STAMP(6);
@@ -557,19 +563,18 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   const int col = blockIdx.x * FCOLS + w * 16 + lr;
   const bool valid = col < g.Bu;
 
-  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
-  load_small(SC, g.C, tid);
-  load_small(SA, g.A, tid);
-  load_big(saW2, g.A.w + g.A.oW2, HPa * LDWa, tid);
-  load_big(saW2T, g.A.w + g.A.oW2T, HPa * LDWa, tid);
-  dma_wait();
-  __syncthreads();
   float xs[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int row = 4 * t + q;
     xs[t] = (valid && row < ns) ? g.s[(size_t)col * ns + row] : 0.f;
   }
+  load_small(SA, g.A, tid);
+  load_big(saW2, g.A.w + g.A.oW2, HPa * LDWa, tid);
+  load_small(SC, g.C, tid);
+  load_big(saW2T, g.A.w + g.A.oW2T, HPa * LDWa, tid);
+  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);   // lands behind the actor forward and the critic's first layer
+  __syncthreads();
   f32x4 ha1[MTA], ha2[MTA];
   layer_in<MTA, 4>(ha1, xs, SA, lr, q);
   layer_hh<MTA, MTA, true>(ha2, ha1, saW2, LDWa, SA.b2, lr, q);
@@ -580,6 +585,8 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   for (int t = 0; t < 4; ++t) x[t] = (4 * t + q == ns) ? (valid ? aout : 0.f) : xs[t];
   f32x4 h1[MT], h2[MT];
   layer_in<MT, 4>(h1, x, SC, lr, q);
+  dma_wait();
+  __syncthreads();
   layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
   relu_<MT>(h2);
   const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
@@ -912,7 +919,8 @@ template <int MT, int MTA>
 static size_t lds_bytes(bool actor_pass) {
   const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD;
   (void)LDW;
-  size_t f = (size_t)wreg_floats(MT, MTA) + small_floats(HP) + small_floats(HPa) + (size_t)HPa * LDWa * (actor_pass ? 2 : 1) + 8;
+  size_t f = (size_t)wreg_floats(MT, MTA) + small_floats(HP) + small_floats(HPa) + (size_t)HPa * LDWa * (actor_pass ? 2 : 1) + 8 +
+             (actor_pass ? 0 : 8 * HP);   // critic pass: [8][HP] cross-wave reduction of pass A
   return f * 4;
 }
 

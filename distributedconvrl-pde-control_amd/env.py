@@ -3,7 +3,7 @@
 Same field names and step semantics; the build's addition is the leading batch dimension B
 (the reference has B = 1).  Tensors are torch CUDA tensors whose MEMORY matches
 `[B][Julia column-major array]`, i.e. shapes are the Julia shapes reversed behind B:
-    y      [B, nx]  (KS)   or [B, nx, 2]  (Keller-Segel; Julia y[2, nx])
+    y      [B, nx]  (KS)   or [B, nx, 2]  (Keller-Segel; Julia y[2, nx])  or [B, ny, nx, 2] (2-D Keller-Segel)
     state  [B, A, ns]      (Julia state[ns, A])
     action [B, A, 1]       (Julia action[1, A])
     reward [B, A]  (mono: [B, 1]),  p [B, nx],  done [B] bool
@@ -45,6 +45,11 @@ class PDEenv:
             _lib.check(self.lib.pdec_fluid_env_create(
                 C.byref(self._h), C.byref(cfg), BH, BW, sb.ctypes.data_as(pd), so.ctypes.data_as(pi),
                 ab.ctypes.data_as(pd), ao.ctypes.data_as(pi), a2s.ctypes.data_as(pi)))
+        elif getattr(setup, "is_kseg2d", False):   # u,v interleaved per cell: memory [ny][nx][2]
+            sx, sy, a2s = setup.tables()
+            _lib.check(self.lib.pdec_kseg2d_env_create(
+                C.byref(self._h), C.byref(cfg), setup.ny, len(sx), len(sy), sx.ctypes.data_as(pi),
+                sy.ctypes.data_as(pi), setup.half_window, a2s.ctypes.data_as(pi)))
         else:
             G, Ga, a2s = setup.tables()
             _lib.check(self.lib.pdec_env_create(C.byref(self._h), C.byref(cfg), G.ctypes.data_as(pd),
@@ -74,7 +79,7 @@ class PDEenv:
         self.action = self.action0.clone()
         self._action_prev = self.action0.clone()
         self._adopted = set()
-        self._pshape = self._yshape if self.is_fluid else (self.B, setup.nx)
+        self._pshape = self._yshape if self.is_fluid else (self.B,) + tuple(reversed(getattr(setup, "p_shape", (setup.nx,))))
         self.p = torch.zeros(self._pshape, **kw)
         self.reward = self._reward_ring[0]
         self._done_flags = self._flag_ring[0]
@@ -89,6 +94,8 @@ class PDEenv:
         """Julia-shaped host array -> memory image (column-major == reversed axes); complex fields get a
         trailing (re, im) axis"""
         a = np.asarray(a)
+        if a.ndim == 3 and not self.is_fluid:     # Julia y[2, nx, ny] (oracle: [2, ny, nx]) -> memory [ny][nx][2]
+            return np.ascontiguousarray(np.moveaxis(np.asarray(a, dtype=np.float64), 0, -1))
         if np.iscomplexobj(a) or self.is_fluid:
             a = np.asarray(a, dtype=np.complex128)
             a = np.swapaxes(a, -1, -2) if a.ndim >= 2 else a
@@ -233,6 +240,8 @@ class PDEenv:
         a = self.y[b].detach().cpu().numpy().astype(np.float64)
         if self.is_fluid:
             return (a[..., 0] + 1j * a[..., 1]).T
+        if a.ndim == 3:
+            return np.moveaxis(a, -1, 0)
         return a.T if a.ndim == 2 else a
 
     def state_julia(self, b=0):

@@ -50,7 +50,9 @@ enum {
   PDEC_PDE_KS_CNAB2 = 0,     /* scripts/KS/setup/KSSetup.jl:130-160 (what the reference runs) */
   PDEC_PDE_KSEG_RK4 = 1,     /* scripts/Keller-Segel/setup/KellerSegelSetup.jl:213-239 with fixed RK4 */
   PDEC_PDE_KS_RK4_FD = 2,    /* north-star variant: RK4 + periodic 5-point FD (KSSetup.jl:55-59 table) */
-  PDEC_PDE_FLUID_RK4 = 3     /* src/fluid_rk4.jl:122-190 + scripts/Fluid/setup/FluidSetup.jl:163-172 */
+  PDEC_PDE_FLUID_RK4 = 3,    /* src/fluid_rk4.jl:122-190 + scripts/Fluid/setup/FluidSetup.jl:163-172 */
+  PDEC_PDE_KSEG2D_RK4 = 4    /* BASELINE.json configs[3]: the Keller-Segel rules (KellerSegelSetup.jl:63-66,213-239)
+                                along both axes of a 2-D grid; no reference counterpart */
 };
 
 enum { PDEC_ACT_IDENTITY = 0, PDEC_ACT_RELU = 1, PDEC_ACT_TANH = 2 };
@@ -112,6 +114,8 @@ typedef struct pdec_env_cfg {
   int ifpad;               /* 1: 3/2-rule de-aliasing (scripts/Fluid/setup/FluidSetup.jl:101) */
   int sensors_per_axis;    /* sensors on a spa x spa grid, S = spa^2 (FluidSetup.jl:61) */
   double nu;               /* viscosity (FluidSetup.jl:28) */
+  /* 2-D Keller-Segel (PDEC_PDE_KSEG2D_RK4) only: rows of the grid; N = nx (multiple of 4), square cells dx = Lx/nx */
+  int Ny;
 } pdec_env_cfg;
 
 /* sensor_kernels [S][N], actuator_kernels [A][N] (host, double, row = one kernel: the
@@ -133,6 +137,17 @@ int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, int BH, int B
                           const double* sensor_boxes, const int32_t* sensor_origin,
                           const double* actuator_boxes, const int32_t* actuator_origin,
                           const int32_t* a2s);
+
+/* 2-D Keller-Segel environment (BASELINE.json configs[3]).  Sensors sit on the tensor grid
+ * sensor_y[Sy] x sensor_x[Sx] (0-based cell indices of the box centres; sensor s = iy*Sx + ix), every sensor
+ * and actuator kernel is the (2*half_window+1)^2 box of ones of KellerSegelSetup.jl:112-126, clipped at the
+ * domain edge; a2s [A] as above (actuator boxes must not overlap).  cfg->N = nx, cfg->Ny = ny = the `ny` argument.
+ *   y [B][ny][nx][2] (u,v interleaved; Julia y[2, nx, ny]), p [B][ny][nx], state [B][A][2*window^2*temporal_steps]
+ * Feature rows: species u then v (:281-286), inside a species the (i,j) shifts of the 3x3 circular window in the
+ * order of scripts/Fluid/setup/FluidSetup.jl:219-223, then the temporal stack (:297-303). */
+int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, int ny, int Sx, int Sy,
+                           const int32_t* sensor_x, const int32_t* sensor_y, int half_window,
+                           const int32_t* a2s);
 
 /* prepare_action(; env): p[B][N] from action[B][A]      (KSSetup.jl:231-245) */
 int pdec_actuate(pdec_handle h, const void* action, void* p_out);

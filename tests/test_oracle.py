@@ -211,3 +211,30 @@ def test_ks_fd_rk4_variant_converges_to_the_spectral_step():
         errs.append(np.abs(a - b).max())
     assert errs[0] / errs[1] > 3.0 and errs[1] / errs[2] > 3.0, errs
     assert errs[2] < 1e-5
+
+
+def test_kseg2d_oracle_reduces_to_pinned_1d():
+    """oracle/keller_segel2d.py on a field that does not depend on y == the 1-D oracle, which the reference's
+    golden pins (test above); transposing the grid commutes with the step"""
+    from oracle import keller_segel as k1, keller_segel2d as k2
+    g = load_golden("kseg_hook.npz")
+    c1, c2 = k1.KSegConfig(), k2.KSeg2DConfig()
+    for b in (0, 11):
+        y1, a, ap = g["y_t"][b], g["action_t1"][b][None, :], g["action_t"][b][None, :]
+        y2 = np.repeat(y1[:, None, :], c2.ny, axis=1)
+        p2 = k2.prepare_action(c2, a)
+        assert np.abs(p2 - g["p_t1"][b][None, :]).max() <= 1e-12
+        out = k2.do_step(c2, y2, p2)
+        assert np.abs(out - g["y_t1"][b][:, None, :]).max() <= 1e-7
+        assert np.abs(out - k1.do_step(c1, y1, g["p_t1"][b])[:, None, :]).max() <= 1e-13
+        assert np.abs(k2.reward_function(c2, out, a, a - ap) - g["reward_t1"][b]).max() <= 1e-9
+        s1, s2 = k1.featurize(c1, y1, None), k2.featurize(c2, y2, None)
+        idx = [j for _ in range(3) for j in range(3)]
+        exp = np.concatenate([s1[0:3][idx], s1[3:6][idx]])
+        assert np.abs(s2 - np.concatenate([exp, exp])).max() <= 1e-14
+    rng = np.random.default_rng(0)
+    c = k2.KSeg2DConfig(nx=20, ny=20, substeps=2)
+    y, p = 1 + 0.2 * rng.standard_normal((2, 20, 20)), rng.standard_normal((20, 20))
+    out = k2.do_step(c, y, p)
+    outT = k2.do_step(c, np.swapaxes(y, 1, 2), p.T)
+    assert np.abs(np.swapaxes(outT, 1, 2) - out).max() <= 1e-13

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Auxiliary bench (not the headline line of bench.py): the 2-D Keller-Segel env step of BASELINE.json configs[3]
+(256 x 256, B = 128, RK4 with 32 sub-steps).  One JSON line per dtype: env-steps/s, the mean duration of one control
+step's RK4 launches (HIP events through pdec_prof_*) and the HBM roofline fraction of the tile kernel against its
+compulsory traffic (read y + p, write y per sub-step: 5 scalars per cell)."""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nx", type=int, default=256)
+    ap.add_argument("--B", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--dtypes", default="f32,f64")
+    args = ap.parse_args()
+    pkg = importlib.import_module("distributedconvrl-pde-control_amd")
+    L = pkg._lib
+    for name in args.dtypes.split(","):
+        dt = torch.float32 if name == "f32" else torch.float64
+        setup = pkg.KellerSegel2DSetup(nx=args.nx, ny=args.nx)
+        rng = np.random.default_rng(0)
+        y0 = np.moveaxis(setup.generate_random_init(rng, args.B), 1, -1)
+        env = pkg.PDEenv(setup, B=args.B, dtype=dt, y0=np.ascontiguousarray(y0))
+        act = torch.as_tensor(rng.uniform(-1, 1, env._ashape), dtype=dt, device="cuda:0")
+        for _ in range(2):
+            env(act)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            env(act)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / args.steps
+        L.check(env.lib.pdec_prof_reset(env.handle))
+        L.check(env.lib.pdec_prof_enable(env.handle, 1))
+        for _ in range(3):
+            env(act)
+        torch.cuda.synchronize()
+        ms, cnt = C.c_double(), C.c_int()
+        L.check(env.lib.pdec_prof_get(env.handle, b"kseg2d_rk4", C.byref(ms), C.byref(cnt)))
+        L.check(env.lib.pdec_prof_enable(env.handle, 0))
+        ts = 4 if name == "f32" else 8
+        cells = args.B * args.nx * args.nx
+        alg = 5 * ts * cells * setup.oversampling            # per control step
+        gbs = alg / (ms.value * 1e-3) / 1e9
+        print(json.dumps({
+            "case": f"kseg2d {args.nx}x{args.nx} B={args.B} {name} K={setup.oversampling} A={setup.n_actuators}",
+            "env_steps_per_s": args.B / sec, "ms_per_control_step": sec * 1e3, "rk4_ms_per_control_step": ms.value,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                         "algorithmic_bytes_per_control_step": alg},
+            "finite": bool(torch.isfinite(env.y).all().item()), "max_abs_y": float(env.y.abs().max().item())}))
+
+
+if __name__ == "__main__":
+    main()
