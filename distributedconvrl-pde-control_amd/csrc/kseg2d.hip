@@ -25,7 +25,7 @@ constexpr int K2_TX = 64, K2_TY = 64, K2_NT = 512;
 template <class T>
 struct K2Dev {
   int B, nx, ny, K, Sx, Sy, S, A, hw, ns, window, temporal, check_max;
-  T idx, idx2, hstep, sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
+  T idx, idx2, c56, hstep, sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
   const int* sx;        // [Sx] 0-based centre columns
   const int* sy;        // [Sy] 0-based centre rows
   const int* a2s;       // [A]
@@ -50,28 +50,47 @@ __device__ __forceinline__ T k2_pow_abs(T d, T pw) {
   return pow(a, pw);
 }
 
-// one cell of the right-hand side (same expression forms as the 1-D kernel kseg_rhs in env.hip)
+// (u, v) of one cell as a 2-vector: for fp32 the compiler emits the packed VOP3P forms (v_pk_add/mul/fma_f32),
+// so the Laplacians, the differences and the RK4 updates of both species cost one instruction
 template <class T>
-__device__ __forceinline__ C2<T> k2_rhs_cell(const K2Dev<T>& e, C2<T> c, C2<T> w, C2<T> ea, C2<T> s, C2<T> n, T p) {
-  const T ux = (T)0.5 * e.idx * (ea.x - w.x), uy = (T)0.5 * e.idx * (n.x - s.x);
-  const T vx = (T)0.5 * e.idx * (ea.y - w.y), vy = (T)0.5 * e.idx * (n.y - s.y);
-  const T lu = (e.idx2 * w.x - (T)2 * e.idx2 * c.x + e.idx2 * ea.x) + (e.idx2 * s.x - (T)2 * e.idx2 * c.x + e.idx2 * n.x);
-  const T lv = (e.idx2 * w.y - (T)2 * e.idx2 * c.y + e.idx2 * ea.y) + (e.idx2 * s.y - (T)2 * e.idx2 * c.y + e.idx2 * n.y);
-  C2<T> k;
-  k.y = lv - c.y + c.x + p;
-  k.x = lu + c.x - (T)5.6 * ux * vx - (T)5.6 * uy * vy - (T)5.6 * c.x * lv - c.x * c.x;
-  return k;
+using V2 = T __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ V2<T> v2(C2<T> c) { V2<T> r; r.x = c.x; r.y = c.y; return r; }
+template <class T>
+__device__ __forceinline__ C2<T> c2(V2<T> v) { return mk<T>(v.x, v.y); }
+
+// Right-hand side of TWO adjacent cells at once (x = cell i, y = cell i+1 of a row), one species per vector: every
+// operation is element-wise over the pair, so for fp32 the whole expression is packed VOP3P math (v_pk_add/mul/fma_f32,
+// two cells per instruction).  Same discretisation as the 1-D kernel kseg_rhs (env.hip) with the constants folded:
+// Lap = ((w + e) + (s + n) - 4c)/dx^2, grad u . grad v = ((e-w)_u (e-w)_v + (n-s)_u (n-s)_v) / (4 dx^2),
+// u' = Lap u + u (1 - 5.6 Lap v - u) - 5.6 grad u . grad v,  v' = Lap v - v + u + p
+template <class T>
+__device__ __forceinline__ void k2_rhs_pair(const K2Dev<T>& e, V2<T> u, V2<T> v, V2<T> uw, V2<T> ue, V2<T> us, V2<T> un,
+                                            V2<T> vw, V2<T> ve, V2<T> vs, V2<T> vn, V2<T> p, V2<T>& ku, V2<T>& kv) {
+  const V2<T> lu = (((uw + ue) + (us + un)) - (T)4 * u) * e.idx2;
+  const V2<T> lv = (((vw + ve) + (vs + vn)) - (T)4 * v) * e.idx2;
+  const V2<T> dot = (ue - uw) * (ve - vw) + (un - us) * (vn - vs);
+  const V2<T> t = ((T)1 - (T)5.6 * lv) - u;
+  kv = (lv + p) + (u - v);
+  ku = (lu + u * t) - e.c56 * dot;
 }
+
+template <class T>
+struct alignas(16) QuadT {  // four consecutive scalars of one plane = two cell pairs
+  V2<T> a, b;
+};
 
 // MODE 0: integrate NSUB sub-steps, 1: right-hand side only (KATs)
 template <class T, int NSUB, int MODE>
-__global__ __launch_bounds__(K2_NT) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<T>* __restrict__ y_in,
+__global__ __launch_bounds__(K2_NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<T>* __restrict__ y_in,
                                                            const T* __restrict__ p_in, C2<T>* __restrict__ y_out,
                                                            int32_t* __restrict__ done, int last) {
   constexpr int H = 4 * NSUB, RX = K2_TX + 2 * H, RY = K2_TY + 2 * H, SW = RX / 4, NSTRIP = SW * RY;
-  constexpr int NS = (NSTRIP + K2_NT - 1) / K2_NT, RXP = RX + 2;
+  constexpr int NS = (NSTRIP + K2_NT - 1) / K2_NT, RXP = RX + 4;
   extern __shared__ __align__(16) unsigned char k2_smem[];
-  C2<T>* S = reinterpret_cast<C2<T>*>(k2_smem);   // [RY][RXP] stage values
+  // stage values, one plane per species (a thread's 4 cells = one conflict-free 128-bit access per plane)
+  T* Su = reinterpret_cast<T*>(k2_smem);        // [RY][RXP]
+  T* Sv = Su + RY * RXP;                        // [RY][RXP]
   const int tid = threadIdx.x, b = blockIdx.z;
   const int gx0 = blockIdx.x * K2_TX - H, gy0 = blockIdx.y * K2_TY - H;
   // part of the region that lies inside the domain (local coordinates); neighbour indices clamp to it, which IS
@@ -80,8 +99,8 @@ __global__ __launch_bounds__(K2_NT) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<
   const int loy = max(0, -gy0), hiy = min(RY, e.ny - gy0) - 1;
   const size_t fo = (size_t)b * e.ny * e.nx;
 
-  C2<T> y0[NS][4], acc[NS][4], cur[NS][4];
-  T pp[NS][4];
+  // per strip: pairs (c0,c1), (c2,c3) of u and of v
+  V2<T> u0[NS][2], v0[NS][2], au[NS][2], av[NS][2], cu[NS][2], cv[NS][2], pp[NS][2];
   int sr[NS], sc[NS];
   bool act[NS];
 #pragma unroll
@@ -93,13 +112,16 @@ __global__ __launch_bounds__(K2_NT) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<
     if (act[k]) {
       const size_t g = fo + (size_t)(gy0 + sr[k]) * e.nx + (gx0 + sc[k]);
       const Quad<T> q = *reinterpret_cast<const Quad<T>*>(y_in + g);
-      const Quad1<T> qp = *reinterpret_cast<const Quad1<T>*>(p_in + g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { y0[k][i] = q.c[i]; cur[k][i] = q.c[i]; pp[k][i] = qp.c[i]; }
+      const QuadT<T> qp = *reinterpret_cast<const QuadT<T>*>(p_in + g);
+      u0[k][0].x = q.c[0].x; u0[k][0].y = q.c[1].x; u0[k][1].x = q.c[2].x; u0[k][1].y = q.c[3].x;
+      v0[k][0].x = q.c[0].y; v0[k][0].y = q.c[1].y; v0[k][1].x = q.c[2].y; v0[k][1].y = q.c[3].y;
+      pp[k][0] = qp.a; pp[k][1] = qp.b;
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { y0[k][i] = mk<T>(0, 0); cur[k][i] = mk<T>(0, 0); pp[k][i] = 0; }
+      for (int i = 0; i < 2; ++i) { u0[k][i] = (V2<T>)(T)0; v0[k][i] = (V2<T>)(T)0; pp[k][i] = (V2<T>)(T)0; }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { cu[k][i] = u0[k][i]; cv[k][i] = v0[k][i]; }
   }
   const T h = e.hstep;
   for (int sub = 0; sub < NSUB; ++sub) {
@@ -110,43 +132,47 @@ __global__ __launch_bounds__(K2_NT) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<
 #pragma unroll
       for (int k = 0; k < NS; ++k)
         if (act[k]) {
-          Quad<T> q;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) q.c[i] = cur[k][i];
-          *reinterpret_cast<Quad<T>*>(S + sr[k] * RXP + sc[k]) = q;
+          QuadT<T> q;
+          q.a = cu[k][0]; q.b = cu[k][1];
+          *reinterpret_cast<QuadT<T>*>(Su + sr[k] * RXP + sc[k]) = q;
+          q.a = cv[k][0]; q.b = cv[k][1];
+          *reinterpret_cast<QuadT<T>*>(Sv + sr[k] * RXP + sc[k]) = q;
         }
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         if (!act[k]) continue;
         const int r = sr[k], c0 = sc[k];
-        const C2<T> W = S[r * RXP + max(c0 - 1, lox)], E = S[r * RXP + min(c0 + 4, hix)];
-        const Quad<T> qs = *reinterpret_cast<const Quad<T>*>(S + max(r - 1, loy) * RXP + c0);
-        const Quad<T> qn = *reinterpret_cast<const Quad<T>*>(S + min(r + 1, hiy) * RXP + c0);
-        C2<T> kk[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          kk[i] = k2_rhs_cell<T>(e, cur[k][i], i == 0 ? W : cur[k][i - 1], i == 3 ? E : cur[k][i + 1], qs.c[i], qn.c[i],
-                                 pp[k][i]);
+        const int ow = r * RXP + max(c0 - 1, lox), oe = r * RXP + min(c0 + 4, hix);
+        const int os = max(r - 1, loy) * RXP + c0, on = min(r + 1, hiy) * RXP + c0;
+        const QuadT<T> us = *reinterpret_cast<const QuadT<T>*>(Su + os), un = *reinterpret_cast<const QuadT<T>*>(Su + on);
+        const QuadT<T> vs = *reinterpret_cast<const QuadT<T>*>(Sv + os), vn = *reinterpret_cast<const QuadT<T>*>(Sv + on);
+        // west / east neighbours of the two pairs: (W,c0) | (c1,c2) | (c3,E)
+        V2<T> uA, uM, uB, vA, vM, vB;
+        uA.x = Su[ow]; uA.y = cu[k][0].x; uM.x = cu[k][0].y; uM.y = cu[k][1].x; uB.x = cu[k][1].y; uB.y = Su[oe];
+        vA.x = Sv[ow]; vA.y = cv[k][0].x; vM.x = cv[k][0].y; vM.y = cv[k][1].x; vB.x = cv[k][1].y; vB.y = Sv[oe];
+        V2<T> ku[2], kv[2];
+        k2_rhs_pair<T>(e, cu[k][0], cv[k][0], uA, uM, us.a, un.a, vA, vM, vs.a, vn.a, pp[k][0], ku[0], kv[0]);
+        k2_rhs_pair<T>(e, cu[k][1], cv[k][1], uM, uB, us.b, un.b, vM, vB, vs.b, vn.b, pp[k][1], ku[1], kv[1]);
         if (MODE == 1) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) y0[k][i] = kk[i];
+          for (int i = 0; i < 2; ++i) { u0[k][i] = ku[i]; v0[k][i] = kv[i]; }
           continue;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
           if (stage == 0) {
-            acc[k][i] = kk[i];
-            cur[k][i] = mk<T>(y0[k][i].x + (T)0.5 * h * kk[i].x, y0[k][i].y + (T)0.5 * h * kk[i].y);
+            au[k][i] = ku[i]; av[k][i] = kv[i];
+            cu[k][i] = u0[k][i] + ((T)0.5 * h) * ku[i]; cv[k][i] = v0[k][i] + ((T)0.5 * h) * kv[i];
           } else if (stage == 1) {
-            acc[k][i] = mk<T>(acc[k][i].x + (T)2 * kk[i].x, acc[k][i].y + (T)2 * kk[i].y);
-            cur[k][i] = mk<T>(y0[k][i].x + (T)0.5 * h * kk[i].x, y0[k][i].y + (T)0.5 * h * kk[i].y);
+            au[k][i] = au[k][i] + (T)2 * ku[i]; av[k][i] = av[k][i] + (T)2 * kv[i];
+            cu[k][i] = u0[k][i] + ((T)0.5 * h) * ku[i]; cv[k][i] = v0[k][i] + ((T)0.5 * h) * kv[i];
           } else if (stage == 2) {
-            acc[k][i] = mk<T>(acc[k][i].x + (T)2 * kk[i].x, acc[k][i].y + (T)2 * kk[i].y);
-            cur[k][i] = mk<T>(y0[k][i].x + h * kk[i].x, y0[k][i].y + h * kk[i].y);
+            au[k][i] = au[k][i] + (T)2 * ku[i]; av[k][i] = av[k][i] + (T)2 * kv[i];
+            cu[k][i] = u0[k][i] + h * ku[i]; cv[k][i] = v0[k][i] + h * kv[i];
           } else {
-            y0[k][i] = mk<T>(y0[k][i].x + h / (T)6 * (acc[k][i].x + kk[i].x), y0[k][i].y + h / (T)6 * (acc[k][i].y + kk[i].y));
-            cur[k][i] = y0[k][i];
+            u0[k][i] = u0[k][i] + (h / (T)6) * (au[k][i] + ku[i]); v0[k][i] = v0[k][i] + (h / (T)6) * (av[k][i] + kv[i]);
+            cu[k][i] = u0[k][i]; cv[k][i] = v0[k][i];
           }
         }
       }
@@ -161,12 +187,12 @@ __global__ __launch_bounds__(K2_NT) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<
     if (!act[k] || sr[k] < H || sr[k] >= H + K2_TY || sc[k] < H || sc[k] >= H + K2_TX) continue;
     const size_t g = fo + (size_t)(gy0 + sr[k]) * e.nx + (gx0 + sc[k]);
     Quad<T> q;
+    q.c[0] = mk<T>(u0[k][0].x, v0[k][0].x); q.c[1] = mk<T>(u0[k][0].y, v0[k][0].y);
+    q.c[2] = mk<T>(u0[k][1].x, v0[k][1].x); q.c[3] = mk<T>(u0[k][1].y, v0[k][1].y);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      q.c[i] = y0[k][i];
+    for (int i = 0; i < 4; ++i)
       // blow-up test max|y| > max_value (src/PDEenv.jl:227); NaN also raises the flag (as in the 1-D kernels)
-      bad |= !(fabs(y0[k][i].x) <= e.max_value && fabs(y0[k][i].y) <= e.max_value);
-    }
+      bad |= !(fabs(q.c[i].x) <= e.max_value && fabs(q.c[i].y) <= e.max_value);
     *reinterpret_cast<Quad<T>*>(y_out + g) = q;
   }
   if (MODE == 0 && last && done && e.check_max == 1) {
@@ -268,7 +294,7 @@ static K2Dev<T> k2_dev(const Kseg2dEnv& E) {
   d.window = c.window; d.temporal = c.temporal_steps; d.ns = 2 * c.window * c.window * c.temporal_steps;
   d.check_max = c.check_max_value;
   const double dx = c.Lx / E.nx;
-  d.idx = (T)(1.0 / dx); d.idx2 = (T)(1.0 / (dx * dx)); d.hstep = (T)(c.dt / c.K);
+  d.idx = (T)(1.0 / dx); d.idx2 = (T)(1.0 / (dx * dx)); d.c56 = (T)(5.6 * 0.25 / (dx * dx)); d.hstep = (T)(c.dt / c.K);
   d.sensor_scale = (T)c.sensor_scale; d.agent_power = (T)c.agent_power; d.r_in_scale = (T)c.reward_in_scale;
   d.r_offset = (T)c.reward_offset; d.r_power = (T)c.reward_power; d.r_denom = (T)c.reward_denom;
   d.a_pun = (T)c.action_punish; d.da_pun = (T)c.delta_action_punish; d.max_value = (T)c.max_value;
@@ -278,8 +304,8 @@ static K2Dev<T> k2_dev(const Kseg2dEnv& E) {
 }
 
 template <int NSUB>
-static constexpr size_t k2_lds(size_t pair_bytes) {
-  return (size_t)(K2_TY + 8 * NSUB) * (K2_TX + 8 * NSUB + 2) * pair_bytes;
+static constexpr size_t k2_lds(size_t pair_bytes) {   // two planes [RY][RX + 4] of T
+  return (size_t)(K2_TY + 8 * NSUB) * (K2_TX + 8 * NSUB + 4) * pair_bytes;
 }
 
 template <class T, int NSUB, int MODE>
@@ -426,8 +452,10 @@ extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, i
   E->cfg = c;
   E->cfg.Ny = ny;
   E->nx = c.N; E->ny = ny; E->Sx = Sx; E->Sy = Sy; E->hw = half_window;
-  // two RK4 sub-steps per launch halve the HBM traffic; fp64 keeps one (register budget)
-  E->nsub = (c.dtype == PDEC_F32 && !getenv("PDEC_KSEG2D_NSUB1")) ? 2 : 1;
+  // One RK4 sub-step per launch (halo 4): measured faster than two fused sub-steps (halo 8, half the HBM traffic but
+  // 1.56x instead of 1.27x redundant cells and too many registers for two workgroups per CU); PDEC_KSEG2D_NSUB2=1
+  // selects the two-sub-step variant (fp32 only).
+  E->nsub = (c.dtype == PDEC_F32 && getenv("PDEC_KSEG2D_NSUB2")) ? 2 : 1;
   std::vector<int32_t> ca((size_t)ny * c.N, -1);
   for (int a = 0; a < c.A; ++a) {
     const int s = a2s[a], iy = s / Sx, ix = s % Sx;

@@ -776,6 +776,8 @@ int pdec_ddpg_critic_grads(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec
   PDEC_REQUIRE(At->dims == A->dims && Ct->dims == C->dims, "ddpg: target networks must have the behaviour networks' shapes");
   if (fused_supported(A, C) && A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream)
     return fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev, nullptr);
+  if (fused2_supported(A, C) && A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream)
+    return fused2_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev, nullptr);
   return C->dtype == PDEC_F64
              ? critic_grads_t<double>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev)
              : critic_grads_t<float>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev);
@@ -787,6 +789,7 @@ int pdec_ddpg_actor_grads(pdec_handle hA, pdec_handle hC, const void* s, int Bu,
   PDEC_REQUIRE(s && Bu >= 1, "pdec_ddpg_actor_grads: null/empty batch");
   PDEC_REQUIRE(A->dtype == C->dtype, "ddpg: dtype mismatch");
   if (fused_supported(A, C) && A->stream == C->stream) return fused_actor_grads(A, C, nullptr, s, Bu, grad_scale, actor_loss_dev, nullptr);
+  if (fused2_supported(A, C) && A->stream == C->stream) return fused2_actor_grads(A, C, nullptr, s, Bu, grad_scale, actor_loss_dev, nullptr);
   return C->dtype == PDEC_F64 ? actor_grads_t<double>(A, C, s, Bu, grad_scale, actor_loss_dev)
                               : actor_grads_t<float>(A, C, s, Bu, grad_scale, actor_loss_dev);
 }
@@ -833,6 +836,10 @@ int pdec_adam_polyak_step(pdec_handle h, pdec_handle h_target, double eta, doubl
     const AdamPolyak ap{eta, beta1, beta2, eps, rho};
     return fused_adam_polyak(M, T, ap);
   }
+  if (fused2_net_supported(M) && M->stream == T->stream) {
+    const AdamPolyak ap{eta, beta1, beta2, eps, rho};
+    return fused2_adam_polyak(M, T, ap);
+  }
   int rc = pdec_adam_step(h, eta, beta1, beta2, eps);
   if (rc) return rc;
   if (M->stream != T->stream) PDEC_HIP(hipStreamSynchronize(M->stream));
@@ -865,6 +872,14 @@ static int ddpg_update_phases(int phase, pdec_handle hA, pdec_handle hC, pdec_ha
         (rc = fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, 1.0, l0, &apc)))
       return rc;
     if (phase & 2) return fused_actor_grads(A, C, At, s, Bu, 1.0, l1, &apa);
+    return PDEC_OK;
+  }
+  if (fused2_supported(A, C) && one_stream && Bu >= 64) {      // 2-layer nets, large batches: same 4 launches
+    const AdamPolyak apc{eta_critic, 0.9, 0.999, 1e-8, rho}, apa{eta_actor, 0.9, 0.999, 1e-8, rho};
+    if ((phase & 1) &&
+        (rc = fused2_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, 1.0, l0, &apc)))
+      return rc;
+    if (phase & 2) return fused2_actor_grads(A, C, At, s, Bu, 1.0, l1, &apa);
     return PDEC_OK;
   }
   if (phase & 1) {

@@ -1,0 +1,749 @@
+// mlp_mfma2.hip -- fused fp32 MFMA path of the DDPG update for the reference-shaped 2-layer nets
+// (`drop_middle_layer = true`, src/PDEagent.jl:30-41: actor Dense(ns,h,relu) -> Dense(h,1,tanh), critic
+// Dense(ns+1,H,relu) -> Dense(H,1)) at large batches, e.g. the 2-D Keller-Segel case of BASELINE.json configs[3]:
+// a 3x3 x 2 species x 2 steps window (ns = 36) over B*A = 100k columns, critic 37 -> 340 -> 1.  This is the
+// "2-D conv as im2col-GEMM" contraction: [H x (ns+1)] x [(ns+1) x columns] on v_mfma_f32_16x16x4_f32.
+// Restates src/PDEagent.jl:385-409 in the same two passes as mlp_mfma.hip:
+//   ddpg2_critic_kernel : a' = At(s'), qt = Ct([s';a']), q = C([s;a]), loss statistics, dq, critic backward -> slab
+//   ddpg2_actor_kernel  : a = A(s), q = C([s;a]), -mean(q), backward through the critic to da, actor backward -> slab
+//   finish2_kernel      : deterministic slab sum -> flat gradients (+ ADAM, Polyak when no all-reduce comes between)
+// Layout: one workgroup = 8 waves = 128 columns, a wave owns 16 columns.  The first-layer weights live in LDS as a
+// padded image [HP][LDK]; the contraction index is blocked by 8 (k = 8 blk + 2 q + t, t = 0,1), so the A operand of
+// two consecutive k-steps is ONE ds_read_b64 (row stride 8 KB + 4 floats = 2 x odd 8-byte slots: conflict-free over
+// each 32-lane service group) and the B operand is the input row pair the lane loaded from HBM.  The output layer is
+// a single row: its forward is a per-lane dot + two lane exchanges, its weight gradient a DPP row sum.  dW1 contracts
+// over columns: dz1 and the inputs are transposed once through LDS and multiplied as MFMA tiles (mfma_blocks.hpp).
+// The kernels read the FLAT parameter buffers (no padded copy to maintain).
+#include "common.hpp"
+#include "mlp.hpp"
+#include "mfma_blocks.hpp"
+
+namespace pdec {
+
+#define K2MAX 6            // k-blocks of 8: ns + 1 <= 48
+
+struct Net2 {              // flat parameters [W1 [H][K0] row-major, b1 [H], W2 [1][H], b2 [1]]
+  const float* p;
+  int K0, H, kb;           // kb = ceil(K0 / 8) k-blocks are multiplied; the image row stride is a template constant
+};
+
+struct Lds2 {
+  float *W1, *b1, *w2, *b2;
+};
+__host__ __device__ inline int lds2_floats(int HP, int ldk) { return HP * ldk + 2 * HP + 4; }
+__device__ __forceinline__ Lds2 carve2(float* base, int HP, int ldk) {
+  Lds2 s;
+  s.W1 = base; s.b1 = base + HP * ldk; s.w2 = s.b1 + HP; s.b2 = s.w2 + HP;
+  return s;
+}
+
+// flat parameters -> padded LDS image: the H*K0 weights are streamed with 16-byte loads (8 in flight per lane) and
+// scattered to their padded rows; the pad cells are zeroed by separate stores (disjoint addresses, no ordering needed)
+__device__ __forceinline__ void load_net2(const Lds2& s, const Net2& n, int HP, int ldk, int tid) {
+  const int K0 = n.K0, H = n.H, nw = H * K0;
+  const int n4 = ((reinterpret_cast<uintptr_t>(n.p) & 15) == 0) ? nw / 4 : 0;
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(n.p);
+  auto put = [&](int idx, float v) {
+    const int r = idx / K0;
+    s.W1[r * ldk + (idx - r * K0)] = v;
+  };
+  int i = tid;
+  for (; i + 7 * FTHREADS < n4; i += 8 * FTHREADS) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = w4[i + u * FTHREADS];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) put(4 * (i + u * FTHREADS) + e, v[u][e]);
+  }
+  for (; i < n4; i += FTHREADS) {
+    const f32x4 v = w4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) put(4 * i + e, v[e]);
+  }
+  for (int k = 4 * n4 + tid; k < nw; k += FTHREADS) put(k, n.p[k]);
+  const int padc = ldk - K0;
+  for (int k = tid; k < H * padc; k += FTHREADS) { const int r = k / padc; s.W1[r * ldk + K0 + (k - r * padc)] = 0.f; }
+  for (int k = tid; k < (HP - H) * ldk; k += FTHREADS) s.W1[H * ldk + k] = 0.f;
+  const float* b1 = n.p + (size_t)nw;
+  for (int k = tid; k < HP; k += FTHREADS) {
+    s.b1[k] = k < H ? b1[k] : 0.f;
+    s.w2[k] = k < H ? b1[H + k] : 0.f;
+  }
+  if (tid == 0) s.b2[0] = b1[2 * H];
+}
+
+// first layer: h = relu(W1 x + b1), tiles kept (D layout)
+template <int MT, int KB>
+__device__ __forceinline__ void layer1_keep(f32x4 (&h)[MT], const float (&x)[K2MAX][2], const Lds2& s, int lr, int q) {
+  constexpr int ldk = 8 * KB + 4;
+#pragma unroll
+  for (int mo = 0; mo < MT; mo += 2) {
+    const bool two = mo + 1 < MT;
+    const float* b = s.b1 + 16 * mo + 4 * q;
+    f32x4 a0 = {b[0], b[1], b[2], b[3]};
+    f32x4 a1 = two ? f32x4{b[16], b[17], b[18], b[19]} : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w0 = s.W1 + (16 * mo + lr) * ldk + 2 * q;
+    const float* w1 = w0 + 16 * ldk;
+#pragma unroll
+    for (int blk = 0; blk < KB; ++blk) {
+        const float2 wa = *reinterpret_cast<const float2*>(w0 + 8 * blk);
+        a0 = mfma4(wa.x, x[blk][0], a0);
+        if (two) {
+          const float2 wb = *reinterpret_cast<const float2*>(w1 + 8 * blk);
+          a1 = mfma4(wb.x, x[blk][0], a1);
+          a0 = mfma4(wa.y, x[blk][1], a0);
+          a1 = mfma4(wb.y, x[blk][1], a1);
+        } else {
+          a0 = mfma4(wa.y, x[blk][1], a0);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a0[r] = fmaxf(a0[r], 0.f);
+    h[mo] = a0;
+    if (two) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1[r] = fmaxf(a1[r], 0.f);
+      h[mo + 1] = a1;
+    }
+  }
+}
+
+// first layer + output row without keeping the tiles: returns w2 . relu(W1 x + b1) + b2 (every lane of a column)
+template <int MT, int KB>
+__device__ __forceinline__ float layer1_head(const float (&x)[K2MAX][2], const Lds2& s, int lr, int q) {
+  constexpr int ldk = 8 * KB + 4;
+  float acc = 0.f;
+#pragma unroll
+  for (int mo = 0; mo < MT; mo += 2) {
+    const bool two = mo + 1 < MT;
+    const float* b = s.b1 + 16 * mo + 4 * q;
+    f32x4 a0 = {b[0], b[1], b[2], b[3]};
+    f32x4 a1 = two ? f32x4{b[16], b[17], b[18], b[19]} : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w0 = s.W1 + (16 * mo + lr) * ldk + 2 * q;
+    const float* w1 = w0 + 16 * ldk;
+#pragma unroll
+    for (int blk = 0; blk < KB; ++blk) {
+        const float2 wa = *reinterpret_cast<const float2*>(w0 + 8 * blk);
+        a0 = mfma4(wa.x, x[blk][0], a0);
+        if (two) {
+          const float2 wb = *reinterpret_cast<const float2*>(w1 + 8 * blk);
+          a1 = mfma4(wb.x, x[blk][0], a1);
+          a0 = mfma4(wa.y, x[blk][1], a0);
+          a1 = mfma4(wb.y, x[blk][1], a1);
+        } else {
+          a0 = mfma4(wa.y, x[blk][1], a0);
+        }
+      }
+    const float* wv = s.w2 + 16 * mo + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc += wv[r] * fmaxf(a0[r], 0.f);
+    if (two) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc += wv[16 + r] * fmaxf(a1[r], 0.f);
+    }
+  }
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  return acc + s.b2[0];
+}
+
+// critic forward inside the actor pass: q partial = w2 . relu(W1 x + b1) and the input-gradient partial
+// da = sum_i W1[i][ns] * relu'(z_i) * w2_i of this lane's rows, tile pair by tile pair (no tile is kept)
+template <int MT, int KB>
+__device__ __forceinline__ void layer1_head_da(const float (&x)[K2MAX][2], const Lds2& s, int ns, int lr, int q, float& qacc,
+                                               float& da) {
+  constexpr int ldk = 8 * KB + 4;
+#pragma unroll
+  for (int mo = 0; mo < MT; mo += 2) {
+    const bool two = mo + 1 < MT;
+    const float* b = s.b1 + 16 * mo + 4 * q;
+    f32x4 a0 = {b[0], b[1], b[2], b[3]};
+    f32x4 a1 = two ? f32x4{b[16], b[17], b[18], b[19]} : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w0 = s.W1 + (16 * mo + lr) * ldk + 2 * q;
+    const float* w1 = w0 + 16 * ldk;
+#pragma unroll
+    for (int blk = 0; blk < KB; ++blk) {
+        const float2 wa = *reinterpret_cast<const float2*>(w0 + 8 * blk);
+        a0 = mfma4(wa.x, x[blk][0], a0);
+        if (two) {
+          const float2 wb = *reinterpret_cast<const float2*>(w1 + 8 * blk);
+          a1 = mfma4(wb.x, x[blk][0], a1);
+          a0 = mfma4(wa.y, x[blk][1], a0);
+          a1 = mfma4(wb.y, x[blk][1], a1);
+        } else {
+          a0 = mfma4(wa.y, x[blk][1], a0);
+        }
+      }
+    {   // unconditional operand loads (a select, not a branch around the load)
+      const int row0 = 16 * mo + 4 * q;
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(s.w2 + row0);
+      const float* wc = s.W1 + row0 * ldk + ns;
+      const float c0 = wc[0], c1 = wc[ldk], c2 = wc[2 * ldk], c3 = wc[3 * ldk];
+      const float cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        qacc += wv[r] * fmaxf(a0[r], 0.f);
+        const float t = cc[r] * wv[r];
+        da += a0[r] > 0.f ? t : 0.f;
+      }
+      if (two) {
+        const f32x4 wv1 = *reinterpret_cast<const f32x4*>(s.w2 + row0 + 16);
+        const float* wc1 = wc + 16 * ldk;
+        const float d0 = wc1[0], d1 = wc1[ldk], d2 = wc1[2 * ldk], d3 = wc1[3 * ldk];
+        const float dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qacc += wv1[r] * fmaxf(a1[r], 0.f);
+          const float t = dd[r] * wv1[r];
+          da += a1[r] > 0.f ? t : 0.f;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every tile pair's operand loads (spills)
+  }
+}
+
+// input rows of a lane: x[blk][t] = X[8 blk + 2 q + t][col]; rows < ns from `s`, row ns from `extra` (the action), 0 above
+__device__ __forceinline__ void load_x2(float (&x)[K2MAX][2], const float* __restrict__ s, size_t col, int ns, int kb, int q,
+                                        bool valid) {
+#pragma unroll
+  for (int blk = 0; blk < K2MAX; ++blk)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 8 * blk + 2 * q + t;
+      x[blk][t] = (valid && blk < kb && row < ns) ? s[col * ns + row] : 0.f;
+    }
+}
+__device__ __forceinline__ void set_row2(float (&x)[K2MAX][2], int row, float v, int q) {
+#pragma unroll
+  for (int blk = 0; blk < K2MAX; ++blk)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (8 * blk + 2 * q + t == row) x[blk][t] = v;
+}
+// write the lane's input rows into a [row][LDP] staging image (row `ones_row` := 1: the bias gradient rides the GEMM)
+__device__ __forceinline__ void stage_x2(float* img, const float (&x)[K2MAX][2], int nrows, int cw, int q, int ones_row) {
+#pragma unroll
+  for (int blk = 0; blk < K2MAX; ++blk)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 8 * blk + 2 * q + t;
+      if (row < nrows) img[row * LDP + cw] = row == ones_row ? 1.f : x[blk][t];
+    }
+}
+
+struct Fused2Args {
+  Net2 A, C, At, Ct;
+  const float *s, *a, *r, *t, *sn;
+  int Bu, ns;
+  float gamma;
+  int quirk;
+  float* slab;
+  const float* rbar;          // device scalar: mean reward (quirk) written by rmean_kernel
+};
+
+// mean of r in a fixed order (one block): the batch-mean reward of the reference's (1xBu).+(Bu) broadcast
+__global__ __launch_bounds__(1024) void rmean_kernel(const float* __restrict__ r, int n, float* __restrict__ out) {
+  __shared__ float part[1024];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  const int n4 = ((reinterpret_cast<uintptr_t>(r) & 15) == 0) ? n / 4 : 0;
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(r);
+  int i = tid;
+  for (; i + 7 * 1024 < n4; i += 8 * 1024) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = r4[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+  }
+  for (; i < n4; i += 1024) { const f32x4 v = r4[i]; acc += (v[0] + v[1]) + (v[2] + v[3]); }
+  for (int k = 4 * n4 + tid; k < n; k += 1024) acc += r[k];
+  part[tid] = acc;
+  __syncthreads();
+  for (int sft = 512; sft > 0; sft >>= 1) {
+    if (tid < sft) part[tid] += part[tid + sft];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = part[0] / (float)n;
+}
+
+// slab tiles of a 2-layer net: dW2/db2 as a [16][HP] product (MT tiles, row 0 real) | dW1/db1 [HP][16 nR] | stats chunk
+__host__ __device__ inline int nr_of(int K0) { return (K0 + 1 + 15) / 16; }
+__host__ __device__ inline int slab2_tiles(int MT, int nR) { return MT + MT * nR; }
+static inline size_t slab2_floats(int MT, int nR, int nslab) { return ((size_t)4 * slab2_tiles(MT, nR) + 1) * nslab * 64; }
+
+// output-row gradient dW2/db2 = sum_cols g[col] * [h; 1]: DPP sum over a wave's 16 columns, LDS over the 8 waves
+template <int MT>
+__device__ __forceinline__ void out_row_grad(const f32x4 (&h)[MT], float g, int H, float* redA, float* slab, int nslab, int T0,
+                                             int tid) {
+  const int w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4, HP = 16 * MT;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * m + 4 * q + r;
+      const float v = row_sum16((row == H ? 1.f : h[m][r]) * g);
+      if (lr == 0) redA[w * HP + row] = v;
+    }
+  __syncthreads();
+  for (int i = tid; i < HP; i += FTHREADS) {
+    float a = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < FTHREADS / 64; ++ww) a += redA[ww * HP + i];
+    slab[((size_t)(4 * (T0 + (i >> 4))) * nslab + blockIdx.x) * 64 + (i & 15)] = a;   // tile i/16, register 0, lane i%16
+  }
+}
+
+// ------------------------------------------------------------------ critic pass
+template <int MT, int MTA, int KB>
+__global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
+  constexpr int LDK = 8 * KB + 4;
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
+  constexpr int HP = 16 * MT, HPa = 16 * MTA;
+  const int ns = g.ns, K0 = ns + 1, nR = (K0 + 1 + 15) / 16;
+  // region 0: the two critic images, later overlaid by redA and the dW1 staging images
+  const int imgc = lds2_floats(HP, LDK);
+  const int stage = HP * LDP + 16 * nR * LDP;
+  const int reg0 = max(2 * imgc, max(stage, 8 * HP));
+  float* base = smem;
+  const Lds2 SC = carve2(base, HP, LDK), SCt = carve2(base + imgc, HP, LDK);
+  float* w2keep = base + reg0;                 // w2 of the behaviour critic survives the overlay   [HP]
+  const Lds2 SA = carve2(w2keep + HP, HPa, LDK);
+  float* red = SA.W1 + lds2_floats(HPa, LDK);   // [8]
+  const int col = blockIdx.x * FCOLS + w * 16 + lr;
+  const bool valid = col < g.Bu;
+
+  float xn[K2MAX][2], xq[K2MAX][2];
+  load_x2(xn, g.sn, (size_t)col, ns, KB, q, valid);
+  load_x2(xq, g.s, (size_t)col, ns, KB, q, valid);
+  const float av = valid ? g.a[col] : 0.f, rv = valid ? g.r[col] : 0.f, tv = valid ? g.t[col] : 0.f;
+  set_row2(xq, ns, av, q);
+  load_net2(SA, g.At, HPa, LDK, tid);
+  load_net2(SCt, g.Ct, HP, LDK, tid);
+  load_net2(SC, g.C, HP, LDK, tid);
+  const float rbar = g.quirk ? g.rbar[0] : 0.f;
+  __syncthreads();                              // the images are visible
+  for (int i = tid; i < HP; i += FTHREADS) w2keep[i] = SC.w2[i];
+
+  // ---- targets: a' = At(s'), qt = Ct([s'; a'])
+  float an;
+  {
+    f32x4 ha[MTA];
+    layer1_keep<MTA, KB>(ha, xn, SA, lr, q);
+    an = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
+  }
+  set_row2(xn, ns, valid ? an : 0.f, q);
+  const float qt = layer1_head<MT, KB>(xn, SCt, lr, q);
+  const float tgt = g.gamma * (1.f - tv) * qt;
+  // ---- q = C([s; a])
+  f32x4 h1[MT];
+  layer1_keep<MT, KB>(h1, xq, SC, lr, q);
+  const float qv = head<MT>(h1, SC.w2, SC.b2[0], q);
+  const float c = valid ? tgt - qv : 0.f;
+  const float dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
+  const bool rep = valid && q == 0;
+  float sv[5] = {rep ? c : 0.f, rep ? c * c : 0.f, rep ? rv : 0.f, rep ? rv * rv : 0.f, rep ? (rv + c) * (rv + c) : 0.f};
+  const int nslab = gridDim.x;
+  __syncthreads();                              // every wave is done with the weight images
+  // ---- dW2 / db2
+  out_row_grad<MT>(h1, dq, g.C.H, base, g.slab, nslab, 0, tid);
+  // ---- dz1 in place, dW1 / db1 = dz1 x [x; 1]^T over the 128 columns (two 64-column halves)
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float* wv = w2keep + 16 * m + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1[m][r] = h1[m][r] > 0.f ? wv[r] * dq : 0.f;
+  }
+  float* Lm = base;                             // DZ1 [HP][LDP]
+  float* Rm = base + HP * LDP;                  // Xaug [16 nR][LDP]
+  const int cw = (w & 3) * 16 + lr;
+  constexpr int NACC = (MT * 3 + 7) / 8;
+  f32x4 acc[NACC];
+  zero_(acc);
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if ((w >> 2) == half) {
+      stage_rows<MT>(Lm, h1, cw, q, -1);
+      stage_x2(Rm, xq, 16 * nR, cw, q, K0);
+    }
+    __syncthreads();
+    gemm_pass(acc, Lm, Rm, MT, nR, w, lr, q);
+  }
+  store_pass(acc, g.slab, nslab, MT, MT, nR, w, l);
+  // ---- loss statistics
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    for (int off = 32; off > 0; off >>= 1) sv[k] += __shfl_xor(sv[k], off);
+  __syncthreads();
+  float* red5 = base;
+  if (l == 0)
+    for (int k = 0; k < 5; ++k) red5[w * 8 + k] = sv[k];
+  __syncthreads();
+  if (tid < 8) {
+    float* st = g.slab + ((size_t)(4 * slab2_tiles(MT, nR)) * nslab + blockIdx.x) * 64;
+    float a = 0.f;
+    if (tid < 5)
+      for (int ww = 0; ww < FTHREADS / 64; ++ww) a += red5[ww * 8 + tid];
+    st[tid] = a;
+  }
+}
+
+// ------------------------------------------------------------------ actor pass
+template <int MT, int MTA, int KB>
+__global__ __launch_bounds__(FTHREADS) void ddpg2_actor_kernel(Fused2Args g) {
+  constexpr int LDK = 8 * KB + 4;
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
+  constexpr int HP = 16 * MT, HPa = 16 * MTA;
+  const int ns = g.ns, nRa = (ns + 1 + 15) / 16;
+  const int imgc = lds2_floats(HP, LDK);
+  const int stage = HPa * LDP + 16 * nRa * LDP;
+  const int reg0 = max(imgc, max(stage, 8 * HPa));
+  float* base = smem;
+  const Lds2 SC = carve2(base, HP, LDK);
+  const Lds2 SA = carve2(base + reg0, HPa, LDK);
+  float* red = SA.W1 + lds2_floats(HPa, LDK);
+  const int col = blockIdx.x * FCOLS + w * 16 + lr;
+  const bool valid = col < g.Bu;
+
+  float xs[K2MAX][2];
+  load_x2(xs, g.s, (size_t)col, ns, KB, q, valid);
+  load_net2(SA, g.A, HPa, LDK, tid);
+  load_net2(SC, g.C, HP, LDK, tid);
+  __syncthreads();
+  f32x4 ha[MTA];
+  layer1_keep<MTA, KB>(ha, xs, SA, lr, q);
+  const float aout = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
+  float x[K2MAX][2];
+#pragma unroll
+  for (int blk = 0; blk < K2MAX; ++blk) { x[blk][0] = xs[blk][0]; x[blk][1] = xs[blk][1]; }
+  set_row2(x, ns, valid ? aout : 0.f, q);
+  // q = C([s; a]) and da = sum_i W1c[i][ns] * relu'(h1_i) * w2c_i * dq, tile by tile (nothing of h1 is kept)
+  const float dq = valid ? -1.f / (float)g.Bu : 0.f;
+  float qacc = 0.f, da = 0.f;
+  layer1_head_da<MT, KB>(x, SC, ns, lr, q, qacc, da);
+  qacc += __shfl_xor(qacc, 16);
+  qacc += __shfl_xor(qacc, 32);
+  da += __shfl_xor(da, 16);
+  da += __shfl_xor(da, 32);
+  const float qv = qacc + SC.b2[0];
+  float st0 = (valid && q == 0) ? qv : 0.f;
+  const float dza2 = da * dq * (1.f - aout * aout);
+  const int nslab = gridDim.x;
+  __syncthreads();                              // the critic image may be overlaid now
+  out_row_grad<MTA>(ha, dza2, g.A.H, base, g.slab, nslab, 0, tid);
+#pragma unroll
+  for (int m = 0; m < MTA; ++m) {
+    const float* wv = SA.w2 + 16 * m + 4 * q;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ha[m][r] = ha[m][r] > 0.f ? wv[r] * dza2 : 0.f;
+  }
+  float* Lm = base;                             // DZA1 [HPa][LDP]
+  float* Rm = base + HPa * LDP;                 // Saug [16 nRa][LDP]
+  const int cw = (w & 3) * 16 + lr;
+  f32x4 acc[1];
+  zero_(acc);
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if ((w >> 2) == half) {
+      stage_rows<MTA>(Lm, ha, cw, q, -1);
+      stage_x2(Rm, xs, 16 * nRa, cw, q, ns);
+    }
+    __syncthreads();
+    gemm_pass(acc, Lm, Rm, MTA, nRa, w, lr, q);
+  }
+  store_pass(acc, g.slab, nslab, MTA, MTA, nRa, w, l);
+  st0 = block_sum(st0, red, tid);
+  if (tid == 0) {
+    float* st = g.slab + ((size_t)(4 * slab2_tiles(MTA, nRa)) * nslab + blockIdx.x) * 64;
+    st[0] = st0;
+    st[1] = st[2] = st[3] = st[4] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ slab reduction (+ ADAM + Polyak)
+struct Finish2Args {
+  const float* slabs;
+  int nslab, K0, H, MT, nR;
+  float* grads;
+  float scale;
+  int mode, Bu, quirk;
+  float* loss_out;
+  int apply;
+  float *p, *m, *v, *pt;
+  double eta, b1, b2, eps, omb1p, omb2p;
+  float rho, omr;
+};
+
+// Flux.Optimise.ADAM in Float64 (src/custom_nna.jl:23-24) and dest = rho dest + (1 - rho) src (src/PDEagent.jl:415-417);
+// the same arithmetic, without FMA contraction, as adam_kernel / polyak_kernel (mlp.hip)
+__device__ __forceinline__ void finish2_param(const Finish2Args& g, int i, float gi) {
+#pragma clang fp contract(off)
+  const double gd = (double)gi;
+  const float mt = (float)(g.b1 * (double)g.m[i] + (1.0 - g.b1) * gd);
+  const float vt = (float)(g.b2 * (double)g.v[i] + (1.0 - g.b2) * gd * gd);
+  g.m[i] = mt;
+  g.v[i] = vt;
+  const float delta = (float)((double)mt / g.omb1p / (sqrt((double)vt / g.omb2p) + g.eps) * g.eta);
+  const float pn = g.p[i] - delta;
+  g.p[i] = pn;
+  if (g.pt) g.pt[i] = g.rho * g.pt[i] + g.omr * pn;
+}
+
+// one block per chunk: 64 chunk elements x 16 slab groups, fixed-order combine -> deterministic
+__global__ __launch_bounds__(1024) void finish2_kernel(Finish2Args g) {
+  __shared__ float part[16][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int K0 = g.K0, H = g.H, MT = g.MT, nR = g.nR;
+  const int offb1 = H * K0, offW2 = offb1 + H, offb2 = offW2 + H;
+  const int c = blockIdx.x, T = c >> 2, r = c & 3;
+  int i = -1;
+  {
+    const int q = tx >> 4, lr = tx & 15;
+    if (T < MT) {
+      const int row = 4 * q + r, col = 16 * T + lr;
+      if (row == 0) i = col < H ? offW2 + col : (col == H ? offb2 : -1);
+    } else {
+      const int u = T - MT, ti = u / nR, tk = u - ti * nR;
+      const int row = 16 * ti + 4 * q + r, col = 16 * tk + lr;
+      if (row < H) i = col < K0 ? row * K0 + col : (col == K0 ? offb1 + row : -1);
+    }
+  }
+  if (__syncthreads_or(i >= 0)) {
+    float acc = 0.f;
+    if (i >= 0) {
+      const float* sp = g.slabs + (size_t)c * g.nslab * 64 + tx;
+      int z = ty;
+      for (; z + 240 < g.nslab; z += 256) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = sp[(size_t)(z + 16 * u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
+      for (; z < g.nslab; z += 16) acc += sp[(size_t)z * 64];
+    }
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && i >= 0) {
+      float a = 0.f;
+      for (int k = 0; k < 16; ++k) a += part[k][tx];
+      a *= g.scale;
+      g.grads[i] = a;
+      if (g.apply) finish2_param(g, i, a);
+    }
+  }
+  if (blockIdx.x == 0 && g.loss_out) {
+    __shared__ double red[5][256];
+    const int tid = threadIdx.x;
+    const float* stc = g.slabs + (size_t)(4 * (MT + MT * nR)) * g.nslab * 64;
+    double st[5] = {0, 0, 0, 0, 0};
+    if (tid < 256) {
+      for (int z = tid; z < g.nslab; z += 256)
+        for (int k = 0; k < 5; ++k) st[k] += (double)stc[(size_t)z * 64 + k];
+      for (int k = 0; k < 5; ++k) red[k][tid] = st[k];
+    }
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+      if (tid < sft)
+        for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + sft];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double inv = 1.0 / g.Bu;
+      if (g.mode == 0)
+        *g.loss_out = (float)(g.quirk ? red[1][0] * inv + 2.0 * (red[0][0] * inv) * (red[2][0] * inv) + red[3][0] * inv
+                                      : red[4][0] * inv);
+      else
+        *g.loss_out = (float)(-red[0][0] * inv);
+    }
+  }
+}
+
+// ADAM + Polyak from the flat gradient buffer (after an external all-reduce): same arithmetic as the fused finish
+__global__ void apply2_kernel(Finish2Args g, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) finish2_param(g, i, g.grads[i]);
+}
+
+// ------------------------------------------------------------------ host side
+static int mt2_of(int H) { return (H + 1 + 15) / 16; }
+
+static bool fused2_disabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PDEC_DISABLE_FUSED");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+bool fused2_supported(const Mlp* A, const Mlp* C) {
+  if (fused2_disabled()) return false;
+  if (A->dtype != PDEC_F32 || C->dtype != PDEC_F32 || A->L != 2 || C->L != 2) return false;
+  const int ns = A->dims[0];
+  if (A->dims[2] != 1 || C->dims[0] != ns + 1 || C->dims[2] != 1 || ns + 2 > 8 * K2MAX) return false;
+  if (A->acts[0] != PDEC_ACT_RELU || A->acts[1] != PDEC_ACT_TANH) return false;
+  if (C->acts[0] != PDEC_ACT_RELU || C->acts[1] != PDEC_ACT_IDENTITY) return false;
+  const int mt = mt2_of(C->dims[1]), mta = mt2_of(A->dims[1]);
+  return (mt == 22 || mt == 9) && (mta == 2 || mta == 1);
+}
+
+static Net2 net2_of(const Mlp* M) {
+  Net2 n;
+  n.p = M->params.as<float>();
+  n.K0 = M->dims[0]; n.H = M->dims[1];
+  n.kb = (n.K0 + 7) / 8;
+  return n;
+}
+
+template <int MT, int MTA, int KB>
+static size_t lds2_bytes(const Fused2Args& g, bool actor_pass) {
+  const int HP = 16 * MT, HPa = 16 * MTA, LDK = 8 * KB + 4;
+  const int imgc = lds2_floats(HP, LDK), imga = lds2_floats(HPa, LDK);
+  size_t f;
+  if (!actor_pass) {
+    const int nR = nr_of(g.C.K0), stage = HP * LDP + 16 * nR * LDP;
+    f = (size_t)std::max(2 * imgc, std::max(stage, 8 * HP)) + HP + imga + 8;
+  } else {
+    const int nRa = nr_of(g.A.K0), stage = HPa * LDP + 16 * nRa * LDP;
+    f = (size_t)std::max(imgc, std::max(stage, 8 * HPa)) + imga + 8;
+  }
+  return f * 4;
+}
+
+template <int MT, int MTA, int KB>
+static int launch2(Mlp* M, const Fused2Args& g, int grid, bool actor_pass) {
+  const size_t lds = lds2_bytes<MT, MTA, KB>(g, actor_pass);
+  PDEC_REQUIRE(lds <= 160 * 1024, "fused 2-layer pass needs %zu B of LDS", lds);
+  const void* kern = actor_pass ? reinterpret_cast<const void*>(ddpg2_actor_kernel<MT, MTA, KB>)
+                                : reinterpret_cast<const void*>(ddpg2_critic_kernel<MT, MTA, KB>);
+  static size_t attr_lds[2] = {0, 0};          // per template instantiation and pass
+  if (attr_lds[actor_pass] < lds) {
+    PDEC_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds[actor_pass] = lds;
+  }
+  ProfScope ps(M, actor_pass ? "ddpg2_actor_fused" : "ddpg2_critic_fused", true);
+  for (int rep = 0; rep < ps.reps; ++rep) {
+    if (actor_pass) hipLaunchKernelGGL((ddpg2_actor_kernel<MT, MTA, KB>), dim3(grid), dim3(FTHREADS), lds, M->stream, g);
+    else hipLaunchKernelGGL((ddpg2_critic_kernel<MT, MTA, KB>), dim3(grid), dim3(FTHREADS), lds, M->stream, g);
+  }
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+template <int KB>
+static int dispatch2k(Mlp* M, const Fused2Args& g, int grid, bool actor_pass, int mt, int mta) {
+  if (mt == 22 && mta == 2) return launch2<22, 2, KB>(M, g, grid, actor_pass);
+  if (mt == 22 && mta == 1) return launch2<22, 1, KB>(M, g, grid, actor_pass);
+  if (mt == 9 && mta == 2) return launch2<9, 2, KB>(M, g, grid, actor_pass);
+  return launch2<9, 1, KB>(M, g, grid, actor_pass);
+}
+// the number of 8-row k-blocks is a compile-time constant (2, 5 or 6: a smaller net runs the next larger variant
+// on zero-padded rows), so the MFMA chains carry no control flow
+static int dispatch2(Mlp* M, const Fused2Args& g, int grid, bool actor_pass, int mt, int mta) {
+  if (g.C.kb <= 2) return dispatch2k<2>(M, g, grid, actor_pass, mt, mta);
+  if (g.C.kb <= 5) return dispatch2k<5>(M, g, grid, actor_pass, mt, mta);
+  return dispatch2k<6>(M, g, grid, actor_pass, mt, mta);
+}
+
+static int launch_finish2(Mlp* M, Mlp* Mt, int nslab, int MT, int nR, double grad_scale, int mode, int Bu, int quirk,
+                          void* loss_dev, const AdamPolyak* ap) {
+  Finish2Args g{};
+  g.slabs = M->fslab.as<float>(); g.nslab = nslab; g.K0 = M->dims[0]; g.H = M->dims[1]; g.MT = MT; g.nR = nR;
+  g.grads = M->grads.as<float>(); g.scale = (float)grad_scale; g.mode = mode; g.Bu = Bu; g.quirk = quirk;
+  g.loss_out = (float*)loss_dev;
+  g.apply = ap != nullptr;
+  if (ap) {
+    if (M->bp[0] < 0) { M->bp[0] = ap->b1; M->bp[1] = ap->b2; }
+    g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
+    g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps; g.omb1p = 1.0 - M->bp[0]; g.omb2p = 1.0 - M->bp[1];
+    if (Mt) {
+      g.pt = Mt->params.as<float>();
+      const float r = (float)ap->rho;
+      g.rho = r; g.omr = 1.0f - r;
+    }
+  }
+  {
+    ProfScope ps(M, ap ? "fused2_finish" : "fused2_reduce");
+    hipLaunchKernelGGL(finish2_kernel, dim3(4 * slab2_tiles(MT, nR)), dim3(1024), 0, M->stream, g);
+  }
+  PDEC_HIP(hipGetLastError());
+  if (ap) {
+    M->bp[0] *= ap->b1;
+    M->bp[1] *= ap->b2;
+    M->fw_dirty = true;
+    if (Mt) Mt->fw_dirty = true;
+  }
+  return PDEC_OK;
+}
+
+bool fused2_net_supported(const Mlp* M) { return !fused2_disabled() && M->dtype == PDEC_F32 && M->L == 2; }
+
+int fused2_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap) {
+  Finish2Args g{};
+  g.grads = M->grads.as<float>();
+  g.apply = 1;
+  if (M->bp[0] < 0) { M->bp[0] = ap.b1; M->bp[1] = ap.b2; }
+  g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
+  g.eta = ap.eta; g.b1 = ap.b1; g.b2 = ap.b2; g.eps = ap.eps; g.omb1p = 1.0 - M->bp[0]; g.omb2p = 1.0 - M->bp[1];
+  if (Mt) {
+    g.pt = Mt->params.as<float>();
+    const float r = (float)ap.rho;
+    g.rho = r; g.omr = 1.0f - r;
+  }
+  {
+    ProfScope ps(M, "fused2_apply");
+    hipLaunchKernelGGL(apply2_kernel, dim3((M->nparams + 255) / 256), dim3(256), 0, M->stream, g, M->nparams);
+  }
+  PDEC_HIP(hipGetLastError());
+  M->bp[0] *= ap.b1;
+  M->bp[1] *= ap.b2;
+  M->fw_dirty = true;
+  if (Mt) Mt->fw_dirty = true;
+  return PDEC_OK;
+}
+
+int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
+                        const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,
+                        const AdamPolyak* apply) {
+  const int mt = mt2_of(C->dims[1]), mta = mt2_of(A->dims[1]), nR = nr_of(C->dims[0]);
+  const int grid = (Bu + FCOLS - 1) / FCOLS;
+  const size_t need = slab2_floats(mt, nR, grid) * 4;
+  if (C->fslab.bytes < need) PDEC_HIP(C->fslab.alloc(need));
+  Fused2Args g{};
+  g.C = net2_of(C); g.At = net2_of(At); g.Ct = net2_of(Ct); g.A = g.At;
+  g.s = (const float*)s; g.a = (const float*)a; g.r = (const float*)r; g.t = (const float*)t; g.sn = (const float*)sn;
+  g.Bu = Bu; g.ns = A->dims[0]; g.gamma = (float)gamma; g.quirk = quirk;
+  g.slab = C->fslab.as<float>();
+  if (quirk) {
+    float* rb = C->scratch.as<float>() + 40;      // device scalar behind the generic path's statistics and losses
+    ProfScope ps(C, "ddpg2_rmean");
+    hipLaunchKernelGGL(rmean_kernel, dim3(1), dim3(1024), 0, C->stream, (const float*)r, Bu, rb);
+    g.rbar = rb;
+  }
+  int rc = dispatch2(C, g, grid, false, mt, mta);
+  if (rc) return rc;
+  return launch_finish2(C, apply ? Ct : nullptr, grid, mt, nR, grad_scale, 0, Bu, quirk, loss_dev, apply);
+}
+
+int fused2_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double grad_scale, void* loss_dev,
+                       const AdamPolyak* apply) {
+  const int mt = mt2_of(C->dims[1]), mta = mt2_of(A->dims[1]), nRa = nr_of(A->dims[0]);
+  const int grid = (Bu + FCOLS - 1) / FCOLS;
+  const size_t need = slab2_floats(mta, nRa, grid) * 4;
+  if (A->fslab.bytes < need) PDEC_HIP(A->fslab.alloc(need));
+  Fused2Args g{};
+  g.C = net2_of(C); g.A = net2_of(A); g.At = g.A; g.Ct = g.C;
+  g.s = (const float*)s; g.Bu = Bu; g.ns = A->dims[0];
+  g.slab = A->fslab.as<float>();
+  int rc = dispatch2(C, g, grid, true, mt, mta);       // on the critic's stream object (shared stream, checked by the caller)
+  if (rc) return rc;
+  return launch_finish2(A, apply ? At : nullptr, grid, mta, nRa, grad_scale, 1, Bu, 0, loss_dev, apply);
+}
+
+}  // namespace pdec

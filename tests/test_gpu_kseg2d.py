@@ -135,6 +135,15 @@ def test_properties_at_full_size(pkg):
     out, _ = env.do_step(y, p)
     outT, _ = env.do_step(y.transpose(1, 2).contiguous(), p.transpose(1, 2).contiguous())
     assert float((outT.transpose(1, 2) - out).abs().max()) <= 1e-12
+    import os
     env32 = pkg.PDEenv(setup, B=B, dtype=torch.float32)
-    o2, _ = env32.do_step(y.float(), p.float())
+    o1, _ = env32.do_step(y.float(), p.float())
+    assert float((o1.double() - out).abs().max()) <= 2e-5
+    os.environ["PDEC_KSEG2D_NSUB2"] = "1"
+    try:
+        env32b = pkg.PDEenv(setup, B=B, dtype=torch.float32)
+    finally:
+        del os.environ["PDEC_KSEG2D_NSUB2"]
+    o2, _ = env32b.do_step(y.float(), p.float())
     assert float((o2.double() - out).abs().max()) <= 2e-5
+    assert float((o2 - o1).abs().max()) <= 2e-6

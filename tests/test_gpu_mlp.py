@@ -184,16 +184,25 @@ def test_policy_act_rng_equals_randn_plus_act(pkg, dims_scale):
     assert np.abs(ref - ref0).max() > 0.1
 
 
+NETS = [(3, 1.6, 7.0, False, 1500),      # C2: 3->16->16->1 / 4->140->140->1 (3-layer fused MFMA passes)
+        (36, 2.0, 17.0, True, 1500),     # 2-D Keller-Segel: 36->20->1 / 37->340->1 (2-layer fused MFMA passes)
+        (12, 2.0, 17.0, True, 777),      # Keller-Segel10_16: 12->20->1 / 13->340->1
+        (9, 1.8, 17.0, True, 300),       # Fluid: 9->18->1 / 10->340->1
+        (1, 0.6, 7.0, True, 4100),       # KS22: 1->6->1 / 2->140->1
+        (40, 1.0, 7.0, True, 200)]       # widest supported window: 40->10->1 / 41->140->1 (6 k-blocks)
+
+
 @pytest.mark.parametrize("quirk", [1, 0])
-def test_update_async_and_split_sequence_agree(pkg, quirk):
+@pytest.mark.parametrize("ns,sa,sc,drop,Bu", NETS)
+def test_update_async_and_split_sequence_agree(pkg, quirk, ns, sa, sc, drop, Bu):
     """pdec_ddpg_update_async (4 launches: reduce+ADAM+Polyak fused) and the data-parallel split sequence
     critic_grads -> [all-reduce] -> adam_polyak_step -> actor_grads -> [all-reduce] -> adam_polyak_step
     leave bit-identical networks (replicas must not drift), and both match the oracle"""
     from oracle import nn
     rng = np.random.default_rng(21)
-    ns, na, Bu = 3, 1, 1500
-    da, aa = nn.layer_sizes(ns, na, 1.6, True, False)
-    dc, ac = nn.layer_sizes(ns, na, 7.0, False, False)
+    na = 1
+    da, aa = nn.layer_sizes(ns, na, sa, True, drop)
+    dc, ac = nn.layer_sizes(ns, na, sc, False, drop)
     dtype, npdt = torch.float32, np.float32
     L = pkg._lib
     nets = []

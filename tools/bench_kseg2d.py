@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--B", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtypes", default="f32,f64")
+    ap.add_argument("--full", action="store_true", help="whole RL step: actor on all B*A columns, env step, one DDPG "
+                    "update on the B*A fresh transitions (fp32; actor 36->20->1, critic 37->340->1 as in the 1-D script)")
     args = ap.parse_args()
     pkg = importlib.import_module("distributedconvrl-pde-control_amd")
     L = pkg._lib
@@ -62,5 +64,60 @@ def main():
             "finite": bool(torch.isfinite(env.y).all().item()), "max_abs_y": float(env.y.abs().max().item())}))
 
 
+def full(args):
+    pkg = importlib.import_module("distributedconvrl-pde-control_amd")
+    L = pkg._lib
+    dt = torch.float32
+    setup = pkg.KellerSegel2DSetup(nx=args.nx, ny=args.nx)
+    rng = np.random.default_rng(0)
+    y0 = np.ascontiguousarray(np.moveaxis(setup.generate_random_init(rng, args.B), 1, -1))
+    env = pkg.PDEenv(setup, B=args.B, dtype=dt, y0=y0)
+    agent = pkg.create_agent(setup=setup, B=args.B, rng=np.random.default_rng(1), dtype=dt, device="cuda:0",
+                             start_steps=-1, noise_seed=7, trajectory_length=1)
+    policy = agent.policy
+    policy.act_noise = 0.3
+    actor = policy.behavior_actor.model
+    ns, A = setup.state_shape
+    cols = args.B * A
+    acts = [torch.empty((cols, 1), dtype=dt, device="cuda:0") for _ in range(2)]
+    term = torch.zeros(cols, dtype=dt, device="cuda:0")
+    env.set_terminal_out(term)
+    off = [0]
+    k = [0]
+
+    def step():
+        a = acts[k[0] % 2]
+        k[0] += 1
+        L.check(env.lib.pdec_policy_act_rng(actor.handle, L.ptr(env.state), cols, policy.act_noise, policy.act_limit, 1, 7,
+                                            off[0], L.ptr(a)))
+        off[0] += (cols + 3) // 4
+        s_t = env.state
+        env(a.view(env._ashape), adopt=True)
+        policy.update(dict(state=s_t.view(cols, ns), action=env.action.view(cols, 1), reward=env.reward.view(cols),
+                           terminal=term, next_state=env.state.view(cols, ns)))
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / args.steps
+    al, cl = policy.losses()
+    print(json.dumps({"case": f"kseg2d full RL step {args.nx}x{args.nx} B={args.B} f32 A={A} cols={cols} "
+                              f"actor {policy.behavior_actor.model.dims} critic {policy.behavior_critic.model.dims}",
+                      "env_steps_per_s": args.B / sec, "ms_per_step": sec * 1e3, "actor_loss": al, "critic_loss": cl,
+                      "finite": bool(torch.isfinite(env.y).all().item())}))
+
+
 if __name__ == "__main__":
+    if "--full" in sys.argv:
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--nx", type=int, default=256)
+        ap.add_argument("--B", type=int, default=128)
+        ap.add_argument("--steps", type=int, default=10)
+        ap.add_argument("--full", action="store_true")
+        full(ap.parse_args())
+        sys.exit(0)
     main()
