@@ -49,6 +49,7 @@ SIGNATURES = {
     "pdec_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _pd, _pd, _pi32],
     "pdec_fluid_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _pd, _pi32, _pd, _pi32, _pi32],
     "pdec_kseg2d_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _i, _pi32, _pi32, _i, _pi32],
+    "pdec_fluid_ic": [Handle, _pd, _i, _vp],
     "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],

@@ -676,11 +676,41 @@ __global__ __launch_bounds__(256) void wave_fft_debug_kernel(const C2<double>* _
 }
 
 // ------------------------------------------------------------------ host side
+
+// Episode initialiser on the device: omega = sum over vortices of the 9 periodic images of a
+// Taylor vortex U/a (2 - r^2/a^2) exp((1 - r^2/a^2)/2)   (src/fluid_rk4.jl:54-69, ic(...) :72-120).  One thread per
+// cell, same summation order as the reference (vortex outer, image offsets i, j inner); vort [B][nv][4] = x0, y0, a, U.
+template <class T>
+__global__ void fluid_ic_kernel(int n, int nv, T Lx, T Ly, const T* __restrict__ vort, T* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char ic_smem[];
+  T* sv = reinterpret_cast<T*>(ic_smem);
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 4 * nv; i += blockDim.x) sv[i] = vort[(size_t)b * 4 * nv + i];
+  __syncthreads();
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  const int jx = idx / n, iy = idx - jx * n;            // memory [nx][ny]: y is the fast axis
+  const T x = (T)jx * (Lx / (T)n), y = (T)iy * (Ly / (T)n);
+  T total = 0;
+  for (int v = 0; v < nv; ++v) {
+    const T x0 = sv[4 * v], y0 = sv[4 * v + 1], a0 = sv[4 * v + 2], U = sv[4 * v + 3];
+    T omg = 0;
+    for (int i = -1; i <= 1; ++i)
+      for (int j = -1; j <= 1; ++j) {
+        const T ddx = x - x0 - (T)i * Lx, ddy = y - y0 - (T)j * Ly;
+        const T r2 = ddx * ddx + ddy * ddy;
+        omg = omg + U / a0 * ((T)2 - r2 / (a0 * a0)) * exp((T)0.5 * ((T)1 - r2 / (a0 * a0)));
+      }
+    total = total + omg;
+  }
+  out[(size_t)b * n * n + idx] = total;
+}
+
 struct FluidEnv : Env {
   int n = 0, p = 0, nl = 0, TL = 0, TLn = 0, BH = 0, BW = 0, nb1 = 0;
   FftPlan plp, pln;
   DevBuf k, twp, twn, sbox, sorg, abox, aorg, a2s_d, blkptr, blkidx;
-  DevBuf W, W2, fs, acc, yreal, tmpc, dots, phat;
+  DevBuf W, W2, fs, acc, yreal, tmpc, dots, phat, icv;
   size_t lds_p = 0, lds_n = 0;
   int wave_E = 0, wave_Q = 0;     // != 0: the one-line-per-wave transforms serve the padded length p
 };
@@ -1048,5 +1078,31 @@ extern "C" int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, i
 #undef WFD
   PDEC_HIP(hipGetLastError());
   PDEC_HIP(hipDeviceSynchronize());
+  return PDEC_OK;
+}
+
+// ic(caseno): spectrum of the sum of Taylor vortices (src/fluid_rk4.jl:72-120 with the random draws made by the
+// caller).  vortices: HOST array [B][nv][4] of (x0, y0, a0, U_max); y_out: device [B][nx][ny][2].
+extern "C" int pdec_fluid_ic(pdec_handle h, const double* vortices, int nv, void* y_out) {
+  Env* E0 = lookup_as<Env>(h, Kind::Env);
+  if (!E0 || E0->cfg.pde_kind != PDEC_PDE_FLUID_RK4) { set_error("pdec_fluid_ic: not a fluid env handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(vortices && y_out && nv >= 1 && nv <= 1024, "pdec_fluid_ic: bad arguments (1 <= nv <= 1024)");
+  typedef C2<double> Z;
+  FluidEnv& E = static_cast<FluidEnv&>(*E0);
+  const pdec_env_cfg& c = E.cfg;
+  const size_t vb = (size_t)c.B * nv * 4 * sizeof(double);
+  if (E.icv.bytes < vb) PDEC_HIP(E.icv.alloc(vb));
+  PDEC_HIP(hipMemcpyAsync(E.icv.p, vortices, vb, hipMemcpyHostToDevice, E.stream));
+  const FluidDev<double> d = fluid_dev(E);
+  const int gt = (E.n + E.TLn - 1) / E.TLn;
+  ProfScope ps(&E, "fluid_ic");
+  hipLaunchKernelGGL(fluid_ic_kernel<double>, dim3((E.n * E.n + 255) / 256, c.B), dim3(256), (size_t)nv * 4 * sizeof(double), E.stream,
+                     E.n, nv, c.Lx, c.Lx, E.icv.as<double>(), E.yreal.as<double>());
+  hipLaunchKernelGGL((fluid_fft_fast_kernel<double, -1, true>), dim3(gt, c.B), dim3(FL_NTH), E.lds_n, E.stream, d, E.yreal.p,
+                     E.tmpc.as<Z>());
+  hipLaunchKernelGGL((fluid_fft_slow_kernel<double, -1, false>), dim3(gt, c.B), dim3(FL_NTH), E.lds_n, E.stream, d,
+                     E.tmpc.as<Z>(), y_out, 1.0);
+  PDEC_HIP(hipGetLastError());
+  PDEC_HIP(hipStreamSynchronize(E.stream));      // the host array may be reused by the caller
   return PDEC_OK;
 }

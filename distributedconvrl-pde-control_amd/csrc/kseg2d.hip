@@ -80,7 +80,9 @@ struct alignas(16) QuadT {  // four consecutive scalars of one plane = two cell 
   V2<T> a, b;
 };
 
-// MODE 0: integrate NSUB sub-steps, 1: right-hand side only (KATs)
+// MODE 0: integrate NSUB sub-steps, 1: right-hand side only (KATs), 2: integrate with the forcing synthesised from the
+// action table (p_in = action [B][A]; p = agent_power * action[cell_act]: the [ny][nx] int table is shared by all
+// trajectories and stays in L2, so the per-sub-step HBM reads drop from 3 to 2 scalars per cell)
 template <class T, int NSUB, int MODE>
 __global__ __launch_bounds__(K2_NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<T>* __restrict__ y_in,
                                                            const T* __restrict__ p_in, C2<T>* __restrict__ y_out,
@@ -91,8 +93,14 @@ __global__ __launch_bounds__(K2_NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void 
   // stage values, one plane per species (a thread's 4 cells = one conflict-free 128-bit access per plane)
   T* Su = reinterpret_cast<T*>(k2_smem);        // [RY][RXP]
   T* Sv = Su + RY * RXP;                        // [RY][RXP]
-  const int tid = threadIdx.x, b = blockIdx.z;
-  const int gx0 = blockIdx.x * K2_TX - H, gy0 = blockIdx.y * K2_TY - H;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive
+  // LOGICAL tiles -- the 16 tiles of a trajectory, which share their halos -- are given to one XCD
+  const int ntx = (e.nx + K2_TX - 1) / K2_TX, nty = (e.ny + K2_TY - 1) / K2_TY;
+  int lid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lid = (lid & 7) * (gridDim.x >> 3) + (lid >> 3);
+  const int b = lid / (ntx * nty), tl = lid - b * (ntx * nty), tyi = tl / ntx, txi = tl - tyi * ntx;
+  const int tid = threadIdx.x;
+  const int gx0 = txi * K2_TX - H, gy0 = tyi * K2_TY - H;
   // part of the region that lies inside the domain (local coordinates); neighbour indices clamp to it, which IS
   // the zero-flux rule on a domain edge and only feeds halo cells (never used) on an inner tile edge
   const int lox = max(0, -gx0), hix = min(RX, e.nx - gx0) - 1;
@@ -112,7 +120,17 @@ __global__ __launch_bounds__(K2_NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void 
     if (act[k]) {
       const size_t g = fo + (size_t)(gy0 + sr[k]) * e.nx + (gx0 + sc[k]);
       const Quad<T> q = *reinterpret_cast<const Quad<T>*>(y_in + g);
-      const QuadT<T> qp = *reinterpret_cast<const QuadT<T>*>(p_in + g);
+      QuadT<T> qp;
+      if (MODE == 2) {
+        const int4 ca = *reinterpret_cast<const int4*>(e.cell_act + (size_t)(gy0 + sr[k]) * e.nx + (gx0 + sc[k]));
+        const T* ab = p_in + (size_t)b * e.A;
+        qp.a.x = ca.x >= 0 ? e.agent_power * ab[ca.x] : (T)0;
+        qp.a.y = ca.y >= 0 ? e.agent_power * ab[ca.y] : (T)0;
+        qp.b.x = ca.z >= 0 ? e.agent_power * ab[ca.z] : (T)0;
+        qp.b.y = ca.w >= 0 ? e.agent_power * ab[ca.w] : (T)0;
+      } else {
+        qp = *reinterpret_cast<const QuadT<T>*>(p_in + g);
+      }
       u0[k][0].x = q.c[0].x; u0[k][0].y = q.c[1].x; u0[k][1].x = q.c[2].x; u0[k][1].y = q.c[3].x;
       v0[k][0].x = q.c[0].y; v0[k][0].y = q.c[1].y; v0[k][1].x = q.c[2].y; v0[k][1].y = q.c[3].y;
       pp[k][0] = qp.a; pp[k][1] = qp.b;
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(K2_NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void 
       bad |= !(fabs(q.c[i].x) <= e.max_value && fabs(q.c[i].y) <= e.max_value);
     *reinterpret_cast<Quad<T>*>(y_out + g) = q;
   }
-  if (MODE == 0 && last && done && e.check_max == 1) {
+  if (MODE != 1 && last && done && e.check_max == 1) {
     if (__any(bad) && (tid & 63) == 0) atomicOr(done + b, 1);
   }
 }
@@ -310,7 +328,7 @@ static constexpr size_t k2_lds(size_t pair_bytes) {   // two planes [RY][RX + 4]
 
 template <class T, int NSUB, int MODE>
 static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_out, int32_t* done, int last) {
-  const dim3 grid((E.nx + K2_TX - 1) / K2_TX, (E.ny + K2_TY - 1) / K2_TY, E.cfg.B);
+  const dim3 grid(((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2_TY - 1) / K2_TY) * E.cfg.B);
   hipLaunchKernelGGL((kseg2d_rk4_kernel<T, NSUB, MODE>), grid, dim3(K2_NT), k2_lds<NSUB>(2 * sizeof(T)), E.stream, k2_dev<T>(E),
                      (const C2<T>*)y_in, (const T*)p, (C2<T>*)y_out, done, last);
   PDEC_HIP(hipGetLastError());
@@ -318,8 +336,9 @@ static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_
 }
 
 template <class T>
-static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, void* y_out, int32_t* done) {
-  // K sub-steps, ping-pong between y_out and the scratch field so that the last launch writes y_out
+static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, const void* action, void* y_out, int32_t* done) {
+  // K sub-steps, ping-pong between y_out and the scratch field so that the last launch writes y_out; with `action`
+  // the forcing is synthesised in the kernel (MODE 2) instead of being read from the p field
   const int K = E.cfg.K, ns = E.nsub;
   const int launches = (K + ns - 1) / ns;
   const size_t bytes = (size_t)E.cfg.B * E.ny * E.nx * 2 * sizeof(T);
@@ -327,17 +346,20 @@ static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, void* y_o
   if (done) PDEC_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * E.cfg.B, E.stream));
   ProfScope ps(&E, "kseg2d_rk4");
   const void* src = y_in;
+  const void* f = action ? action : p;
   int left = K;
   for (int l = 0; l < launches; ++l) {
     void* dst = ((launches - 1 - l) & 1) ? E.ytmp.p : y_out;
     const int last = l == launches - 1;
     int rc;
+    const bool two = sizeof(T) == 4 && left >= 2 && ns == 2;
     if constexpr (sizeof(T) == 4) {
-      if (left >= 2 && ns == 2) { rc = k2_launch_rk4<T, 2, 0>(E, src, p, dst, done, last); left -= 2; }
-      else { rc = k2_launch_rk4<T, 1, 0>(E, src, p, dst, done, last); left -= 1; }
+      if (two) rc = action ? k2_launch_rk4<T, 2, 2>(E, src, f, dst, done, last) : k2_launch_rk4<T, 2, 0>(E, src, f, dst, done, last);
+      else rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last);
     } else {
-      rc = k2_launch_rk4<T, 1, 0>(E, src, p, dst, done, last); left -= 1;
+      rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last);
     }
+    left -= two ? 2 : 1;
     if (rc) return rc;
     src = dst;
   }
@@ -394,7 +416,7 @@ int kseg2d_rhs_eval(Env& E0, const void* y, const void* p, void* out) {
 int kseg2d_pde_step(Env& E0, const void* y_in, const void* p, void* y_out, int32_t* done) {
   Kseg2dEnv& E = as_k2(E0);
   PDEC_REQUIRE(y_in != y_out, "kseg2d: y_out must not alias y_in");
-  return K2_DISPATCH(k2_integrate, y_in, p, y_out, done);
+  return K2_DISPATCH(k2_integrate, y_in, p, nullptr, y_out, done);
 }
 
 int kseg2d_env_step(Env& E0, const void* y_in, const void* action, const void* action_prev, const void* state_prev,
@@ -414,7 +436,12 @@ int kseg2d_env_step(Env& E0, const void* y_in, const void* action, const void* a
   }
   int rc;
   if ((rc = kseg2d_actuate(E0, action, ph))) return rc;                                 // src/PDEenv.jl:199
-  if ((rc = kseg2d_pde_step(E0, y_in, ph, y_out, dn))) return rc;                       // :216-218 (zeroes done)
+  PDEC_REQUIRE(y_in != y_out, "kseg2d: y_out must not alias y_in");
+  // fp64 (HBM-bound): the forcing is synthesised in the kernel from the action table; fp32: reading the p field
+  // measured faster than the two-level gather (PDEC_KSEG2D_GATHER=0/1 overrides)
+  static const char* gv = getenv("PDEC_KSEG2D_GATHER");
+  const bool gather = gv ? gv[0] == '1' : E.cfg.dtype == PDEC_F64;
+  if ((rc = K2_DISPATCH(k2_integrate, y_in, ph, gather ? action : nullptr, y_out, dn))) return rc;   // :216-218 (zeroes done)
   if ((rc = K2_DISPATCH(k2_sense, y_out, action, action_prev, state_prev, state_out, reward_out, dn))) return rc;   // :220-222
   if (E.term_out && dn) {
     const int nA = E.cfg.B * E.cfg.A;
@@ -484,6 +511,9 @@ extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, i
   if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 1, 1>, k2_lds<1>(8)))) return rc;
   if ((rc = set_lds((const void*)kseg2d_rk4_kernel<double, 1, 0>, k2_lds<1>(16)))) return rc;
   if ((rc = set_lds((const void*)kseg2d_rk4_kernel<double, 1, 1>, k2_lds<1>(16)))) return rc;
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 1, 2>, k2_lds<1>(8)))) return rc;
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 2, 2>, k2_lds<2>(8)))) return rc;
+  if ((rc = set_lds((const void*)kseg2d_rk4_kernel<double, 1, 2>, k2_lds<1>(16)))) return rc;
   *h = register_object(std::move(E));
   return PDEC_OK;
 }

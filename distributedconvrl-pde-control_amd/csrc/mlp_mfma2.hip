@@ -313,7 +313,6 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
   const Lds2 SC = carve2(base, HP, LDK), SCt = carve2(base + imgc, HP, LDK);
   float* w2keep = base + reg0;                 // w2 of the behaviour critic survives the overlay   [HP]
   const Lds2 SA = carve2(w2keep + HP, HPa, LDK);
-  float* red = SA.W1 + lds2_floats(HPa, LDK);   // [8]
   const int col = blockIdx.x * FCOLS + w * 16 + lr;
   const bool valid = col < g.Bu;
 

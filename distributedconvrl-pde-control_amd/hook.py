@@ -47,10 +47,13 @@ class PDEhook:
                 self.bestNNA = copy.deepcopy(agent.policy.behavior_actor)
         elif stage == PRE_EPISODE_STAGE:                        # :42-49
             if self.use_random_init:
-                y0 = env.setup.generate_random_init(self.init_rng, env.B)
-                if y0.ndim == 3:
-                    y0 = np.swapaxes(y0, 1, 2)
-                env.y0 = env._as_batch(y0, env._yshape)
+                if hasattr(env.setup, "random_init_device"):   # initialiser kernel (row F4): no host field generation
+                    env.y0 = env.setup.random_init_device(env, self.init_rng)
+                else:
+                    y0 = env.setup.generate_random_init(self.init_rng, env.B)
+                    if y0.ndim == 3:
+                        y0 = np.swapaxes(y0, 1, 2)
+                    env.y0 = env._as_batch(y0, env._yshape)
                 env.y.copy_(env.y0)
                 env.state.copy_(env.featurize(env.y, env.state if env.setup.temporal_steps > 1 else None))
         elif stage == POST_ACT_STAGE:                           # :51-63

@@ -127,6 +127,34 @@ class FluidSetup:
             out = out + self.taylorvtx(x0, y0, a0, rng.random() * 2 - 1.0)
         return out
 
+    def ic_vortices(self, caseno, rng, B=1):
+        """the vortex table [B, nv, 4] = (x0, y0, a0, U_max) of ic(caseno) with the same draws, in the same order,
+        as `ic` above (src/fluid_rk4.jl:72-120); input of the device initialiser pdec_fluid_ic"""
+        Lx, Ly = self.Lx, self.Ly
+        out = []
+        for _ in range(B):
+            if caseno == 1:
+                v = [(Lx / 2, Ly / 2, Lx / 8, 1.0)]
+            elif caseno == 2:
+                v = [(Lx / 2, 0.4 * Ly, Lx / 10, 1.0), (Lx / 2, 0.6 * Ly, Lx / 10, 1.0)]
+            else:
+                v = []
+                for _ in range(30 if caseno == 3 else 50):
+                    x0, y0 = rng.random() * Lx, rng.random() * Ly
+                    a0 = Lx / 20 if caseno == 3 else Lx / 20 * (0.5 + rng.random())
+                    v.append((x0, y0, a0, rng.random() * 2 - 1.0))
+            out.append(v)
+        return np.ascontiguousarray(out, dtype=np.float64)
+
+    def random_init_device(self, env, rng):
+        """generate_random_init (FluidSetup.jl:386-394) evaluated on the GPU: returns a device tensor shaped like env.y"""
+        import ctypes as C
+        import torch
+        v = self.ic_vortices(4 if self.evaluation else 3, rng, env.B)
+        out = torch.empty_like(env.y)
+        _lib.check(env.lib.pdec_fluid_ic(env.handle, v.ctypes.data_as(C.POINTER(C.c_double)), v.shape[1], _lib.ptr(out)))
+        return out
+
     # shapes of the RL.jl-facing arrays (per trajectory, Julia shapes)
     @property
     def n_actuators(self):

@@ -149,6 +149,11 @@ int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, int ny, int 
                            const int32_t* sensor_x, const int32_t* sensor_y, int half_window,
                            const int32_t* a2s);
 
+/* Fluid episode initialiser ic(caseno) (src/fluid_rk4.jl:72-120; taylorvtx :54-69) on the device: y_out[B][nx][ny][2]
+ * = fft2 of the sum over nv vortices (9 periodic images each).  vortices: HOST [B][nv][4] = (x0, y0, a0, U_max), the
+ * random draws of ic(3)/ic(4) made by the caller (scripts/Fluid/setup/FluidSetup.jl:386-394 generate_random_init). */
+int pdec_fluid_ic(pdec_handle h, const double* vortices, int nv, void* y_out);
+
 /* prepare_action(; env): p[B][N] from action[B][A]      (KSSetup.jl:231-245) */
 int pdec_actuate(pdec_handle h, const void* action, void* p_out);
 /* do_step(env): y_out[B][n_species*N] from y_in, p[B][N]; done[B] int32 (bit0 = blow-up,

@@ -176,3 +176,26 @@ def test_wave_fft_engine_matches_numpy(pkg, n):
     got = out.cpu().numpy()
     ref = np.fft.ifft(x, axis=1) * n
     assert np.abs(got[..., 0] + 1j * got[..., 1] - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_device_initialiser_matches_host_ic(pkg):
+    """pdec_fluid_ic (taylorvtx sum + fft2 on the GPU) against the host restatement of ic(3) / ic(4) with the same draws"""
+    import ctypes as C
+    setup = pkg.FluidSetup(nx=64, sensors_per_axis=4, oversampling=2)
+    B = 3
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float64)
+    for case in (3, 4, 2):
+        v = setup.ic_vortices(case, np.random.default_rng(7), B)
+        ref = np.stack([setup.ic(case, np.random.default_rng(7))] + [None] * 0)      # first trajectory: same stream prefix
+        out = torch.empty_like(env.y)
+        pkg._lib.check(env.lib.pdec_fluid_ic(env.handle, v.ctypes.data_as(C.POINTER(C.c_double)), v.shape[1], pkg._lib.ptr(out)))
+        got = out[0].cpu().numpy()
+        got = (got[..., 0] + 1j * got[..., 1]).T
+        assert np.abs(got - ref[0]).max() <= 1e-11 * np.abs(ref[0]).max()
+    setup.evaluation = False
+    y0 = setup.random_init_device(env, np.random.default_rng(3))
+    assert y0.shape == env.y.shape and bool(torch.isfinite(y0).all())
+    # Hermitian spectrum of a real field: the inverse transform has no imaginary part
+    z = y0[1].cpu().numpy()
+    f = np.fft.ifft2((z[..., 0] + 1j * z[..., 1]).T)
+    assert np.abs(f.imag).max() <= 1e-12 * np.abs(f.real).max()
