@@ -275,10 +275,41 @@ __host__ __device__ inline int nr_of(int K0) { return (K0 + 1 + 15) / 16; }
 __host__ __device__ inline int slab2_tiles(int MT, int nR) { return MT + MT * nR; }
 static inline size_t slab2_floats(int MT, int nR, int nslab) { return ((size_t)4 * slab2_tiles(MT, nR) + 1) * nslab * 64; }
 
-// output-row gradient dW2/db2 = sum_cols g[col] * [h; 1]: DPP sum over a wave's 16 columns, LDS over the 8 waves
+#define CPWMAX 4           // column chunks (of 128) one workgroup walks through: the weight images are loaded once per
+                           // workgroup and the partial gradients of all its chunks share one slab
+#define LDQ 40             // leading dim of the 32-column staging images (8 mod 16 floats: conflict-free ds_read_b128)
+
+// D[i][k] += sum over NC16 * 16 staged columns L[i][c] * R[k][c] (images [row][LD]); wave w takes tiles w, w+8, ...
+template <int NACC, int LD, int NC16>
+__device__ __forceinline__ void gemm_cols(f32x4 (&acc)[NACC], const float* L, const float* R, int nL, int nR, int w, int lr,
+                                          int q) {
+#pragma unroll
+  for (int pp = 0; pp < NACC; ++pp) {
+    const int p = w + 8 * pp;
+    if (p < nL * nR) {
+      const int ti = p / nR, tk = p - ti * nR;
+      const float* lrow = L + (16 * ti + lr) * LD + 4 * q;
+      const float* rrow = R + (16 * tk + lr) * LD + 4 * q;
+      f32x4 a = acc[pp];
+#pragma unroll
+      for (int t = 0; t < NC16; ++t) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(lrow + 16 * t);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(rrow + 16 * t);
+        a = mfma4(av[0], bv[0], a);
+        a = mfma4(av[1], bv[1], a);
+        a = mfma4(av[2], bv[2], a);
+        a = mfma4(av[3], bv[3], a);
+      }
+      acc[pp] = a;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// output-row gradient dW2/db2 += sum_cols g[col] * [h; 1]: DPP sum over a wave's 16 columns, LDS over the 8 waves,
+// accumulated over the workgroup's chunks in dacc [HP] (fixed order -> deterministic)
 template <int MT>
-__device__ __forceinline__ void out_row_grad(const f32x4 (&h)[MT], float g, int H, float* redA, float* slab, int nslab, int T0,
-                                             int tid) {
+__device__ __forceinline__ void out_row_grad(const f32x4 (&h)[MT], float g, int H, float* redA, float* dacc, int tid) {
   const int w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4, HP = 16 * MT;
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -290,14 +321,38 @@ __device__ __forceinline__ void out_row_grad(const f32x4 (&h)[MT], float g, int 
     }
   __syncthreads();
   for (int i = tid; i < HP; i += FTHREADS) {
-    float a = 0.f;
+    float a = dacc[i];
 #pragma unroll
     for (int ww = 0; ww < FTHREADS / 64; ++ww) a += redA[ww * HP + i];
-    slab[((size_t)(4 * (T0 + (i >> 4))) * nslab + blockIdx.x) * 64 + (i & 15)] = a;   // tile i/16, register 0, lane i%16
+    dacc[i] = a;
   }
+}
+__device__ __forceinline__ void store_row(const float* dacc, int HP, float* slab, int nslab, int T0, int tid) {
+  for (int i = tid; i < HP; i += FTHREADS)
+    slab[((size_t)(4 * (T0 + (i >> 4))) * nslab + blockIdx.x) * 64 + (i & 15)] = dacc[i];   // tile i/16, register 0, lane i%16
+}
+
+template <int LD>
+__device__ __forceinline__ void stage_x2_ld(float* img, const float (&x)[K2MAX][2], int nrows, int cw, int q, int ones_row) {
+#pragma unroll
+  for (int blk = 0; blk < K2MAX; ++blk)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 8 * blk + 2 * q + t;
+      if (row < nrows) img[row * LD + cw] = row == ones_row ? 1.f : x[blk][t];
+    }
+}
+template <int MT, int LD>
+__device__ __forceinline__ void stage_rows_ld(float* img, const f32x4 (&v)[MT], int cw, int q) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) img[(16 * m + 4 * q + r) * LD + cw] = v[m][r];
 }
 
 // ------------------------------------------------------------------ critic pass
+// LDS: [critic image: Ct, then C][staging DZ1 [HP][LDQ] + Xaug [16 nR][LDQ] (overlaid by the [8][HP] row reduction)]
+//      [target actor image][dW2 accumulator [HP]]
 template <int MT, int MTA, int KB>
 __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
   constexpr int LDK = 8 * KB + 4;
@@ -305,80 +360,96 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
   constexpr int HP = 16 * MT, HPa = 16 * MTA;
   const int ns = g.ns, K0 = ns + 1, nR = (K0 + 1 + 15) / 16;
-  // region 0: the two critic images, later overlaid by redA and the dW1 staging images
   const int imgc = lds2_floats(HP, LDK);
-  const int stage = HP * LDP + 16 * nR * LDP;
-  const int reg0 = max(2 * imgc, max(stage, 8 * HP));
+  const int stg = max(HP * LDQ + 16 * nR * LDQ, 8 * HP);
   float* base = smem;
-  const Lds2 SC = carve2(base, HP, LDK), SCt = carve2(base + imgc, HP, LDK);
-  float* w2keep = base + reg0;                 // w2 of the behaviour critic survives the overlay   [HP]
-  const Lds2 SA = carve2(w2keep + HP, HPa, LDK);
-  const int col = blockIdx.x * FCOLS + w * 16 + lr;
-  const bool valid = col < g.Bu;
+  const Lds2 SC = carve2(base, HP, LDK);
+  float* Lm = base + imgc;                     // DZ1 [HP][LDQ]
+  float* Rm = Lm + HP * LDQ;                   // Xaug [16 nR][LDQ]
+  float* redA = Lm;
+  const Lds2 SA = carve2(base + imgc + stg, HPa, LDK);
+  float* dacc = SA.W1 + lds2_floats(HPa, LDK); // [HP]
+  const int nchunk = (g.Bu + FCOLS - 1) / FCOLS;
 
-  float xn[K2MAX][2], xq[K2MAX][2];
-  load_x2(xn, g.sn, (size_t)col, ns, KB, q, valid);
-  load_x2(xq, g.s, (size_t)col, ns, KB, q, valid);
-  const float av = valid ? g.a[col] : 0.f, rv = valid ? g.r[col] : 0.f, tv = valid ? g.t[col] : 0.f;
-  set_row2(xq, ns, av, q);
   load_net2(SA, g.At, HPa, LDK, tid);
-  load_net2(SCt, g.Ct, HP, LDK, tid);
-  load_net2(SC, g.C, HP, LDK, tid);
+  load_net2(SC, g.Ct, HP, LDK, tid);
+  for (int i = tid; i < HP; i += FTHREADS) dacc[i] = 0.f;
   const float rbar = g.quirk ? g.rbar[0] : 0.f;
-  __syncthreads();                              // the images are visible
-  for (int i = tid; i < HP; i += FTHREADS) w2keep[i] = SC.w2[i];
-
-  // ---- targets: a' = At(s'), qt = Ct([s'; a'])
-  float an;
-  {
-    f32x4 ha[MTA];
-    layer1_keep<MTA, KB>(ha, xn, SA, lr, q);
-    an = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
-  }
-  set_row2(xn, ns, valid ? an : 0.f, q);
-  const float qt = layer1_head<MT, KB>(xn, SCt, lr, q);
-  const float tgt = g.gamma * (1.f - tv) * qt;
-  // ---- q = C([s; a])
-  f32x4 h1[MT];
-  layer1_keep<MT, KB>(h1, xq, SC, lr, q);
-  const float qv = head<MT>(h1, SC.w2, SC.b2[0], q);
-  const float c = valid ? tgt - qv : 0.f;
-  const float dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
-  const bool rep = valid && q == 0;
-  float sv[5] = {rep ? c : 0.f, rep ? c * c : 0.f, rep ? rv : 0.f, rep ? rv * rv : 0.f, rep ? (rv + c) * (rv + c) : 0.f};
-  const int nslab = gridDim.x;
-  __syncthreads();                              // every wave is done with the weight images
-  // ---- dW2 / db2
-  out_row_grad<MT>(h1, dq, g.C.H, base, g.slab, nslab, 0, tid);
-  // ---- dz1 in place, dW1 / db1 = dz1 x [x; 1]^T over the 128 columns (two 64-column halves)
+  __syncthreads();
+  // ---- targets of every chunk: a' = At(s'), qt = Ct([s'; a'])
+  float tgt[CPWMAX];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const float* wv = w2keep + 16 * m + 4 * q;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h1[m][r] = h1[m][r] > 0.f ? wv[r] * dq : 0.f;
+  for (int j = 0; j < CPWMAX; ++j) {
+    const int chunk = blockIdx.x + j * gridDim.x;
+    tgt[j] = 0.f;
+    if (chunk < nchunk) {
+      const int col = chunk * FCOLS + w * 16 + lr;
+      const bool valid = col < g.Bu;
+      float xn[K2MAX][2];
+      load_x2(xn, g.sn, (size_t)col, ns, KB, q, valid);
+      const float tv = valid ? g.t[col] : 0.f;
+      f32x4 ha[MTA];
+      layer1_keep<MTA, KB>(ha, xn, SA, lr, q);
+      const float an = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
+      set_row2(xn, ns, valid ? an : 0.f, q);
+      const float qt = layer1_head<MT, KB>(xn, SC, lr, q);
+      tgt[j] = g.gamma * (1.f - tv) * qt;
+    }
   }
-  float* Lm = base;                             // DZ1 [HP][LDP]
-  float* Rm = base + HP * LDP;                  // Xaug [16 nR][LDP]
-  const int cw = (w & 3) * 16 + lr;
+  __syncthreads();                              // every wave is done with the target critic's image
+  load_net2(SC, g.C, HP, LDK, tid);
+  __syncthreads();
+  // ---- q = C([s; a]), dq, gradients, chunk by chunk
   constexpr int NACC = (MT * 3 + 7) / 8;
   f32x4 acc[NACC];
   zero_(acc);
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-    if ((w >> 2) == half) {
-      stage_rows<MT>(Lm, h1, cw, q, -1);
-      stage_x2(Rm, xq, 16 * nR, cw, q, K0);
+  float sv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const int cw = (w & 1) * 16 + lr;
+#pragma unroll 1
+  for (int j = 0; j < CPWMAX; ++j) {
+    const int chunk = blockIdx.x + j * gridDim.x;
+    if (chunk >= nchunk) break;
+    const float tgj = j == 0 ? tgt[0] : (j == 1 ? tgt[1] : (j == 2 ? tgt[2] : tgt[3]));
+    const int col = chunk * FCOLS + w * 16 + lr;
+    const bool valid = col < g.Bu;
+    float xq[K2MAX][2];
+    load_x2(xq, g.s, (size_t)col, ns, KB, q, valid);
+    const float av = valid ? g.a[col] : 0.f, rv = valid ? g.r[col] : 0.f;
+    set_row2(xq, ns, av, q);
+    f32x4 h1[MT];
+    layer1_keep<MT, KB>(h1, xq, SC, lr, q);
+    const float qv = head<MT>(h1, SC.w2, SC.b2[0], q);
+    const float c = valid ? tgj - qv : 0.f;
+    const float dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
+    if (valid && q == 0) { sv[0] += c; sv[1] += c * c; sv[2] += rv; sv[3] += rv * rv; sv[4] += (rv + c) * (rv + c); }
+    __syncthreads();                            // the previous chunk's tiles have been consumed
+    out_row_grad<MT>(h1, dq, g.C.H, redA, dacc, tid);      // dW2 / db2
+    // dz1 in place; dW1 / db1 += dz1 x [x; 1]^T over the 128 columns (four 32-column quarters)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float* wv = SC.w2 + 16 * m + 4 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1[m][r] = h1[m][r] > 0.f ? wv[r] * dq : 0.f;
     }
-    __syncthreads();
-    gemm_pass(acc, Lm, Rm, MT, nR, w, lr, q);
+    for (int qq = 0; qq < 4; ++qq) {
+      __syncthreads();
+      if ((w >> 1) == qq) {
+        stage_rows_ld<MT, LDQ>(Lm, h1, cw, q);
+        stage_x2_ld<LDQ>(Rm, xq, 16 * nR, cw, q, K0);
+      }
+      __syncthreads();
+      gemm_cols<NACC, LDQ, 2>(acc, Lm, Rm, MT, nR, w, lr, q);
+    }
   }
+  const int nslab = gridDim.x;
   store_pass(acc, g.slab, nslab, MT, MT, nR, w, l);
+  __syncthreads();
+  store_row(dacc, HP, g.slab, nslab, 0, tid);
   // ---- loss statistics
 #pragma unroll
   for (int k = 0; k < 5; ++k)
     for (int off = 32; off > 0; off >>= 1) sv[k] += __shfl_xor(sv[k], off);
-  __syncthreads();
-  float* red5 = base;
+  float* red5 = Lm;
   if (l == 0)
     for (int k = 0; k < 5; ++k) red5[w * 8 + k] = sv[k];
   __syncthreads();
@@ -392,6 +463,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
 }
 
 // ------------------------------------------------------------------ actor pass
+// LDS: [critic image][actor image][staging DZA1 [HPa][LDP] + Saug [16 nRa][LDP]][row reduction [8][HPa]][dW2a accumulator]
 template <int MT, int MTA, int KB>
 __global__ __launch_bounds__(FTHREADS) void ddpg2_actor_kernel(Fused2Args g) {
   constexpr int LDK = 8 * KB + 4;
@@ -399,63 +471,69 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_actor_kernel(Fused2Args g) {
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
   constexpr int HP = 16 * MT, HPa = 16 * MTA;
   const int ns = g.ns, nRa = (ns + 1 + 15) / 16;
-  const int imgc = lds2_floats(HP, LDK);
-  const int stage = HPa * LDP + 16 * nRa * LDP;
-  const int reg0 = max(imgc, max(stage, 8 * HPa));
   float* base = smem;
   const Lds2 SC = carve2(base, HP, LDK);
-  const Lds2 SA = carve2(base + reg0, HPa, LDK);
-  float* red = SA.W1 + lds2_floats(HPa, LDK);
-  const int col = blockIdx.x * FCOLS + w * 16 + lr;
-  const bool valid = col < g.Bu;
+  const Lds2 SA = carve2(base + lds2_floats(HP, LDK), HPa, LDK);
+  float* Lm = SA.W1 + lds2_floats(HPa, LDK);  // DZA1 [HPa][LDP]
+  float* Rm = Lm + HPa * LDP;                  // Saug [16 nRa][LDP]
+  float* redA = Rm + 16 * nRa * LDP;           // [8][HPa]
+  float* dacc = redA + 8 * HPa;                // [HPa]
+  float* red = dacc + HPa;                     // [8]
+  const int nchunk = (g.Bu + FCOLS - 1) / FCOLS;
 
-  float xs[K2MAX][2];
-  load_x2(xs, g.s, (size_t)col, ns, KB, q, valid);
   load_net2(SA, g.A, HPa, LDK, tid);
   load_net2(SC, g.C, HP, LDK, tid);
+  for (int i = tid; i < HPa; i += FTHREADS) dacc[i] = 0.f;
   __syncthreads();
-  f32x4 ha[MTA];
-  layer1_keep<MTA, KB>(ha, xs, SA, lr, q);
-  const float aout = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
-  float x[K2MAX][2];
-#pragma unroll
-  for (int blk = 0; blk < K2MAX; ++blk) { x[blk][0] = xs[blk][0]; x[blk][1] = xs[blk][1]; }
-  set_row2(x, ns, valid ? aout : 0.f, q);
-  // q = C([s; a]) and da = sum_i W1c[i][ns] * relu'(h1_i) * w2c_i * dq, tile by tile (nothing of h1 is kept)
-  const float dq = valid ? -1.f / (float)g.Bu : 0.f;
-  float qacc = 0.f, da = 0.f;
-  layer1_head_da<MT, KB>(x, SC, ns, lr, q, qacc, da);
-  qacc += __shfl_xor(qacc, 16);
-  qacc += __shfl_xor(qacc, 32);
-  da += __shfl_xor(da, 16);
-  da += __shfl_xor(da, 32);
-  const float qv = qacc + SC.b2[0];
-  float st0 = (valid && q == 0) ? qv : 0.f;
-  const float dza2 = da * dq * (1.f - aout * aout);
-  const int nslab = gridDim.x;
-  __syncthreads();                              // the critic image may be overlaid now
-  out_row_grad<MTA>(ha, dza2, g.A.H, base, g.slab, nslab, 0, tid);
-#pragma unroll
-  for (int m = 0; m < MTA; ++m) {
-    const float* wv = SA.w2 + 16 * m + 4 * q;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ha[m][r] = ha[m][r] > 0.f ? wv[r] * dza2 : 0.f;
-  }
-  float* Lm = base;                             // DZA1 [HPa][LDP]
-  float* Rm = base + HPa * LDP;                 // Saug [16 nRa][LDP]
-  const int cw = (w & 3) * 16 + lr;
   f32x4 acc[1];
   zero_(acc);
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-    if ((w >> 2) == half) {
-      stage_rows<MTA>(Lm, ha, cw, q, -1);
-      stage_x2(Rm, xs, 16 * nRa, cw, q, ns);
+  float st0 = 0.f;
+  const int cw = (w & 3) * 16 + lr;
+#pragma unroll 1
+  for (int chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+    const int col = chunk * FCOLS + w * 16 + lr;
+    const bool valid = col < g.Bu;
+    float xs[K2MAX][2];
+    load_x2(xs, g.s, (size_t)col, ns, KB, q, valid);
+    f32x4 ha[MTA];
+    layer1_keep<MTA, KB>(ha, xs, SA, lr, q);
+    const float aout = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
+    float x[K2MAX][2];
+#pragma unroll
+    for (int blk = 0; blk < K2MAX; ++blk) { x[blk][0] = xs[blk][0]; x[blk][1] = xs[blk][1]; }
+    set_row2(x, ns, valid ? aout : 0.f, q);
+    // q = C([s; a]) and da = sum_i W1c[i][ns] * relu'(h1_i) * w2c_i * dq, tile by tile (nothing of h1 is kept)
+    const float dq = valid ? -1.f / (float)g.Bu : 0.f;
+    float qacc = 0.f, da = 0.f;
+    layer1_head_da<MT, KB>(x, SC, ns, lr, q, qacc, da);
+    qacc += __shfl_xor(qacc, 16);
+    qacc += __shfl_xor(qacc, 32);
+    da += __shfl_xor(da, 16);
+    da += __shfl_xor(da, 32);
+    if (valid && q == 0) st0 += qacc + SC.b2[0];
+    const float dza2 = da * dq * (1.f - aout * aout);
+    __syncthreads();                            // the previous chunk's tiles have been consumed
+    out_row_grad<MTA>(ha, dza2, g.A.H, redA, dacc, tid);
+#pragma unroll
+    for (int m = 0; m < MTA; ++m) {
+      const float* wv = SA.w2 + 16 * m + 4 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ha[m][r] = ha[m][r] > 0.f ? wv[r] * dza2 : 0.f;
     }
-    __syncthreads();
-    gemm_pass(acc, Lm, Rm, MTA, nRa, w, lr, q);
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((w >> 2) == half) {
+        stage_rows<MTA>(Lm, ha, cw, q, -1);
+        stage_x2(Rm, xs, 16 * nRa, cw, q, ns);
+      }
+      __syncthreads();
+      gemm_pass(acc, Lm, Rm, MTA, nRa, w, lr, q);
+    }
   }
+  const int nslab = gridDim.x;
   store_pass(acc, g.slab, nslab, MTA, MTA, nRa, w, l);
+  __syncthreads();
+  store_row(dacc, HPa, g.slab, nslab, 0, tid);
   st0 = block_sum(st0, red, tid);
   if (tid == 0) {
     float* st = g.slab + ((size_t)(4 * slab2_tiles(MTA, nRa)) * nslab + blockIdx.x) * 64;
@@ -592,6 +670,13 @@ bool fused2_supported(const Mlp* A, const Mlp* C) {
   return (mt == 22 || mt == 9) && (mta == 2 || mta == 1);
 }
 
+// workgroups of a pass: up to CPWMAX chunks of 128 columns each once the batch exceeds one chunk per CU
+static int grid2_of(int Bu) {
+  const int nchunk = (Bu + FCOLS - 1) / FCOLS;
+  const int cpw = std::min(CPWMAX, std::max(1, (nchunk + 255) / 256));
+  return (nchunk + cpw - 1) / cpw;
+}
+
 static Net2 net2_of(const Mlp* M) {
   Net2 n;
   n.p = M->params.as<float>();
@@ -606,11 +691,11 @@ static size_t lds2_bytes(const Fused2Args& g, bool actor_pass) {
   const int imgc = lds2_floats(HP, LDK), imga = lds2_floats(HPa, LDK);
   size_t f;
   if (!actor_pass) {
-    const int nR = nr_of(g.C.K0), stage = HP * LDP + 16 * nR * LDP;
-    f = (size_t)std::max(2 * imgc, std::max(stage, 8 * HP)) + HP + imga + 8;
+    const int nR = nr_of(g.C.K0), stg = std::max(HP * LDQ + 16 * nR * LDQ, 8 * HP);
+    f = (size_t)imgc + stg + imga + HP;
   } else {
-    const int nRa = nr_of(g.A.K0), stage = HPa * LDP + 16 * nRa * LDP;
-    f = (size_t)std::max(imgc, std::max(stage, 8 * HPa)) + imga + 8;
+    const int nRa = nr_of(g.A.K0);
+    f = (size_t)imgc + imga + HPa * LDP + 16 * nRa * LDP + 8 * HPa + HPa + 8;
   }
   return f * 4;
 }
@@ -711,7 +796,7 @@ int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const v
                         const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,
                         const AdamPolyak* apply) {
   const int mt = mt2_of(C->dims[1]), mta = mt2_of(A->dims[1]), nR = nr_of(C->dims[0]);
-  const int grid = (Bu + FCOLS - 1) / FCOLS;
+  const int grid = grid2_of(Bu);
   const size_t need = slab2_floats(mt, nR, grid) * 4;
   if (C->fslab.bytes < need) PDEC_HIP(C->fslab.alloc(need));
   Fused2Args g{};
@@ -733,7 +818,7 @@ int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const v
 int fused2_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double grad_scale, void* loss_dev,
                        const AdamPolyak* apply) {
   const int mt = mt2_of(C->dims[1]), mta = mt2_of(A->dims[1]), nRa = nr_of(A->dims[0]);
-  const int grid = (Bu + FCOLS - 1) / FCOLS;
+  const int grid = grid2_of(Bu);
   const size_t need = slab2_floats(mta, nRa, grid) * 4;
   if (A->fslab.bytes < need) PDEC_HIP(A->fslab.alloc(need));
   Fused2Args g{};
