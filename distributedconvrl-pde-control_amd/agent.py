@@ -189,13 +189,19 @@ class CustomDDPGPolicy:
                 A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), Bu, float(self.p), float(oa.eta),
                 C.c_void_p(L.data_ptr())))
             return
-        _lib.check(self.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a),
-                                                   _lib.ptr(r), _lib.ptr(t), _lib.ptr(sn), Bu, float(self.y), int(self.quirk),
-                                                   scale, C.c_void_p(L.data_ptr())))
-        self.reducer.all_reduce(Cn)
-        # update!(critic) :400 fused with the critic's Polyak step :415-417 (independent of the actor)
-        _lib.check(self.lib.pdec_adam_polyak_step(Cn.handle, Ct.handle, float(oc.eta), oc.beta[0], oc.beta[1],
-                                                  oc.epsilon, float(self.p)))
+        if not self.reducer.reduce_critic:
+            # policy-gradient-only exchange: the critic half is the local fused form (no all-reduce)
+            _lib.check(self.lib.pdec_ddpg_update_critic_async(
+                A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r), _lib.ptr(t),
+                _lib.ptr(sn), Bu, float(self.y), float(self.p), int(self.quirk), float(oc.eta), C.c_void_p(L.data_ptr())))
+        else:
+            _lib.check(self.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a),
+                                                       _lib.ptr(r), _lib.ptr(t), _lib.ptr(sn), Bu, float(self.y),
+                                                       int(self.quirk), scale, C.c_void_p(L.data_ptr())))
+            self.reducer.all_reduce(Cn)
+            # update!(critic) :400 fused with the critic's Polyak step :415-417 (independent of the actor)
+            _lib.check(self.lib.pdec_adam_polyak_step(Cn.handle, Ct.handle, float(oc.eta), oc.beta[0], oc.beta[1],
+                                                      oc.epsilon, float(self.p)))
         if before_actor_half is not None:
             before_actor_half()
         _lib.check(self.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, _lib.ptr(s), Bu, scale,

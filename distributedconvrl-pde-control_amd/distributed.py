@@ -22,10 +22,15 @@ class _DevArray:
 
 
 class GradReducer:
-    """all_reduce(model): sums the model's flat gradient buffer over the process group"""
+    """all_reduce(model): sums the model's flat gradient buffer over the process group.
+    reduce_critic=False is the north-star's "all-reduce of the policy gradient only": every rank trains its own
+    critic on its shard of the trajectories (no critic exchange) and only the actor gradient is summed, so the
+    ACTORS stay bit-identical replicas; reduce_critic=True also sums the critic gradient (all four networks
+    identical on every rank)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, reduce_critic=True):
         self.group = group
+        self.reduce_critic = bool(reduce_critic)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self._views = {}
 

@@ -116,6 +116,11 @@ lo, hi = pkg.distributed.shard_range(Bu, world, rank)
 loc = nn.ddpg_losses_and_grads(A, C, At, Ct, aa, ac, s[:, lo:hi], a[:, lo:hi], r[lo:hi], t[lo:hi], sn[:, lo:hi], 0.99, quirk=False)["gC"]
 red = pkg.distributed.all_reduce_host_grads([g / world for g in loc])
 err = max(np.abs(x - y).max() for x, y in zip(red, full))
+# the policy gradient (the north-star's only exchange): same identity for the actor
+gA_full = nn.actor_grads(A, C, aa, ac, s)["gA"]
+gA_loc = nn.actor_grads(A, C, aa, ac, s[:, lo:hi])["gA"]
+redA = pkg.distributed.all_reduce_host_grads([g / world for g in gA_loc])
+err = max(err, max(np.abs(x - y).max() for x, y in zip(redA, gA_full)))
 # identical ADAM step on every rank keeps the replicas bit-identical
 opt = nn.Adam([c.copy() for c in C], 1e-3); Cn = opt.step([c.copy() for c in C], red)
 chk = torch.tensor([float(sum(np.sum(c) for c in Cn))], dtype=torch.float64)
