@@ -164,3 +164,39 @@ def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol):
         r = ks.reward_function(cfg, ref, a1[b][None], (a1[b] - a0[b])[None])
         assert np.abs(env.reward[b].cpu().numpy() - r).max() <= 10 * tol
     assert int(flags.sum()) == 0
+
+
+@pytest.mark.parametrize("nx", [1024, 4096, 600, 250, 60])
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 3e-5)])
+def test_every_fft_engine_and_size_limit(pkg, nx, prec, tol):
+    """the fused step at the other engine sizes: 1024 (config C3, radix-4 through LDS), 4096 / 2048 (the largest fp32 / fp64 N the
+    in-LDS kernel accepts), 600 (KS500's grid: factors 2,3,5), 250 (2 * 5^3), 60 (fewer points than a wave has lanes; the reference's kernels need nx >= 50); odd batch"""
+    from oracle import ks
+    if nx == 4096 and prec == "f64":
+        nx = 2048       # complex fp64: the two 64 KiB transform buffers of 4096 points would exceed the 160 KiB LDS
+    setup = pkg.KSSetup.bench_C2(nx)
+    if nx >= 2048:      # sensors every 16 cells: the sensing scratch of 1024 sensors would not fit beside the 4096-point FFT
+        setup = pkg.KSSetup(nx, setup.Lx, np.arange(1, nx + 1, 16), sigma_sensors=1.0, sigma_actuators=1.0, window_size=3)
+    cfg = ks.KSConfig(nx, setup.Lx, setup.sensor_positions, sigma_sensors=1.0, sigma_actuators=1.0, window_size=3)
+    dt = torch.float64 if prec == "f64" else torch.float32
+    rng = np.random.default_rng(nx)
+    B, A = 3, setup.n_actuators
+    y0 = setup.generate_random_init(rng, B) * 0.15
+    act_prev, act = rng.uniform(-1, 1, (B, A)), rng.uniform(-1, 1, (B, A))
+    env = pkg.PDEenv(setup, B=B, dtype=dt)
+    env.y.copy_(to_dev(y0, dt))
+    env.action.copy_(to_dev(act_prev, dt).reshape(env._ashape))
+    env(to_dev(act, dt).reshape(env._ashape))
+    for b in range(B):
+        o = ks.env_step(cfg, y0[b], act_prev[b][None], act[b][None], 0.0)
+        assert np.abs(env.y[b].cpu().numpy() - o["y"]).max() <= tol * max(1.0, np.abs(o["y"]).max())
+        assert np.abs(env.reward[b].cpu().numpy() - o["reward"]).max() <= tol * 10
+        assert np.abs(env.state[b].cpu().numpy().T - o["state"]).max() <= tol * 10
+    assert int(env.done.sum()) == 0
+
+
+def test_size_limits_are_reported_not_crashed(pkg):
+    """beyond the limits the create call fails with a message (no launch with shapes the kernels do not cover)"""
+    for nx in (8192, 254 * 7):          # too large for LDS; a prime factor other than 2, 3, 5
+        with pytest.raises(pkg.PdecError):
+            pkg.PDEenv(pkg.KSSetup.bench_C2(nx), B=1, dtype=torch.float32)
