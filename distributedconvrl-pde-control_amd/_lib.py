@@ -77,6 +77,7 @@ SIGNATURES = {
     "pdec_ddpg_update_critic_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _vp],
     "pdec_ddpg_update_actor_async": [Handle] * 4 + [_vp, _i, _d, _d, _vp],
     "pdec_policy_act": [Handle, _vp, _vp, _i, _d, _d, _vp],
+    "pdec_rollout": [Handle, Handle, _i, _vp, _vp, _vp, _d, _d, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdec_randn": [Handle, _vp, _sz, _i, _u64, _u64],
     "pdec_ddpg_critic_grads": [Handle] * 4 + [_vp] * 5 + [_i, _d, _i, _d, _vp],
     "pdec_ddpg_actor_grads": [Handle, Handle, _vp, _i, _d, _vp],

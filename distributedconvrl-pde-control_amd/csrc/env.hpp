@@ -33,6 +33,7 @@ struct Env : Object {
   DevBuf Gs, sn0, GaC, an0, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
   int Wd = 0, Cnt = 0;
   DevBuf stage;  // staging for the _host wrappers
+  DevBuf roll;   // ping-pong buffers of pdec_rollout
   void* term_out = nullptr;
   FftPlan fft;
   int nthreads = 64;

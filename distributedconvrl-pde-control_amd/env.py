@@ -235,6 +235,38 @@ class PDEenv:
         self.time += self.dt
         self._done_stale = True
 
+    # ---- T control steps without returning to the host
+    def rollout(self, actor, T, act_noise=0.0, act_limit=1.0, learning=False, seed=0, offset=0, log=False):
+        """for t in 1:T; action = policy(env); env(action); end  (src/PDEagent.jl:175-209 + src/PDEenv.jl:195-241)
+        enqueued in ONE library call: actor forward (+ exploration noise when `learning`), clamp, fused env step,
+        device-side reward accumulation and -- with log=True -- the per-step rows PDEhook records
+        (src/PDEhook.jl:54-62).  `actor` is a HipMLP of the environment's dtype on the environment's stream.
+        Returns device tensors: reward_sum [B, A], done_step [B] (first step that raised `done`, -1 = none) and the logs
+        y [T, ...], p, action, reward.  env.y / state / action / steps / time advance by T steps."""
+        T = int(T)
+        kw = dict(dtype=self.dtype, device=self.device)
+        out = dict(reward_sum=torch.zeros((self.B, self.setup.reward_len), **kw),
+                   done_any=torch.zeros(self.B, dtype=torch.int32, device=self.device),
+                   done_step=torch.zeros(self.B, dtype=torch.int32, device=self.device))
+        if log:
+            out.update(y=torch.empty((T,) + self._yshape, **kw), p=torch.empty((T,) + self._pshape, **kw),
+                       action=torch.empty((T,) + self._ashape, **kw),
+                       reward=torch.empty((T, self.B, self.setup.reward_len), **kw))
+        if self.action.data_ptr() in self._adopted:      # never write into a caller-owned buffer
+            self.action = self.action.clone()
+        state = self.state
+        _lib.check(self.lib.pdec_rollout(
+            self._h, actor.handle, T, _lib.ptr(self.y), _lib.ptr(state), _lib.ptr(self.action), float(act_noise),
+            float(act_limit), int(bool(learning)), int(seed), int(offset), _lib.ptr(out["reward_sum"]),
+            _lib.ptr(out.get("y")), _lib.ptr(out.get("p")), _lib.ptr(out.get("action")), _lib.ptr(out.get("reward")),
+            _lib.ptr(out["done_any"]), _lib.ptr(out["done_step"])))
+        self.prev_state = None
+        self.steps += T
+        self.time += T * self.dt
+        torch.ne(out["done_any"], 0, out=self._done)
+        self._done_stale = False
+        return out
+
     # ---- Julia-shaped host views for B == 1 (what PDEhook logs, src/PDEhook.jl:54-62)
     def y_julia(self, b=0):
         a = self.y[b].detach().cpu().numpy().astype(np.float64)

@@ -225,6 +225,21 @@ int pdec_polyak(pdec_handle dst, pdec_handle src, double rho);
 int pdec_adam_polyak_step(pdec_handle h, pdec_handle h_target, double eta, double beta1, double beta2,
                           double eps, double rho);
 
+/* T control steps in one call, no host round trip per step: for t = 0..T-1
+ *   action_t = clamp(actor(state_t) + randn * act_noise, +-act_limit)   (src/PDEagent.jl:183-207, pdec_policy_act_rng
+ *              with noise offset `offset + t * ceil(cols*na/4)`; learning = 0 -> no noise)
+ *   (y, state, reward, done) = (env::PDEenv)(action_t)                  (src/PDEenv.jl:195-241, pdec_env_step)
+ * all enqueued on the environment's stream (the actor handle must use the same stream and dtype).  In/out device
+ * arrays: y, state, action (in: the previous action, for delta_action; out: the last one).  Optional outputs (NULL to
+ * skip): reward_sum [B][A] += every step's reward; log_y / log_p / log_action / log_reward: [T][...] rows of the
+ * trajectory (what PDEhook logs per step, src/PDEhook.jl:54-62); done_any [B] = OR of the step flags, done_step [B] =
+ * first step that raised a flag (-1: none).  The reference stops an episode at `done`; a rollout keeps integrating
+ * (blown-up trajectories saturate to inf/NaN) and reports the step, the caller discards what follows it. */
+int pdec_rollout(pdec_handle env, pdec_handle actor, int T, void* y, void* state, void* action,
+                 double act_noise, double act_limit, int learning, uint64_t seed, uint64_t offset,
+                 void* reward_sum, void* log_y, void* log_p, void* log_action, void* log_reward,
+                 int32_t* done_any, int32_t* done_step);
+
 /* policy act: actions[cols][na] = clamp(actor(state) + noise*act_noise, +-act_limit)
  * (src/PDEagent.jl:183-207).  noise [cols][na] device standard normals or NULL (-> no noise,
  * `learning=false`). */

@@ -154,3 +154,50 @@ def test_agent_checkpoint_roundtrip(pkg, tmp_path):
     for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
         for x, y in zip(getattr(a1.policy, n).model.params(), getattr(a2.policy, n).model.params()):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("case", ["ks_c2_f32", "kseg_f64", "kseg2d_f32"])
+def test_rollout_equals_step_by_step_loop(pkg, case):
+    """pdec_rollout (T control steps enqueued in one call, row F2) == the per-step loop policy_act_rng -> env(action),
+    bit for bit, including the accumulated reward, the logged rows and the step at which a trajectory blows up"""
+    import ctypes as C
+    L = pkg._lib
+    if case == "ks_c2_f32":
+        setup, dt, B = pkg.KSSetup.bench_C2(256), torch.float32, 5
+        y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
+    elif case == "kseg_f64":
+        setup, dt, B = pkg.KellerSegelSetup(), torch.float64, 3
+        y0 = np.swapaxes(setup.generate_random_init(np.random.default_rng(0), B), 1, 2)
+    else:
+        setup, dt, B = pkg.KellerSegel2DSetup(nx=64, ny=32, substeps=4), torch.float32, 2
+        y0 = np.moveaxis(setup.generate_random_init(np.random.default_rng(0), B), 1, -1)
+    T, noise, lim, seed = 6, 0.3, 1.0, 99
+    envs = [pkg.PDEenv(setup, B=B, dtype=dt, y0=np.ascontiguousarray(y0)) for _ in range(2)]
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=dt, start_steps=-1)
+    actor = agent.policy.behavior_actor.model
+    ns, A = setup.state_shape
+    cols = B * A
+    # reference loop
+    e = envs[0]
+    rsum = torch.zeros_like(e.reward)
+    rows = []
+    off = 0
+    for t in range(T):
+        a = torch.empty(e._ashape, dtype=dt, device="cuda:0")
+        L.check(e.lib.pdec_policy_act_rng(actor.handle, L.ptr(e.state), cols, noise, lim, 1, seed, off, L.ptr(a)))
+        off += (cols + 3) // 4
+        e(a)
+        rsum += e.reward
+        rows.append((e.y.clone(), e.p.clone(), e.action.clone(), e.reward.clone()))
+    out = envs[1].rollout(actor, T, act_noise=noise, act_limit=lim, learning=True, seed=seed, offset=0, log=True)
+    torch.cuda.synchronize()
+    assert torch.equal(envs[1].y, e.y) and torch.equal(envs[1].state, e.state) and torch.equal(envs[1].action, e.action)
+    assert torch.equal(out["reward_sum"], rsum)
+    for t in range(T):
+        assert torch.equal(out["y"][t], rows[t][0]) and torch.equal(out["p"][t], rows[t][1])
+        assert torch.equal(out["action"][t], rows[t][2]) and torch.equal(out["reward"][t], rows[t][3])
+    assert envs[1].steps == T and int(out["done_any"].sum()) == 0 and out["done_step"].tolist() == [-1] * B
+    # blow-up bookkeeping: a trajectory started beyond max_value is flagged at step 0
+    envs[1].y[B - 1].fill_(1e3)
+    out2 = envs[1].rollout(actor, 2, learning=False)
+    assert out2["done_step"].tolist()[B - 1] == 0 and bool(envs[1].done[B - 1])
