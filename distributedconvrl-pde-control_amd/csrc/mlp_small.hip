@@ -265,6 +265,324 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g_in) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 2-layer nets (the reference's `drop_middle_layer = true` shape, src/PDEagent.jl:30-41): one THREAD per hidden unit.
+// A thread keeps its unit's weights (first-layer row, bias, output weight), their ADAM moments and the target copies in
+// REGISTERS for all `loops` updates; forward, backward, ADAM and Polyak of a unit are thread-local, and only the
+// output-layer sums cross threads (DPP/shuffle inside a wave, one LDS exchange + one barrier across waves).  Six barriers
+// per update instead of ~35, no weight traffic at all between the first load and the final write-back.
+#define S2_BU 4            // most minibatch columns the register-resident kernel holds (reference: batch_size = 3)
+
+struct Small2Args {
+  SmallArgs g;
+  int nC, nA;              // hidden widths
+};
+
+template <int N>
+__device__ __forceinline__ void s2_reduce(float (&v)[N], int n, float* buf, int nw, int tid) {
+  // sum v[0..n) over the workgroup; result in every thread.  buf: [nw][N] (the caller alternates two buffers)
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n)
+      for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i < n) buf[(tid >> 6) * N + i] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) {
+      float a = 0.f;
+      for (int w = 0; w < nw; ++w) a += buf[w * N + i];
+      v[i] = a;
+    }
+}
+
+// Flux ADAM (fp64 arithmetic, no FMA contraction) + Polyak of one parameter held in registers
+__device__ __forceinline__ void s2_adam(float& p, float& m, float& v, float& pt, float gi, double eta, double b1, double b2,
+                                        double eps, double omb1p, double omb2p, float rho, float omr) {
+#pragma clang fp contract(off)
+  const double gd = (double)gi;
+  m = (float)(b1 * (double)m + (1.0 - b1) * gd);
+  v = (float)(b2 * (double)v + (1.0 - b2) * gd * gd);
+  const float delta = (float)((double)m / omb1p / (sqrt((double)v / omb2p) + eps) * eta);
+  p = p - delta;
+  pt = rho * pt + omr * p;
+}
+
+// EXACT: ns == KA and Bu == BUT are compile-time constants (the shipped experiments: (1,3) KS, (12,3) Keller-Segel,
+// (9,3) fluid), so every column / input-row guard folds away; otherwise KA / BUT are upper bounds checked at run time
+template <int KC, int KA, int BUT, bool EXACT>
+__global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
+  const SmallArgs& g = a_in.g;
+  extern __shared__ __align__(16) float sm[];
+  const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
+  const int Bu = EXACT ? BUT : g.Bu, ns = EXACT ? KA : g.ns, K0 = ns + 1, nC = a_in.nC, nA = a_in.nA;
+  const bool isC = tid < nC, isA = tid < nA;
+  // the minibatches of ALL loops are fetched into LDS up front (pde_fetch!, src/PDEagent.jl:323-340): the replay traces
+  // do not change during the launch, so the two dependent global loads (slot index, then the row) are paid once
+  const int bstride = (2 * ns + 3) * Bu;    // per loop: s' [ns][Bu], s [ns][Bu], a [Bu], r [Bu], t [Bu]
+  float* batch = sm;
+  float* red0 = batch + (size_t)g.loops * bstride;   // [nw][2 * BUT]
+  float* red1 = red0 + nw * 2 * BUT;
+  for (int idx = tid; idx < g.loops * ns * Bu; idx += nt) {
+    const int it = idx / (ns * Bu), rem = idx - it * (ns * Bu), k = rem / Bu, c = rem - k * Bu;
+    batch[it * bstride + rem] = g.state[(size_t)g.i_sn[it * Bu + c] * ns + k];
+    batch[it * bstride + ns * Bu + rem] = g.state[(size_t)g.i_s[it * Bu + c] * ns + k];
+  }
+  for (int idx = tid; idx < g.loops * Bu; idx += nt) {
+    const int it = idx / Bu, c = idx - it * Bu;
+    float* b = batch + it * bstride + 2 * ns * Bu;
+    b[c] = g.action[g.i_s[idx]];
+    b[Bu + c] = g.reward[g.i_rt[idx]];
+    b[2 * Bu + c] = g.terminal[g.i_rt[idx]];
+  }
+  // ---- this thread's unit: parameters p, moments m/v, target pt
+  float cw1[KC], cw1m[KC], cw1v[KC], cw1t[KC], cb1 = 0, cb1m = 0, cb1v = 0, cb1t = 0, cw2 = 0, cw2m = 0, cw2v = 0, cw2t = 0;
+  float aw1[KA], aw1m[KA], aw1v[KA], aw1t[KA], ab1 = 0, ab1m = 0, ab1v = 0, ab1t = 0, aw2 = 0, aw2m = 0, aw2v = 0, aw2t = 0;
+  // output biases: replicated in every thread (identical arithmetic), written back by thread 0
+  const int cob1 = nC * K0, cow2 = cob1 + nC, cob2 = cow2 + nC;
+  const int aob1 = nA * ns, aow2 = aob1 + nA, aob2 = aow2 + nA;
+  float cb2 = g.C.p[cob2], cb2m = g.C.m[cob2], cb2v = g.C.v[cob2], cb2t = g.C.pt[cob2];
+  float ab2 = g.A.p[aob2], ab2m = g.A.m[aob2], ab2v = g.A.v[aob2], ab2t = g.A.pt[aob2];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    const bool ok = isC && k < K0;
+    cw1[k] = ok ? g.C.p[tid * K0 + k] : 0.f; cw1m[k] = ok ? g.C.m[tid * K0 + k] : 0.f;
+    cw1v[k] = ok ? g.C.v[tid * K0 + k] : 0.f; cw1t[k] = ok ? g.C.pt[tid * K0 + k] : 0.f;
+  }
+  if (isC) {
+    cb1 = g.C.p[cob1 + tid]; cb1m = g.C.m[cob1 + tid]; cb1v = g.C.v[cob1 + tid]; cb1t = g.C.pt[cob1 + tid];
+    cw2 = g.C.p[cow2 + tid]; cw2m = g.C.m[cow2 + tid]; cw2v = g.C.v[cow2 + tid]; cw2t = g.C.pt[cow2 + tid];
+  }
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const bool ok = isA && k < ns;
+    aw1[k] = ok ? g.A.p[tid * ns + k] : 0.f; aw1m[k] = ok ? g.A.m[tid * ns + k] : 0.f;
+    aw1v[k] = ok ? g.A.v[tid * ns + k] : 0.f; aw1t[k] = ok ? g.A.pt[tid * ns + k] : 0.f;
+  }
+  if (isA) {
+    ab1 = g.A.p[aob1 + tid]; ab1m = g.A.m[aob1 + tid]; ab1v = g.A.v[aob1 + tid]; ab1t = g.A.pt[aob1 + tid];
+    aw2 = g.A.p[aow2 + tid]; aw2m = g.A.m[aow2 + tid]; aw2v = g.A.v[aow2 + tid]; aw2t = g.A.pt[aow2 + tid];
+  }
+  double bpa0 = g.bp_a0, bpa1 = g.bp_a1, bpc0 = g.bp_c0, bpc1 = g.bp_c1;
+  const float omr = 1.0f - g.rho, invB = 1.f / (float)Bu;
+  float closs = 0.f, aloss = 0.f;
+  for (int it = 0; it < g.loops; ++it) {
+    const float* bsn = batch + it * bstride;
+    const float* bs = bsn + ns * Bu;
+    const float* ba = bs + ns * Bu;
+    const float* br = ba + Bu;
+    const float* bt = br + Bu;
+    if (it == 0) __syncthreads();          // the batches are staged
+    float v[2 * BUT];
+    // ---- a' = At(s')                                                            :385
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) {
+      float z = ab1t;
+#pragma unroll
+      for (int k = 0; k < KA; ++k)
+        if (k < ns) z += aw1t[k] * bsn[k * Bu + (c < Bu ? c : 0)];
+      v[c] = (isA && c < Bu) ? aw2t * fmaxf(z, 0.f) : 0.f;
+    }
+    s2_reduce<2 * BUT>(v, Bu, red0, nw, tid);
+    float an[BUT];
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) an[c] = tanhf(v[c] + ab2t);
+    // ---- qt = Ct([s'; a'])                                                      :386
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) {
+      float z = cb1t;
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (k < ns) z += cw1t[k] * bsn[k * Bu + (c < Bu ? c : 0)];
+        else if (k == ns) z += cw1t[k] * an[c];
+      v[c] = (isC && c < Bu) ? cw2t * fmaxf(z, 0.f) : 0.f;
+    }
+    s2_reduce<2 * BUT>(v, Bu, red1, nw, tid);
+    float qt[BUT];
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) qt[c] = v[c] + cb2t;
+    // ---- q = C([s; a]), critic loss and gradients                              :388-400
+    float h[BUT];
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) {
+      float z = cb1;
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (k < ns) z += cw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
+        else if (k == ns) z += cw1[k] * ba[c < Bu ? c : 0];
+      h[c] = (isC && c < Bu) ? fmaxf(z, 0.f) : 0.f;
+      v[c] = cw2 * h[c];
+    }
+    s2_reduce<2 * BUT>(v, Bu, red0, nw, tid);
+    float dq[BUT];
+    {
+      float rbar = 0.f;
+      for (int c = 0; c < Bu; ++c) rbar += br[c];
+      rbar *= invB;
+      float loss = 0.f, gb2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < BUT; ++c) {
+        dq[c] = 0.f;
+        if (c < Bu) {
+          const float cc = g.gamma * (1.f - bt[c]) * qt[c] - (v[c] + cb2);
+          if (g.quirk) {
+            for (int j = 0; j < Bu; ++j) loss += (br[j] + cc) * (br[j] + cc);
+          } else {
+            loss += (br[c] + cc) * (br[c] + cc);
+          }
+          dq[c] = -(2.f * invB) * ((g.quirk ? rbar : br[c]) + cc);
+          gb2 += dq[c];
+        }
+      }
+      closs = g.quirk ? loss / (float)(Bu * Bu) : loss * invB;
+      const double o1 = 1.0 - bpc0, o2 = 1.0 - bpc1;
+      // thread-local backward of unit `tid`: dW2 = sum_c dq h, dz1 = relu'(h) w2 dq, db1 = sum_c dz1, dW1[k] = sum_c dz1 x[k]
+      float gw2 = 0.f, gb1 = 0.f, gw1[KC];
+#pragma unroll
+      for (int k = 0; k < KC; ++k) gw1[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < BUT; ++c)
+        if (c < Bu) {
+          gw2 = fmaf(dq[c], h[c], gw2);
+          const float dz = h[c] > 0.f ? cw2 * dq[c] : 0.f;
+          gb1 += dz;
+#pragma unroll
+          for (int k = 0; k < KC; ++k)
+            if (k < ns) gw1[k] = fmaf(dz, bs[k * Bu + c], gw1[k]);
+            else if (k == ns) gw1[k] = fmaf(dz, ba[c], gw1[k]);
+        }
+      if (isC) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+          if (k < K0) s2_adam(cw1[k], cw1m[k], cw1v[k], cw1t[k], gw1[k], g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+        s2_adam(cb1, cb1m, cb1v, cb1t, gb1, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+        s2_adam(cw2, cw2m, cw2v, cw2t, gw2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+      }
+      s2_adam(cb2, cb2m, cb2v, cb2t, gb2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+      bpc0 *= g.b1;
+      bpc1 *= g.b2;
+    }
+    // ---- actor: -mean(C([s; A(s)])) with the updated critic                     :402-412
+    float ha[BUT];
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) {
+      float z = ab1;
+#pragma unroll
+      for (int k = 0; k < KA; ++k)
+        if (k < ns) z += aw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
+      ha[c] = (isA && c < Bu) ? fmaxf(z, 0.f) : 0.f;
+      v[c] = aw2 * ha[c];
+    }
+    s2_reduce<2 * BUT>(v, Bu, red1, nw, tid);
+    float ao[BUT];
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) ao[c] = tanhf(v[c] + ab2);
+    // critic forward on [s; A(s)]: q for the reported loss and da[c] = sum_f W1c[f][ns] relu'(h) w2 (-1/Bu) in ONE exchange
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) {
+      float z = cb1;
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (k < ns) z += cw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
+        else if (k == ns) z += cw1[k] * ao[c];
+      const bool on = isC && c < Bu;
+      v[c] = on ? cw2 * fmaxf(z, 0.f) : 0.f;
+      float wns = 0.f;
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (k == ns) wns = cw1[k];
+      v[BUT + c] = (on && z > 0.f) ? wns * cw2 * (-invB) : 0.f;
+    }
+    {
+      // both halves in one exchange: entries [0, Bu) and [BUT, BUT + Bu)
+#pragma unroll
+      for (int i = 0; i < 2 * BUT; ++i)
+        if ((i < BUT ? i : i - BUT) < Bu)
+          for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+      if ((tid & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < 2 * BUT; ++i) red0[(tid >> 6) * 2 * BUT + i] = v[i];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2 * BUT; ++i) {
+        float acc = 0.f;
+        if ((i < BUT ? i : i - BUT) < Bu)
+          for (int w = 0; w < nw; ++w) acc += red0[w * 2 * BUT + i];
+        v[i] = acc;
+      }
+    }
+    {
+      float s = 0.f;
+      for (int c = 0; c < Bu; ++c) s += v[c] + cb2;
+      aloss = -s * invB;
+      const double o1 = 1.0 - bpa0, o2 = 1.0 - bpa1;
+      float gw2 = 0.f, gb1 = 0.f, gb2 = 0.f, gw1[KA];
+#pragma unroll
+      for (int k = 0; k < KA; ++k) gw1[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < BUT; ++c)
+        if (c < Bu) {
+          const float dz2 = v[BUT + c] * (1.f - ao[c] * ao[c]);      // tanh'
+          gb2 += dz2;
+          gw2 = fmaf(dz2, ha[c], gw2);
+          const float dz = ha[c] > 0.f ? aw2 * dz2 : 0.f;
+          gb1 += dz;
+#pragma unroll
+          for (int k = 0; k < KA; ++k)
+            if (k < ns) gw1[k] = fmaf(dz, bs[k * Bu + c], gw1[k]);
+        }
+      if (isA) {
+#pragma unroll
+        for (int k = 0; k < KA; ++k)
+          if (k < ns) s2_adam(aw1[k], aw1m[k], aw1v[k], aw1t[k], gw1[k], g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+        s2_adam(ab1, ab1m, ab1v, ab1t, gb1, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+        s2_adam(aw2, aw2m, aw2v, aw2t, gw2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+      }
+      s2_adam(ab2, ab2m, ab2v, ab2t, gb2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+      bpa0 *= g.b1;
+      bpa1 *= g.b2;
+    }
+  }
+  // ---- write the learner state back
+  if (isC) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < K0) {
+        g.C.p[tid * K0 + k] = cw1[k]; g.C.m[tid * K0 + k] = cw1m[k]; g.C.v[tid * K0 + k] = cw1v[k]; g.C.pt[tid * K0 + k] = cw1t[k];
+      }
+    g.C.p[cob1 + tid] = cb1; g.C.m[cob1 + tid] = cb1m; g.C.v[cob1 + tid] = cb1v; g.C.pt[cob1 + tid] = cb1t;
+    g.C.p[cow2 + tid] = cw2; g.C.m[cow2 + tid] = cw2m; g.C.v[cow2 + tid] = cw2v; g.C.pt[cow2 + tid] = cw2t;
+  }
+  if (isA) {
+#pragma unroll
+    for (int k = 0; k < KA; ++k)
+      if (k < ns) {
+        g.A.p[tid * ns + k] = aw1[k]; g.A.m[tid * ns + k] = aw1m[k]; g.A.v[tid * ns + k] = aw1v[k]; g.A.pt[tid * ns + k] = aw1t[k];
+      }
+    g.A.p[aob1 + tid] = ab1; g.A.m[aob1 + tid] = ab1m; g.A.v[aob1 + tid] = ab1v; g.A.pt[aob1 + tid] = ab1t;
+    g.A.p[aow2 + tid] = aw2; g.A.m[aow2 + tid] = aw2m; g.A.v[aow2 + tid] = aw2v; g.A.pt[aow2 + tid] = aw2t;
+  }
+  if (tid == 0) {
+    g.C.p[cob2] = cb2; g.C.m[cob2] = cb2m; g.C.v[cob2] = cb2v; g.C.pt[cob2] = cb2t;
+    g.A.p[aob2] = ab2; g.A.m[aob2] = ab2m; g.A.v[aob2] = ab2v; g.A.pt[aob2] = ab2t;
+    if (g.losses) { g.losses[0] = closs; g.losses[1] = aloss; }
+  }
+}
+
+// 2-layer relu/tanh actor [ns, h, 1] + relu/identity critic [ns+1, H, 1], H and h <= 512, ns <= 15, Bu <= S2_BU
+static bool small2_ok(const Mlp* A, const Mlp* C, int Bu) {
+  if (getenv("PDEC_SMALL_GENERIC")) return false;
+  if (A->L != 2 || C->L != 2 || Bu > S2_BU) return false;
+  if (A->dims[2] != 1 || C->dims[2] != 1 || C->dims[0] != A->dims[0] + 1 || A->dims[0] > 15) return false;
+  if (A->acts[0] != PDEC_ACT_RELU || A->acts[1] != PDEC_ACT_TANH || C->acts[0] != PDEC_ACT_RELU || C->acts[1] != PDEC_ACT_IDENTITY)
+    return false;
+  return A->dims[1] <= 512 && C->dims[1] <= 512;
+}
+
 static int fill_net(SmallNet& n, Mlp* M, Mlp* T) {
   PDEC_REQUIRE(M->L <= SM_MAXL, "small update: at most %d layers", SM_MAXL);
   n.p = M->params.as<float>(); n.g = M->grads.as<float>(); n.m = M->m.as<float>(); n.v = M->v.as<float>();
@@ -327,7 +645,24 @@ extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handl
                                  160 * 1024));
     attr_set = true;
   }
-  {
+  if (small2_ok(A, C, Bu) && (size_t)loops * (2 * ns + 3) * Bu * 4 <= 120 * 1024) {
+    Small2Args a2{};
+    a2.g = g;
+    a2.g.lds_params = 0;
+    a2.nC = C->dims[1]; a2.nA = A->dims[1];
+    const int nt = (std::max(a2.nC, a2.nA) + 63) / 64 * 64, nwv = nt / 64;
+    const size_t lds2 = ((size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * nwv * 2 * S2_BU) * 4;   // reduction rows: at most 2 * S2_BU
+    ProfScope ps(C, "ddpg_small");
+#define S2_LAUNCH(KC, KA, BUT, EX) hipLaunchKernelGGL((ddpg_small2_kernel<KC, KA, BUT, EX>), dim3(1), dim3(nt), lds2, C->stream, a2)
+    if (Bu == 3 && ns == 1) S2_LAUNCH(2, 1, 3, true);            // KS22 / KS200 / KS500
+    else if (Bu == 3 && ns == 12) S2_LAUNCH(13, 12, 3, true);    // Keller-Segel10_16
+    else if (Bu == 3 && ns == 9) S2_LAUNCH(10, 9, 3, true);      // Fluid
+    else if (ns <= 3) S2_LAUNCH(4, 3, S2_BU, false);
+    else if (ns <= 9) S2_LAUNCH(10, 9, S2_BU, false);
+    else if (ns <= 12) S2_LAUNCH(13, 12, S2_BU, false);
+    else S2_LAUNCH(16, 15, S2_BU, false);
+#undef S2_LAUNCH
+  } else {
     ProfScope ps(C, "ddpg_small");
     hipLaunchKernelGGL(ddpg_small_kernel, dim3(1), dim3(SM_THREADS), lds, C->stream, g);
   }

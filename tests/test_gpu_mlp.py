@@ -242,7 +242,8 @@ def test_update_async_and_split_sequence_agree(pkg, quirk, ns, sa, sc, drop, Bu)
 
 
 @pytest.mark.parametrize("quirk", [1, 0])
-@pytest.mark.parametrize("ns,na,sa,sc,drop", [(1, 1, 0.6, 7.0, True), (12, 1, 2.0, 17.0, True), (3, 1, 1.6, 7.0, False), (8, 8, 4.8, 56.0, True)])
+@pytest.mark.parametrize("ns,na,sa,sc,drop", [(1, 1, 0.6, 7.0, True), (12, 1, 2.0, 17.0, True), (9, 1, 1.8, 17.0, True),
+                                             (15, 1, 1.0, 25.0, True), (3, 1, 1.6, 7.0, False), (8, 8, 4.8, 56.0, True)])
 def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop):
     """pdec_ddpg_update_small: the reference's update shape (update_loops x minibatch of batch_size = 3 drawn from the
     replay traces, src/PDEagent.jl:317-418) in one launch == the oracle's update applied loop by loop on the same slots"""
