@@ -30,7 +30,7 @@ class EnvCfg(C.Structure):
         ("reward_offset", C.c_double), ("reward_power", C.c_double), ("reward_denom", C.c_double),
         ("action_punish", C.c_double), ("delta_action_punish", C.c_double),
         ("ifpad", C.c_int), ("sensors_per_axis", C.c_int), ("nu", C.c_double),
-        ("Ny", C.c_int),
+        ("Ny", C.c_int), ("integrator", C.c_int),
     ]
 
 

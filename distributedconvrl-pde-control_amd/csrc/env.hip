@@ -746,6 +746,12 @@ __global__ void kseg_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
   for (int it = 0; it < e.K; ++it) {
     T k1u = 0, k1v = 0, k2u = 0, k2v = 0, k3u = 0, k3v = 0, k4u = 0, k4v = 0;
     kseg_rhs<T>(u, v, p, su, sv, n, N, idx, idx2, live, k1u, k1v);
+    if (e.rk2) {     // PDEenv's built-in integrator (src/PDEenv.jl:208-214): explicit midpoint, `oversampling` sub-steps
+      kseg_rhs<T>(u + (T)0.5 * h * k1u, v + (T)0.5 * h * k1v, p, su, sv, n, N, idx, idx2, live, k2u, k2v);
+      u = u + h * k2u;
+      v = v + h * k2v;
+      continue;
+    }
     kseg_rhs<T>(u + (T)0.5 * h * k1u, v + (T)0.5 * h * k1v, p, su, sv, n, N, idx, idx2, live, k2u, k2v);
     kseg_rhs<T>(u + (T)0.5 * h * k2u, v + (T)0.5 * h * k2v, p, su, sv, n, N, idx, idx2, live, k3u, k3v);
     kseg_rhs<T>(u + h * k3u, v + h * k3v, p, su, sv, n, N, idx, idx2, live, k4u, k4v);
@@ -854,6 +860,10 @@ __global__ void ksfd_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
   const T h = e.hstep;
   for (int it = 0; it < e.K; ++it) {
     const T k1 = ksfd_rhs<T>(u, force, su, n, N, i2dx, idx2, idx4, live);
+    if (e.rk2) {     // PDEenv's built-in integrator (src/PDEenv.jl:208-214): explicit midpoint, `oversampling` sub-steps
+      u = u + h * ksfd_rhs<T>(u + (T)0.5 * h * k1, force, su, n, N, i2dx, idx2, idx4, live);
+      continue;
+    }
     const T k2 = ksfd_rhs<T>(u + (T)0.5 * h * k1, force, su, n, N, i2dx, idx2, idx4, live);
     const T k3 = ksfd_rhs<T>(u + (T)0.5 * h * k2, force, su, n, N, i2dx, idx2, idx4, live);
     const T k4 = ksfd_rhs<T>(u + h * k3, force, su, n, N, i2dx, idx2, idx4, live);
@@ -947,6 +957,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.max_value = (T)c.max_value;
   e.dx = (T)(c.Lx / c.N);
   e.hstep = (T)(c.dt / c.K);
+  e.rk2 = c.integrator == 1;
   e.dist_mu = (T)c.mu;
   e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
   e.Wd = E.Wd; e.Cnt = E.Cnt;
@@ -1060,6 +1071,8 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
   PDEC_REQUIRE(c.window >= 1 && (c.window & 1) && c.temporal_steps >= 1, "pdec_env_create: window must be odd >= 1");
   PDEC_REQUIRE(c.window <= c.S || c.mono, "pdec_env_create: window %d larger than sensor count %d", c.window, c.S);
   PDEC_REQUIRE(c.Lx > 0 && c.dt > 0, "pdec_env_create: Lx and dt must be positive");
+  PDEC_REQUIRE(c.integrator == 0 || (c.integrator == 1 && (c.pde_kind == PDEC_PDE_KSEG_RK4 || c.pde_kind == PDEC_PDE_KS_RK4_FD)),
+               "pdec_env_create: integrator %d is not available for pde_kind %d", c.integrator, c.pde_kind);
   for (int a = 0; a < c.A && !c.mono; ++a)
     PDEC_REQUIRE(a2s[a] >= 0 && a2s[a] < c.S, "pdec_env_create: a2s[%d]=%d out of range", a, a2s[a]);
   auto E = std::make_unique<Env>();

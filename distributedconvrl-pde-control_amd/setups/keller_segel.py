@@ -20,7 +20,8 @@ class KellerSegelSetup:
                  nna_scale=2.0, nna_scale_critic=17.0, drop_middle_layer=True, gamma=0.99, rho=0.995,
                  batch_size=3, start_steps=-1, update_after=1, update_freq=1, update_loops=20,
                  learning_rate=0.0005, learning_rate_critic=0.001, act_limit=1.0, act_noise=1.2,
-                 trajectory_length=100_000):
+                 trajectory_length=100_000, integrator="rk4"):
+        self.integrator = integrator          # "rk4" (do_step, :234-239) or "midpoint" (PDEenv's built-in, src/PDEenv.jl:208-214)
         self.nx, self.Lx = int(nx), float(Lx)
         self.dx = self.Lx / self.nx
         self.sensor_positions = (np.arange(3, nx + 1, 5) if sensor_positions is None
@@ -91,6 +92,7 @@ class KellerSegelSetup:
         c.pde_kind, c.dtype, c.B, c.N, c.n_species = _lib.PDE_KSEG_RK4, dtype_code, B, self.nx, 2
         c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, self.temporal_steps, 0
         c.K = self.oversampling
+        c.integrator = 1 if self.integrator == "midpoint" else 0
         c.check_max_value = {"y": 1, "reward": 2}.get(self.check_max_value, 0)
         c.Lx, c.dt, c.mu, c.max_value = self.Lx, self.dt, 0.0, self.max_value
         c.sensor_scale = 0.25                                      # KellerSegelSetup.jl:276

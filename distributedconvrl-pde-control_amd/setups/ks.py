@@ -107,7 +107,10 @@ class KSSetup:
 
     def env_cfg(self, B, dtype_code):
         c = _lib.EnvCfg()
-        kind = _lib.PDE_KS_RK4_FD if self.integrator == "rk4_fd" else _lib.PDE_KS_CNAB2
+        # "cnab2" (the scripts' do_step), "rk4_fd" (north-star variant on the KSSetup.jl:55-59 stencil table) or
+        # "midpoint_fd" (the same right-hand side under PDEenv's built-in explicit-midpoint integrator, src/PDEenv.jl:208-214)
+        kind = _lib.PDE_KS_RK4_FD if self.integrator in ("rk4_fd", "midpoint_fd") else _lib.PDE_KS_CNAB2
+        c.integrator = 1 if self.integrator == "midpoint_fd" else 0
         c.pde_kind, c.dtype, c.B, c.N, c.n_species = kind, dtype_code, B, self.nx, 1
         c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, 1, int(self.mono)
         c.K = self.oversampling

@@ -116,6 +116,10 @@ typedef struct pdec_env_cfg {
   double nu;               /* viscosity (FluidSetup.jl:28) */
   /* 2-D Keller-Segel (PDEC_PDE_KSEG2D_RK4) only: rows of the grid; N = nx (multiple of 4), square cells dx = Lx/nx */
   int Ny;
+  /* time integrator of the right-hand-side kinds (PDEC_PDE_KSEG_RK4, PDEC_PDE_KS_RK4_FD): 0 = classical RK4 (what the
+   * setups' do_step use), 1 = PDEenv's built-in explicit midpoint rule, K = `oversampling` sub-steps
+   * (src/PDEenv.jl:208-214, taken when no do_step closure is supplied) */
+  int integrator;
 } pdec_env_cfg;
 
 /* sensor_kernels [S][N], actuator_kernels [A][N] (host, double, row = one kernel: the

@@ -77,6 +77,18 @@ def do_step(cfg, y, p, substeps=None):
     return y
 
 
+def do_step_midpoint(cfg, y, p, oversampling):
+    """PDEenv's built-in integrator when no do_step is supplied (src/PDEenv.jl:208-214): explicit midpoint rule,
+    `oversampling` sub-steps of dt/oversampling."""
+    h = cfg.dt / oversampling
+    y = np.asarray(y, dtype=np.float64)
+    for _ in range(oversampling):
+        y_old = y
+        y = y + 0.5 * h * f(cfg, y, p)                                        # :211
+        y = y_old + h * f(cfg, y, p)                                          # :212
+    return y
+
+
 def reward_function(cfg, y, action, delta_action):
     """KellerSegelSetup.jl:241-257."""
     a2s = cfg.actuators_to_sensors - 1

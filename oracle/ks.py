@@ -130,6 +130,18 @@ def do_step_rk4_fd(cfg, y, p, K=None):
     return u
 
 
+def do_step_midpoint_fd(cfg, y, p, K=None):
+    """PDEenv's built-in integrator (src/PDEenv.jl:208-214: explicit midpoint, K = oversampling sub-steps) on rhs_fd"""
+    K = cfg.oversampling if K is None else K
+    h = cfg.dt / K
+    u = np.asarray(y, dtype=np.float64)
+    for _ in range(K):
+        u_old = u
+        u = u + 0.5 * h * rhs_fd(cfg, u, p)
+        u = u_old + h * rhs_fd(cfg, u, p)
+    return u
+
+
 def sensor_dots(cfg, y):
     return cfg.gaussians @ np.asarray(y, dtype=np.float64)
 

@@ -131,14 +131,16 @@ def test_host_pointer_wrapper(pkg):
     assert np.abs(out - g["y"][4]).max() <= 1e-12 and done[0] == 0
 
 
+@pytest.mark.parametrize("integ", ["rk4_fd", "midpoint_fd"])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 2e-4)])
-def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol):
+def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol, integ):
     """north-star variant: RK4 + periodic 5-point FD (stencils of KSSetup.jl:55-59); rhs, do_step and the fused
     (env)(action) against oracle/ks.py rhs_fd / do_step_rk4_fd (relative to max|value|)"""
     from oracle import ks
     nx, Lx, K, dtc = 240, 200.0, 30, 0.1
     pos = np.arange(1, nx + 1, 3)
-    setup = pkg.KSSetup(nx, Lx, pos, integrator="rk4_fd", mu=0.02, dt=dtc, oversampling=K, window_size=3)
+    setup = pkg.KSSetup(nx, Lx, pos, integrator=integ, mu=0.02, dt=dtc, oversampling=K, window_size=3)
+    step = ks.do_step_rk4_fd if integ == "rk4_fd" else ks.do_step_midpoint_fd     # midpoint: src/PDEenv.jl:208-214
     cfg = ks.KSConfig(nx, Lx, pos, mu=0.02, dt=dtc, oversampling=K, window_size=3)
     dt = torch.float64 if prec == "f64" else torch.float32
     rng = np.random.default_rng(4)
@@ -156,7 +158,7 @@ def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol):
     env.action.copy_(to_dev(a0, dt).reshape(env._ashape))
     env(to_dev(a1, dt).reshape(env._ashape))
     for b in range(B):
-        ref = ks.do_step_rk4_fd(cfg, y[b], p[b])
+        ref = step(cfg, y[b], p[b])
         assert np.abs(out[b].cpu().numpy() - ref).max() <= tol * np.abs(ref).max()
         assert np.abs(env.y[b].cpu().numpy() - ref).max() <= tol * np.abs(ref).max()
         st = ks.featurize(cfg, ref)

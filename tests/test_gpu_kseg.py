@@ -66,3 +66,20 @@ def test_reset_form_featurize(pkg):
     y0 = setup.y0_standard()
     st = kg.featurize(cfg, y0, None)
     assert np.abs(env.state[1].cpu().numpy().T - st).max() <= 1e-13
+
+
+def test_builtin_midpoint_integrator(pkg):
+    """PDEenv's own integrator when no do_step closure is given (src/PDEenv.jl:208-214): explicit midpoint rule with
+    `oversampling` sub-steps on the Keller-Segel right-hand side"""
+    from oracle import keller_segel as kg
+    g = load_golden("kseg_hook.npz")
+    K = 8
+    setup, cfg = pkg.KellerSegelSetup(integrator="midpoint", substeps=K), kg.KSegConfig()
+    B = 6
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float64)
+    y, p = g["y_t"][:B], g["p_t1"][:B]
+    out, _ = env.do_step(to_dev(_mem(y), torch.float64), to_dev(p, torch.float64))
+    for b in range(B):
+        ref = kg.do_step_midpoint(cfg, y[b], p[b], K)
+        assert np.abs(np.swapaxes(out[b].cpu().numpy(), 0, 1) - ref).max() <= 1e-12
+        assert np.abs(ref - g["y_t1"][b]).max() <= 1e-3        # second order: near (5e-4), not at, the adaptive solution
