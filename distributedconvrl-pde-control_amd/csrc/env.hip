@@ -190,6 +190,8 @@ struct FftGeneric {
   static __host__ __device__ size_t lds_complex(int N) { return 3 * (size_t)N; }
   // wave-space mode held in slot j after a forward transform (natural order for this engine)
   __device__ __forceinline__ int mode_index(int j) const { return tid + j * nt; }
+  // cell held in slot j in physical space
+  __device__ __forceinline__ int phys_index(int j) const { return tid + j * nt; }
   template <int SGN>
   __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
 #pragma unroll
@@ -241,6 +243,7 @@ struct FftR4 {
   }
   static __host__ __device__ size_t lds_complex(int) { return 2 * (size_t)N; }
   __device__ __forceinline__ int mode_index(int j) const { return tid + j * NT; }
+  __device__ __forceinline__ int phys_index(int j) const { return tid + j * NT; }
   template <int SGN>
   __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
 #pragma unroll
@@ -455,6 +458,7 @@ struct FftWave256 {
   __device__ __forceinline__ int mode_index(int j) const {
     return (tid >> 4) + 4 * ((tid >> 2) & 3) + 16 * (tid & 3) + 64 * j;
   }
+  __device__ __forceinline__ int phys_index(int j) const { return tid + NT * j; }
   template <int ST>
   __device__ __forceinline__ void exchange(C2<T> (&a)[4]) {
     if constexpr (sizeof(T) == 4) {
@@ -506,6 +510,100 @@ struct FftWave256 {
   }
 };
 
+// Compile-time mixed-radix engine for the reference's own grid sizes (KS22: 192 = 4.4.3.4, KS200: 240 = 4.5.3.4,
+// KS500: 600 = 4.5.5.2.3).  Stockham stages like FftGeneric, but (i) every radix, stride and index split is a template
+// constant (no runtime plan walk, divisions by constants, fully unrolled), and (ii) the plan has radices <= 4 at both
+// ends: in PHYSICAL space thread t owns the cells t + (N/R_first) j -- exactly the inputs of its first-stage butterfly
+// -- and in WAVE space the modes t + (N/R_last) k -- the outputs of its last-stage butterfly; the inverse runs the plan
+// backwards, so it consumes the wave-space layout and lands on the physical one.  A transform therefore costs L-1 LDS
+// round trips (the generic engine: L+2) and one butterfly per thread and stage.  A single wave per trajectory pair has
+// nothing to hide latency behind, so dependent round trips and instruction count ARE the step time at these sizes.
+template <class T, int N_, int L_, int R0, int R1, int R2, int R3, int R4>
+struct FftFixed {
+  static constexpr int N = N_, L = L_;
+  C2<T>* buf[2];
+  const C2<T>* tw;
+  int tid;
+  static constexpr int rad(int i) { return i == 0 ? R0 : (i == 1 ? R1 : (i == 2 ? R2 : (i == 3 ? R3 : R4))); }
+  static constexpr int M0 = N / R0, ML = N / rad(L - 1);
+  __device__ __forceinline__ void init(unsigned char* smem, const EnvDev<T>& e, int tid_, int nt) {
+    tid = tid_;
+    buf[0] = reinterpret_cast<C2<T>*>(smem);
+    buf[1] = buf[0] + N;
+    C2<T>* t = buf[1] + N;
+    for (int k = tid; k < N; k += nt) t[k] = e.tw[k];
+    tw = t;
+  }
+  static __host__ __device__ size_t lds_complex(int) { return 3 * (size_t)N; }
+  __device__ __forceinline__ int mode_index(int j) const { return (tid < ML && j < rad(L - 1)) ? tid + j * ML : N; }
+  __device__ __forceinline__ int phys_index(int j) const { return (tid < M0 && j < R0) ? tid + j * M0 : N; }
+
+  // one Stockham stage of radix R on sub-length NN with stride S; FIRST: inputs are the caller's registers,
+  // LAST: outputs stay in registers
+  template <int R, int SGN, bool FIRST, bool LAST, int NN, int S>
+  __device__ __forceinline__ void stage(C2<T> (&a)[KS_MPT], const C2<T>* __restrict__ X, C2<T>* __restrict__ Y) {
+    constexpr int m = NN / R, nb = N / R;
+    if (tid < nb) {
+      const int p = tid / S, q = tid - p * S;
+      C2<T> b[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (FIRST) b[j] = a[j < KS_MPT ? j : 0];
+        else b[j] = X[q + S * (p + m * j)];
+      }
+      C2<T> w[R];
+      const int ps = p * S;
+      if (!LAST) {
+#pragma unroll
+        for (int k = 1; k < R; ++k) w[k] = tw[ps * k];
+      }
+      dft_small<R, SGN, T>(b);
+      const int base = q + S * R * p;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        C2<T> v = b[k];
+        if (!LAST && k > 0) {
+          C2<T> ww = w[k];
+          if (SGN > 0) ww.y = -ww.y;
+          v = cmul(v, ww);
+        }
+        if (LAST) a[k < KS_MPT ? k : 0] = v;
+        else Y[base + S * k] = v;
+      }
+    }
+  }
+  // stage I of the (forward or reversed) plan, sub-length and stride accumulated at compile time
+  template <int SGN, int I, int NN, int S>
+  __device__ __forceinline__ void walk(C2<T> (&a)[KS_MPT]) {
+    if constexpr (I < L) {
+      constexpr int R = rad(SGN < 0 ? I : L - 1 - I);
+      constexpr bool FIRST = I == 0, LAST = I == L - 1;
+      // stage I reads what stage I-1 wrote: buffers alternate, stage 0 writes buf[0]
+      stage<R, SGN, FIRST, LAST, NN, S>(a, buf[(I + 1) & 1], buf[I & 1]);
+      if (!LAST) __syncthreads();
+      walk<SGN, I + 1, NN / R, S * R>(a);
+    }
+  }
+  template <int SGN>
+  __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
+    walk<SGN, 0, N, 1>(a);
+    __syncthreads();      // the last stage's readers are done before the next transform writes buf[0] again
+  }
+  __device__ __forceinline__ C2<T>* publish(const C2<T> (&a)[KS_MPT]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int k = phys_index(j);
+      if (k < N) buf[0][k] = a[j];
+    }
+    __syncthreads();
+    return buf[0];
+  }
+};
+template <class T> using FftFixed192 = FftFixed<T, 192, 4, 4, 4, 3, 4, 1>;
+template <class T> using FftFixed240 = FftFixed<T, 240, 4, 4, 5, 3, 4, 1>;
+template <class T> using FftFixed600 = FftFixed<T, 600, 5, 4, 5, 5, 2, 3>;
+
 template <class T, class ENG, bool FUSED>
 __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
                                    const T* __restrict__ action, const T* __restrict__ action_prev,
@@ -545,7 +643,7 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   // forcing p (packed pair) -> spectrum -> constant term of the CNAB2 update
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
-    const int n = tid + j * nt;
+    const int n = eng.phys_index(j);
     T pa = 0, pb = 0;
     if (n < N) {
       if (FUSED) {
@@ -583,7 +681,7 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   // Nn = G * fft(u^2);  u_hat = fft(u)
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
-    const int n = tid + j * nt;
+    const int n = eng.phys_index(j);
     U[j] = n < N ? mk<T>(y_in[o0 + n], has1 ? y_in[o1 + n] : (T)0) : mk<T>(0, 0);
     v[j] = mk<T>(U[j].x * U[j].x, U[j].y * U[j].y);
   }
@@ -615,7 +713,7 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   T mx0 = 0, mx1 = 0;
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
-    const int n = tid + j * nt;
+    const int n = eng.phys_index(j);
     U[j] = mk<T>(U[j].x * invN, U[j].y * invN);
     if (n < N) {
       y_out[o0 + n] = U[j].x;
@@ -971,7 +1069,7 @@ static EnvDev<T> make_dev(const Env& E) {
 
 static size_t ks_lds_bytes(const pdec_env_cfg& c, int r4_log) {
   const size_t ts = dtype_size(c.dtype);
-  return (r4_log == 1 ? 1 : (r4_log ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
+  return (r4_log == 1 ? 1 : ((r4_log == 4 || r4_log == 5) ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
 }
 static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
@@ -1005,6 +1103,9 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
     if (E.r4_log == 1) { if (fused) KS_LAUNCH(FftWave256<T>, true); else KS_LAUNCH(FftWave256<T>, false); }
     else if (E.r4_log == 4) { if (fused) KS_LAUNCH(FftR4<T COMMA 4>, true); else KS_LAUNCH(FftR4<T COMMA 4>, false); }
     else if (E.r4_log == 5) { if (fused) KS_LAUNCH(FftR4<T COMMA 5>, true); else KS_LAUNCH(FftR4<T COMMA 5>, false); }
+    else if (E.r4_log == 7) { if (fused) KS_LAUNCH(FftFixed192<T>, true); else KS_LAUNCH(FftFixed192<T>, false); }
+    else if (E.r4_log == 8) { if (fused) KS_LAUNCH(FftFixed240<T>, true); else KS_LAUNCH(FftFixed240<T>, false); }
+    else if (E.r4_log == 9) { if (fused) KS_LAUNCH(FftFixed600<T>, true); else KS_LAUNCH(FftFixed600<T>, false); }
     else { if (fused) KS_LAUNCH(FftGeneric<T>, true); else KS_LAUNCH(FftGeneric<T>, false); }
 #undef KS_LAUNCH
   } else if (c.pde_kind == PDEC_PDE_KSEG_RK4) {
@@ -1091,6 +1192,14 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
     // engines: 1 = single-wave register FFT (N = 256), 4 / 5 = radix-4 through LDS (N = 256 / 1024), 0 = generic
     E->r4_log = (N == 256 && !getenv("PDEC_KS_GENERIC_FFT")) ? (getenv("PDEC_KS_LDS_FFT") ? 4 : 1)
                                                               : ((N == 1024 && !getenv("PDEC_KS_GENERIC_FFT")) ? 5 : 0);
+    if (E->r4_log == 0 && !getenv("PDEC_KS_GENERIC_FFT")) {
+      // engines 7 / 8 / 9: compile-time plans for the grids of the shipped experiments (KS22, KS200, KS500); one
+      // butterfly per thread and stage -> nt = the largest N / radix, rounded up to whole waves
+      if (N == 192) { E->r4_log = 7; nt = 64; }
+      else if (N == 240) { E->r4_log = 8; nt = 128; }
+      else if (N == 600) { E->r4_log = 9; nt = 320; }
+      E->nthreads = nt;
+    }
     E->lds_bytes = ks_lds_bytes(c, E->r4_log);
     PDEC_REQUIRE(E->lds_bytes <= 160 * 1024, "KS kernel needs %zu B of LDS (> 160 KiB)", E->lds_bytes);
     // per-mode constants, scripts/KS/setup/KSSetup.jl:115-123,131-135
