@@ -918,6 +918,8 @@ int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double a
   PDEC_REQUIRE(state && actions_out && cols >= 1, "pdec_policy_act_rng: null/empty");
   if (fused_net_supported(M) && M->dims[M->L] == 1 && M->dims[1] <= 31)
     return fused_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out);
+  if (fused2_act_supported(M, cols))
+    return fused2_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out);
   void* noise = nullptr;
   if (learning) {
     const size_t n = (size_t)cols * M->dims[M->L];

@@ -70,6 +70,9 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
 // mlp_mfma2.hip: the same passes for the reference-shaped 2-layer nets [ns, h, 1] / [ns+1, H, 1] (flat parameters, no image)
 bool fused2_supported(const Mlp* A, const Mlp* C);
 bool fused2_net_supported(const Mlp* M);
+bool fused2_act_supported(const Mlp* A, int cols);
+int fused2_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning, uint64_t seed,
+                      uint64_t offset, void* actions_out);
 int fused2_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap);
 int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
                         const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,

@@ -647,6 +647,50 @@ __global__ void apply2_kernel(Finish2Args g, int n) {
   if (i < n) finish2_param(g, i, g.grads[i]);
 }
 
+// ------------------------------------------------------------------ fused policy act (2-layer actor)
+// actions = clamp(actor(state) + randn * act_noise, +-act_limit)   (src/PDEagent.jl:183-207) in ONE launch: first layer
+// on MFMA out of the padded LDS image, output row + tanh, exploration noise from the Philox stream of pdec_randn
+// (element index = column: both paths draw identical numbers), clamp.  256 threads = 4 waves x 16 columns.
+template <int MTA, int KB>
+__global__ __launch_bounds__(256) void policy_act2_kernel(Net2 n, const float* __restrict__ state, int cols, float act_noise,
+                                                          float lim, int learning, int tanh_out, uint64_t seed, uint64_t offset,
+                                                          float* __restrict__ out) {
+  constexpr int LDK = 8 * KB + 4, HPa = 16 * MTA;
+  extern __shared__ __align__(16) float smem[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
+  const Lds2 SA = carve2(smem, HPa, LDK);
+  // image load with 256 threads (load_net2 assumes FTHREADS): plain row copy, the actor is small
+  for (int i = tid; i < HPa * LDK; i += 256) {
+    const int r = i / LDK, c = i - r * LDK;
+    SA.W1[i] = (r < n.H && c < n.K0) ? n.p[(size_t)r * n.K0 + c] : 0.f;
+  }
+  const float* b1 = n.p + (size_t)n.H * n.K0;
+  for (int i = tid; i < HPa; i += 256) { SA.b1[i] = i < n.H ? b1[i] : 0.f; SA.w2[i] = i < n.H ? b1[n.H + i] : 0.f; }
+  if (tid == 0) SA.b2[0] = b1[2 * n.H];
+  __syncthreads();
+  const int c = blockIdx.x * 64 + w * 16 + lr;
+  const bool valid = c < cols;
+  float x[K2MAX][2];
+  load_x2(x, state, (size_t)c, n.K0, KB, q, valid);
+  f32x4 ha[MTA];
+  layer1_keep<MTA, KB>(ha, x, SA, lr, q);
+  float o = head<MTA>(ha, SA.w2, SA.b2[0], q);
+  if (!valid || q != 0) return;
+  if (tanh_out) o = tanhf(o);
+  if (learning) {
+    const uint64_t ctr = offset + (uint64_t)(c >> 2);
+    uint32_t ph[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    philox4x32(ph, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int hsel = (c >> 1) & 1;
+    const double sc = 1.0 / 4294967296.0;
+    const double u1 = ((double)ph[2 * hsel] + 0.5) * sc, u2 = ((double)ph[2 * hsel + 1] + 0.5) * sc;
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+    const float z = (float)((c & 1) ? rad * sin(ang) : rad * cos(ang));
+    o += z * act_noise;
+  }
+  out[c] = fminf(fmaxf(o, -lim), lim);
+}
+
 // ------------------------------------------------------------------ host side
 static int mt2_of(int H) { return (H + 1 + 15) / 16; }
 
@@ -763,6 +807,31 @@ static int launch_finish2(Mlp* M, Mlp* Mt, int nslab, int MT, int nR, double gra
     M->fw_dirty = true;
     if (Mt) Mt->fw_dirty = true;
   }
+  return PDEC_OK;
+}
+
+// 2-layer fp32 actor [ns, h, 1] (relu, tanh | identity), h <= 31, ns <= 48, at least a few hundred columns
+bool fused2_act_supported(const Mlp* A, int cols) {
+  if (fused2_disabled() || A->dtype != PDEC_F32 || A->L != 2 || A->dims[2] != 1 || cols < 256) return false;
+  if (A->acts[0] != PDEC_ACT_RELU || (A->acts[1] != PDEC_ACT_TANH && A->acts[1] != PDEC_ACT_IDENTITY)) return false;
+  return A->dims[0] <= 8 * K2MAX && mt2_of(A->dims[1]) <= 2;
+}
+
+int fused2_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning, uint64_t seed,
+                      uint64_t offset, void* actions_out) {
+  const Net2 n = net2_of(A);
+  const int mta = mt2_of(A->dims[1]), tanh_out = A->acts[1] == PDEC_ACT_TANH;
+  const dim3 grid((cols + 63) / 64), block(256);
+  ProfScope ps(A, "policy_act_fused");
+#define ACT2(MTA, KB)                                                                                                       \
+  hipLaunchKernelGGL((policy_act2_kernel<MTA, KB>), grid, block, (size_t)lds2_floats(16 * MTA, 8 * KB + 4) * 4, A->stream, n, \
+                     (const float*)state, cols, (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset,       \
+                     (float*)actions_out)
+  if (n.kb <= 2) { if (mta == 1) ACT2(1, 2); else ACT2(2, 2); }
+  else if (n.kb <= 5) { if (mta == 1) ACT2(1, 5); else ACT2(2, 5); }
+  else { if (mta == 1) ACT2(1, 6); else ACT2(2, 6); }
+#undef ACT2
+  PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
 

@@ -158,16 +158,17 @@ def test_randn_moments_and_determinism(pkg):
     assert not torch.equal(a, b)
 
 
-@pytest.mark.parametrize("dims_scale", [1.6, 1.2])
-def test_policy_act_rng_equals_randn_plus_act(pkg, dims_scale):
+@pytest.mark.parametrize("ns,dims_scale,drop", [(3, 1.6, False), (3, 1.2, False), (36, 2.0, True), (12, 2.0, True), (1, 0.6, True),
+                                                (9, 1.8, True), (44, 3.0, True)])
+def test_policy_act_rng_equals_randn_plus_act(pkg, ns, dims_scale, drop):
     """pdec_policy_act_rng (one launch, noise drawn in-kernel) == pdec_randn + pdec_policy_act: the same Philox
     stream element per column; forward within the fp32 tolerance (1e-5 rel) of the fp64 oracle"""
     from oracle import nn
     rng = np.random.default_rng(9)
-    dims, acts = nn.layer_sizes(3, 1, dims_scale, True, False)     # 3->16->16->1 / 3->12->12->1
+    dims, acts = nn.layer_sizes(ns, 1, dims_scale, True, drop)     # 3->16->16->1 / 3->12->12->1 / 2-layer ns->h->1
     cols = 1000
     net, P = make_net(pkg, rng, dims, acts, torch.float32, cols)
-    state = rng.standard_normal((3, cols)).astype(np.float32)
+    state = rng.standard_normal((ns, cols)).astype(np.float32)
     dstate = to_dev(state.T, torch.float32)
     noise = torch.empty((cols, 1), dtype=torch.float32, device="cuda:0")
     seed, off = 4321, 17
