@@ -249,16 +249,19 @@ __global__ void kseg2d_boxsum_kernel(K2Dev<T> e, const C2<T>* __restrict__ y, T*
 }
 
 // reward (KellerSegelSetup.jl:241-257) and featurize (:265-316, 3x3 circular window in the
-// scripts/Fluid/setup/FluidSetup.jl:219-223 shift order) for column (b, a)
+// scripts/Fluid/setup/FluidSetup.jl:219-223 shift order): one thread per STATE ELEMENT (b, a, row), so consecutive
+// lanes write consecutive addresses; the row-0 thread of a column also evaluates its reward
 template <class T>
 __global__ void kseg2d_feat_kernel(K2Dev<T> e, const T* __restrict__ sums, const T* __restrict__ action,
                                    const T* __restrict__ action_prev, const T* __restrict__ state_prev,
                                    T* __restrict__ state_out, T* __restrict__ reward_out, int32_t* __restrict__ done) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= e.B * e.A) return;
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)e.B * e.A * e.ns;
+  if (gi >= total) return;
+  const int i = (int)(gi / e.ns), rr = (int)(gi - (size_t)i * e.ns);          // column, row
   const int b = i / e.A, a = i - b * e.A, s = e.a2s[a], iy = s / e.Sx, ix = s - iy * e.Sx;
   const T* sb = sums + (size_t)b * 2 * e.S;
-  if (reward_out) {
+  if (reward_out && rr == 0) {
     const int cy = e.sy[iy], cx = e.sx[ix];
     const int nr = min(cy + e.hw, e.ny - 1) - max(cy - e.hw, 0) + 1, nc = min(cx + e.hw, e.nx - 1) - max(cx - e.hw, 0) + 1;
     const T d = e.r_in_scale * (sb[s] + e.r_offset * (T)(nr * nc));
@@ -268,23 +271,20 @@ __global__ void kseg2d_feat_kernel(K2Dev<T> e, const T* __restrict__ sums, const
     if (done && e.check_max == 2 && !(fabs(r) <= e.max_value)) atomicOr(done + b, 1);
   }
   if (state_out) {
-    const int w = e.window / 2, fresh = 2 * e.window * e.window;
-    T* so = state_out + (size_t)i * e.ns;
-    for (int rr = 0; rr < e.ns; ++rr) {
-      T v;
-      if (rr < fresh || state_prev == nullptr) {
-        const int r0 = rr % fresh, sp = r0 / (e.window * e.window), q = r0 - sp * e.window * e.window;
-        const int di = q / e.window - w, dj = q - (q / e.window) * e.window - w;
-        // circshift(sensors, [di, dj])[iy, ix] = sensors[iy - di, ix - dj]
-        int jy = (iy - di) % e.Sy, jx = (ix - dj) % e.Sx;
-        if (jy < 0) jy += e.Sy;
-        if (jx < 0) jx += e.Sx;
-        v = sb[(size_t)sp * e.S + jy * e.Sx + jx] * e.sensor_scale;
-      } else {
-        v = state_prev[(size_t)i * e.ns + (rr - fresh)];
-      }
-      so[rr] = v;
+    const int w = e.window / 2, ww = e.window * e.window, fresh = 2 * ww;
+    T v;
+    if (rr < fresh || state_prev == nullptr) {
+      const int r0 = rr % fresh, sp = r0 / ww, q = r0 - sp * ww;
+      const int di = q / e.window - w, dj = q - (q / e.window) * e.window - w;
+      // circshift(sensors, [di, dj])[iy, ix] = sensors[iy - di, ix - dj]
+      int jy = (iy - di) % e.Sy, jx = (ix - dj) % e.Sx;
+      if (jy < 0) jy += e.Sy;
+      if (jx < 0) jx += e.Sx;
+      v = sb[(size_t)sp * e.S + jy * e.Sx + jx] * e.sensor_scale;
+    } else {
+      v = state_prev[gi - fresh];
     }
+    state_out[gi] = v;
   }
 }
 
@@ -384,7 +384,8 @@ static int k2_sense(Kseg2dEnv& E, const void* y, const void* action, const void*
   hipLaunchKernelGGL(kseg2d_boxsum_kernel<T>, dim3((nS + 127) / 128), dim3(128), 0, E.stream, k2_dev<T>(E), (const C2<T>*)y,
                      E.sums.as<T>());
   PDEC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(kseg2d_feat_kernel<T>, dim3((nA + 127) / 128), dim3(128), 0, E.stream, k2_dev<T>(E), E.sums.as<T>(),
+  const size_t nel = (size_t)nA * (2 * E.cfg.window * E.cfg.window * E.cfg.temporal_steps);
+  hipLaunchKernelGGL(kseg2d_feat_kernel<T>, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, E.stream, k2_dev<T>(E), E.sums.as<T>(),
                      (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)state_out, (T*)reward_out, done);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
