@@ -147,3 +147,34 @@ def test_properties_at_full_size(pkg):
     o2, _ = env32b.do_step(y.float(), p.float())
     assert float((o2.double() - out).abs().max()) <= 2e-5
     assert float((o2 - o1).abs().max()) <= 2e-6
+
+
+def test_host_pointer_wrappers(pkg):
+    """pdec_pde_step_host / pdec_env_step_host (what a Julia closure binds: host arrays in and out) on the 2-D grid"""
+    from oracle import keller_segel2d as k2
+    nx, ny = 64, 20
+    setup, cfg = _pair(pkg, nx, ny, substeps=3)
+    B = 2
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float64)
+    y, a, ap = _fields(np.random.default_rng(8), B, ny, nx, cfg.A)
+    p = np.stack([k2.prepare_action(cfg, a[b]) for b in range(B)])
+    ym = _mem(y)
+    out = np.empty_like(ym)
+    done = np.zeros(B, dtype=np.int32)
+    lib = pkg._lib.load()
+    pkg._lib.check(lib.pdec_pde_step_host(env.handle, ym.ctypes.data, np.ascontiguousarray(p).ctypes.data, out.ctypes.data,
+                                          done.ctypes.data))
+    ref = np.stack([k2.do_step(cfg, y[b], p[b]) for b in range(B)])
+    assert np.abs(np.moveaxis(out, -1, -3) - ref).max() <= 1e-11 and not done.any()
+    ns = setup.state_shape[0]
+    prev = np.stack([k2.featurize(cfg, y[b], None) for b in range(B)])
+    sp = np.ascontiguousarray(np.swapaxes(prev, 1, 2))
+    yo, po = np.empty_like(ym), np.empty((B, ny, nx))
+    so, ro = np.empty((B, cfg.A, ns)), np.empty((B, cfg.A))
+    a2, ap2 = np.ascontiguousarray(a.reshape(B, cfg.A)), np.ascontiguousarray(ap.reshape(B, cfg.A))
+    pkg._lib.check(lib.pdec_env_step_host(env.handle, ym.ctypes.data, a2.ctypes.data, ap2.ctypes.data, sp.ctypes.data,
+                                          yo.ctypes.data, po.ctypes.data, so.ctypes.data, ro.ctypes.data, done.ctypes.data))
+    assert np.abs(np.moveaxis(yo, -1, -3) - ref).max() <= 1e-11 and np.abs(po - p).max() <= 1e-13
+    for b in range(B):
+        assert np.abs(so[b].T - k2.featurize(cfg, ref[b], prev[b])).max() <= 1e-11
+        assert np.abs(ro[b] - k2.reward_function(cfg, ref[b], a[b], a[b] - ap[b])).max() <= 1e-11
