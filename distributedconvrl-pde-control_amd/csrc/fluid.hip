@@ -491,24 +491,27 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
 // Same three passes, but every line transform runs in the registers of ONE wave (wave_fft.hpp): no LDS stage
 // round trips, no barriers inside a transform.  LDS is only used to turn coalesced global accesses into the
 // permuted (digit-reversed) element order the transforms consume / produce, and for K2's column transposition.
-// Used when the padded length p is one of 128/256/384/512/768 (otherwise the LDS-tile kernels above).
+// Used when the padded length p is one of 64/128/192/256/384/512/768 (otherwise the LDS-tile kernels above); 64 and
+// 192 run two lines per wave (half-wave transforms).
 
 // K1w: one wave per carried line s.  LDS: per wave the two spectrum lines j and mirror(j) (2 n complex).
-template <int E, int Q>
+template <int E, int Q, int LB>
 __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, const C2<double>* __restrict__ omg,
                                                         C2<double>* __restrict__ W) {
-  typedef WaveFftD<E, Q> F;
+  typedef WaveFftD<E, Q, LB> F;
   typedef C2<double> Z;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = d.n, p = d.p;
-  Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)wv * 2 * n;
+  // a "line slot" is a wave (LB = 6) or a half wave (LB = 5: two lines per wave); l = position inside the line
+  const int lane = threadIdx.x & 63, l = lane & (F::LANES - 1), slot = (threadIdx.x >> 6) * F::LPW + (lane >> LB);
+  const int n = d.n, p = d.p;
+  Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)slot * 2 * n;
   Z* Lm = Lj + n;
-  const int s = blockIdx.x * 4 + wv, b = blockIdx.y;
-  if (s >= d.nl) return;                                  // whole wave; the kernel has no workgroup barrier
+  const int s = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
+  if (s >= d.nl) return;                                  // whole line slot; the kernel has no workgroup barrier
   const int jp = fl_line_jp(s, n, p, d.nl);
   const int j = fl_unpad(jp, n, p), jm = fl_unpad((p - jp) % p, n, p);
   const Z zero = mk<double>(0, 0);
-  for (int i = lane; i < n; i += 64) {
+  for (int i = l; i < n; i += F::LANES) {
     Lj[i] = j >= 0 ? omg[((size_t)b * n + j) * n + i] : zero;
     Lm[i] = jm >= 0 ? omg[((size_t)b * n + jm) * n + i] : zero;
   }
@@ -537,38 +540,39 @@ __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, cons
     f.inverse(a);
     Z* w = W + (((size_t)b * 2 + fld) * d.nl + s) * p;
 #pragma unroll
-    for (int jj = 0; jj < F::R; ++jj) w[lane + 64 * jj] = a[jj];
+    for (int jj = 0; jj < F::R; ++jj) w[l + F::LANES * jj] = a[jj];
   }
 }
 
 // K2w: TC columns per workgroup, one wave per column.  LDS: the [TC][p] column tile (transposition + permuted access).
 // TC = 4 keeps the tile at 48 KB so that several workgroups share a CU and one's global loads / stores overlap the
 // others' transforms (with TC = 8 a CU holds a single workgroup and load -> transform -> store serialise).
-template <int E, int Q, int TC>
-__global__ __launch_bounds__(64 * TC) void fluid_k2w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W,
+template <int E, int Q, int TC, int LB>
+__global__ __launch_bounds__(64 * TC >> (6 - LB)) void fluid_k2w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W,
                                                             C2<double>* __restrict__ W2) {
-  typedef WaveFftD<E, Q> F;
+  typedef WaveFftD<E, Q, LB> F;
   typedef C2<double> Z;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   Z* tile = reinterpret_cast<Z*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = d.n, p = d.p, LS = p + 1;
+  constexpr int NT = 64 * TC / F::LPW;                      // one line slot (wave or half wave) per column
+  const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) * F::LPW + (lane >> LB), n = d.n, p = d.p, LS = p + 1;
   const int ip0 = blockIdx.x * TC, b = blockIdx.y;
   F f;
   f.init(d.twp, lane);
   Z r0[F::R], a[F::R];
   // tile element (t, jp) of a field: W[fld][s(jp)][ip0 + t] or 0 (pad() along x); thread-strided over the TC x p tile
-  constexpr int NPF = (F::N + 63) / 64;                     // elements per thread (TC * p / (64 TC))
+  constexpr int NPF = (TC * F::N + NT - 1) / NT;            // tile elements per thread
   auto tile_src = [&](int fld, int idx) -> Z {
     const int t = idx % TC, jp = idx / TC;
     const int s = fl_line_of(jp, n, p, d.nl), ip = ip0 + t;
     if (s >= 0 && ip < p) return W[(((size_t)b * 2 + fld) * d.nl + s) * p + ip];
     return mk<double>(0, 0);
   };
-  for (int idx = tid; idx < TC * p; idx += 64 * TC) tile[(idx % TC) * LS + idx / TC] = tile_src(0, idx);
+  for (int idx = tid; idx < TC * p; idx += NT) tile[(idx % TC) * LS + idx / TC] = tile_src(0, idx);
   Z pre[NPF];                                               // field 1 is fetched while field 0 is transformed
 #pragma unroll
   for (int u = 0; u < NPF; ++u) {
-    const int idx = tid + u * 64 * TC;
+    const int idx = tid + u * NT;
     pre[u] = idx < TC * p ? tile_src(1, idx) : mk<double>(0, 0);
   }
   __syncthreads();
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(64 * TC) void fluid_k2w_kernel(FluidDev<double> d, 
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < NPF; ++u) {
-    const int idx = tid + u * 64 * TC;
+    const int idx = tid + u * NT;
     if (idx < TC * p) tile[(idx % TC) * LS + idx / TC] = pre[u];
   }
   __syncthreads();
@@ -593,31 +597,32 @@ __global__ __launch_bounds__(64 * TC) void fluid_k2w_kernel(FluidDev<double> d, 
 #pragma unroll
   for (int jj = 0; jj < F::R; ++jj) tile[wv * LS + f.mode_index(jj)] = a[jj];
   __syncthreads();
-  for (int idx = tid; idx < TC * n; idx += 64 * TC) {        // chop() along x + coalesced store
+  for (int idx = tid; idx < TC * n; idx += NT) {        // chop() along x + coalesced store
     const int t = idx % TC, jj = idx / TC, ip = ip0 + t;
     if (ip < p) W2[((size_t)b * n + jj) * p + ip] = tile[t * LS + fl_pad(jj, n, p)];
   }
 }
 
 // K3w: one wave per kept line j.  LDS: per wave one n-complex line (digit-reversed -> natural for coalesced global access).
-template <int E, int Q>
+template <int E, int Q, int LB>
 __global__ __launch_bounds__(256) void fluid_k3w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W2,
                                                         const C2<double>* omg_s, const C2<double>* __restrict__ phat,
                                                         const C2<double>* f0, C2<double>* acc, C2<double>* out, int mode,
                                                         double ca, double cb) {
-  typedef WaveFftD<E, Q> F;
+  typedef WaveFftD<E, Q, LB> F;
   typedef C2<double> Z;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = d.n, p = d.p;
-  Z* Ln = reinterpret_cast<Z*>(smem_raw) + (size_t)wv * n;
-  const int j = blockIdx.x * 4 + wv, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, l = lane & (F::LANES - 1), slot = (threadIdx.x >> 6) * F::LPW + (lane >> LB);
+  const int n = d.n, p = d.p;
+  Z* Ln = reinterpret_cast<Z*>(smem_raw) + (size_t)slot * n;
+  const int j = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
   if (j >= n) return;
   F f;
   f.init(d.twp, lane);
   Z a[F::R];
   const Z* w2 = W2 + ((size_t)b * n + j) * p;
 #pragma unroll
-  for (int jj = 0; jj < F::R; ++jj) a[jj] = w2[lane + 64 * jj];
+  for (int jj = 0; jj < F::R; ++jj) a[jj] = w2[l + F::LANES * jj];
   f.forward(a);
 #pragma unroll
   for (int jj = 0; jj < F::R; ++jj) {
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(256) void fluid_k3w_kernel(FluidDev<double> d, cons
   }
   __builtin_amdgcn_wave_barrier();
   const double kj = d.k[j];
-  for (int i = lane; i < n; i += 64) {
+  for (int i = l; i < n; i += F::LANES) {
     const size_t off = ((size_t)b * n + j) * n + i;
     const double ki = d.k[i], lin = -d.nu * (kj * kj + ki * ki);
     const Z o = omg_s[off], nlv = Ln[i], ph = phat[off];
@@ -649,11 +654,12 @@ __global__ __launch_bounds__(256) void fluid_k3w_kernel(FluidDev<double> d, cons
 }
 
 // ------------------------------------------------------------------ wave FFT unit-test entry (pdec_debug_wave_fft)
-template <int E, int Q>
+template <int E, int Q, int LB>
 __global__ __launch_bounds__(256) void wave_fft_debug_kernel(const C2<double>* __restrict__ in, C2<double>* __restrict__ out,
                                                             const C2<double>* __restrict__ tw, int nlines, int sgn) {
-  typedef WaveFftD<E, Q> F;
-  const int lane = threadIdx.x & 63, line = blockIdx.x * 4 + (threadIdx.x >> 6);
+  typedef WaveFftD<E, Q, LB> F;
+  const int lane = threadIdx.x & 63, l = lane & (F::LANES - 1);
+  const int line = (blockIdx.x * 4 + (threadIdx.x >> 6)) * F::LPW + (lane >> LB);
   if (line >= nlines) return;
   F f;
   f.init(tw, lane);
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(256) void wave_fft_debug_kernel(const C2<double>* _
   C2<double>* y = out + (size_t)line * F::N;
   if (sgn < 0) {
 #pragma unroll
-    for (int j = 0; j < F::R; ++j) a[j] = x[lane + 64 * j];
+    for (int j = 0; j < F::R; ++j) a[j] = x[l + F::LANES * j];
     f.forward(a);
 #pragma unroll
     for (int j = 0; j < F::R; ++j) y[f.mode_index(j)] = a[j];
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(256) void wave_fft_debug_kernel(const C2<double>* _
     for (int j = 0; j < F::R; ++j) a[j] = x[f.mode_index(j)];
     f.inverse(a);
 #pragma unroll
-    for (int j = 0; j < F::R; ++j) y[lane + 64 * j] = a[j];
+    for (int j = 0; j < F::R; ++j) y[l + F::LANES * j] = a[j];
   }
 }
 
@@ -713,6 +719,7 @@ struct FluidEnv : Env {
   DevBuf W, W2, fs, acc, yreal, tmpc, dots, phat, icv;
   size_t lds_p = 0, lds_n = 0;
   int wave_E = 0, wave_Q = 0;     // != 0: the one-line-per-wave transforms serve the padded length p
+  int wave_LB = 6;                // 5: one line per HALF wave (p = 192, 64)
 };
 
 static FluidDev<double> fluid_dev(const FluidEnv& E) {
@@ -754,34 +761,35 @@ static int fluid_set_attrs(const FluidEnv& E) {
 }
 
 // one rhs evaluation fused with an RK4 stage update (mode as in fluid_k3_kernel)
-template <int E, int Q>
+template <int E, int Q, int LB>
 static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const void* omg_s, const void* phat, const void* f0,
                                  void* acc, void* out, int mode, double ca, double cb) {
   typedef C2<double> Z;
   const int B = Ev.cfg.B, n = Ev.n, p = Ev.p;
+  constexpr int LPW = 64 >> LB, LPB = 4 * LPW;               // line slots per wave / per 256-thread workgroup
   static bool attr = false;
   if (!attr) {
-    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k1w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k2w_kernel<E, Q, FL_K2_TC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k3w_kernel<E, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k1w_kernel<E, Q, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k2w_kernel<E, Q, FL_K2_TC, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k3w_kernel<E, Q, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   {
     ProfScope ps(&Ev, "fluid_k1", true);
     for (int r = 0; r < ps.reps; ++r)
-      hipLaunchKernelGGL((fluid_k1w_kernel<E, Q>), dim3((Ev.nl + 3) / 4, B), dim3(256), (size_t)4 * 2 * n * 16, Ev.stream, d,
+      hipLaunchKernelGGL((fluid_k1w_kernel<E, Q, LB>), dim3((Ev.nl + LPB - 1) / LPB, B), dim3(256), (size_t)LPB * 2 * n * 16, Ev.stream, d,
                          (const Z*)omg_s, Ev.W.as<Z>());
   }
   {
     ProfScope ps(&Ev, "fluid_k2", true);
     for (int r = 0; r < ps.reps; ++r)
-      hipLaunchKernelGGL((fluid_k2w_kernel<E, Q, FL_K2_TC>), dim3((p + FL_K2_TC - 1) / FL_K2_TC, B), dim3(64 * FL_K2_TC),
+      hipLaunchKernelGGL((fluid_k2w_kernel<E, Q, FL_K2_TC, LB>), dim3((p + FL_K2_TC - 1) / FL_K2_TC, B), dim3(64 * FL_K2_TC / LPW),
                          (size_t)FL_K2_TC * (p + 1) * 16, Ev.stream, d, Ev.W.as<Z>(), Ev.W2.as<Z>());
   }
   {
     ProfScope ps(&Ev, "fluid_k3", mode == 0);
     for (int r = 0; r < ps.reps; ++r)
-      hipLaunchKernelGGL((fluid_k3w_kernel<E, Q>), dim3((n + 3) / 4, B), dim3(256), (size_t)4 * n * 16, Ev.stream, d,
+      hipLaunchKernelGGL((fluid_k3w_kernel<E, Q, LB>), dim3((n + LPB - 1) / LPB, B), dim3(256), (size_t)LPB * n * 16, Ev.stream, d,
                          Ev.W2.as<Z>(), (const Z*)omg_s, (const Z*)phat, (const Z*)f0, (Z*)acc, (Z*)out, mode, ca, cb);
   }
   PDEC_HIP(hipGetLastError());
@@ -793,11 +801,13 @@ static int fluid_rhs_launch(FluidEnv& E, const void* omg_s, const void* phat, co
   typedef C2<double> Z;
   const FluidDev<double> d = fluid_dev(E);
   const int B = E.cfg.B;
-  if (E.wave_E == 4 && E.wave_Q == 3) return fluid_rhs_launch_wave<4, 3>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
-  if (E.wave_E == 4 && E.wave_Q == 2) return fluid_rhs_launch_wave<4, 2>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
-  if (E.wave_E == 4 && E.wave_Q == 1) return fluid_rhs_launch_wave<4, 1>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
-  if (E.wave_E == 2 && E.wave_Q == 3) return fluid_rhs_launch_wave<2, 3>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
-  if (E.wave_E == 2 && E.wave_Q == 1) return fluid_rhs_launch_wave<2, 1>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 4 && E.wave_Q == 3) return fluid_rhs_launch_wave<4, 3, 6>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 4 && E.wave_Q == 2) return fluid_rhs_launch_wave<4, 2, 6>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 4 && E.wave_Q == 1) return fluid_rhs_launch_wave<4, 1, 6>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 2 && E.wave_Q == 3 && E.wave_LB == 6) return fluid_rhs_launch_wave<2, 3, 6>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 2 && E.wave_Q == 1 && E.wave_LB == 6) return fluid_rhs_launch_wave<2, 1, 6>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 2 && E.wave_Q == 3 && E.wave_LB == 5) return fluid_rhs_launch_wave<2, 3, 5>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
+  if (E.wave_E == 2 && E.wave_Q == 1 && E.wave_LB == 5) return fluid_rhs_launch_wave<2, 1, 5>(E, d, omg_s, phat, f0, acc, out, mode, ca, cb);
   {
     ProfScope ps(&E, "fluid_k1", true);
     for (int r = 0; r < ps.reps; ++r)
@@ -996,6 +1006,8 @@ extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, in
       case 256: E->wave_E = 4; E->wave_Q = 1; break;
       case 384: E->wave_E = 2; E->wave_Q = 3; break;
       case 128: E->wave_E = 2; E->wave_Q = 1; break;
+      case 192: E->wave_E = 2; E->wave_Q = 3; E->wave_LB = 5; break;     // the reference's 128^2 training grid, padded
+      case 64: E->wave_E = 2; E->wave_Q = 1; E->wave_LB = 5; break;
       default: break;
     }
   }
@@ -1057,7 +1069,7 @@ extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, in
 }
 
 // Unit-test entry for the register-resident wave FFT (wave_fft.hpp): nlines lines of `len` complex doubles, natural
-// order in and out, unnormalised forward (sgn < 0) or inverse (sgn > 0).  len in {128, 256, 384, 512, 768}.
+// order in and out, unnormalised forward (sgn < 0) or inverse (sgn > 0).  len in {64, 128, 192, 256, 384, 512, 768}.
 extern "C" int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, int nlines, int sgn) {
   PDEC_REQUIRE(in_dev && out_dev && nlines >= 1, "pdec_debug_wave_fft: null/empty");
   std::vector<double> tw(2 * (size_t)len);
@@ -1065,15 +1077,17 @@ extern "C" int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, i
   DevBuf d;
   int rc = upload_converted(d, tw.data(), tw.size(), PDEC_F64);
   if (rc) return rc;
-  const dim3 grid((nlines + 3) / 4), block(256);
+  const dim3 block(256);
   typedef const C2<double>* CI;
   typedef C2<double>* CO;
-#define WFD(E, Q) hipLaunchKernelGGL((wave_fft_debug_kernel<E, Q>), grid, block, 0, 0, (CI)in_dev, (CO)out_dev, d.as<C2<double>>(), nlines, sgn)
-  if (len == 768) WFD(4, 3);
-  else if (len == 512) WFD(4, 2);
-  else if (len == 256) WFD(4, 1);
-  else if (len == 384) WFD(2, 3);
-  else if (len == 128) WFD(2, 1);
+#define WFD(E, Q, LB) hipLaunchKernelGGL((wave_fft_debug_kernel<E, Q, LB>), dim3((nlines + 4 * (64 >> LB) - 1) / (4 * (64 >> LB))), block, 0, 0, (CI)in_dev, (CO)out_dev, d.as<C2<double>>(), nlines, sgn)
+  if (len == 768) WFD(4, 3, 6);
+  else if (len == 512) WFD(4, 2, 6);
+  else if (len == 256) WFD(4, 1, 6);
+  else if (len == 384) WFD(2, 3, 6);
+  else if (len == 128) WFD(2, 1, 6);
+  else if (len == 192) WFD(2, 3, 5);
+  else if (len == 64) WFD(2, 1, 5);
   else { set_error("pdec_debug_wave_fft: unsupported length %d", len); return PDEC_E_INVALID; }
 #undef WFD
   PDEC_HIP(hipGetLastError());

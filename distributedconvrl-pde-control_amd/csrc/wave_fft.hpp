@@ -1,4 +1,5 @@
 // wave_fft.hpp -- register-resident FFT of one line per WAVE (fp64): N = 64 * E * Q points, element n = lane + 64 j
+// (or per half wave: N = 32 * 2 * Q, see LB below)
 // in register slot j = e + E * qd (e < E: the "exchange digit", 4 or 2; qd < Q: 1, 2 or 3).
 //
 // Decimation in frequency: radix-Q over qd (in-lane), then Q independent FFTs of size 64 E: radix-E over e, and for
@@ -67,10 +68,15 @@ __device__ __forceinline__ void wx_pair(C2<double>& a, C2<double>& b) {
   __builtin_memcpy(&b, q, 16);
 }
 
-template <int E, int Q>
+// LB = 6: one line per wave (64 lanes).  LB = 5 (E = 2 only): one line per HALF wave -- N = 32 * 2 * Q, e.g. 192 for the
+// fluid's 128^2 training grid padded by 3/2 -- two independent lines per wave (lanes 0-31 and 32-63); the exchanges
+// then only use lane bits 4..0, none of which crosses the halves.
+template <int E, int Q, int LB = 6>
 struct WaveFftD {
-  static constexpr int R = E * Q, N = 64 * R, M = 64 * E;
-  static constexpr int NST = E == 4 ? 3 : 6;          // lane-digit stages
+  static_assert(LB == 6 || (LB == 5 && E == 2), "half-wave lines need the 1-bit exchange digit");
+  static constexpr int LANES = 1 << LB, LPW = 64 / LANES;   // lanes per line, lines per wave
+  static constexpr int R = E * Q, N = LANES * R, M = LANES * E;
+  static constexpr int NST = E == 4 ? LB / 2 : LB;    // lane-digit stages
   C2<double> wq[Q > 1 ? (Q - 1) * E : 1];             // radix-Q stage twiddles  tw_N[kq (lane + 64 e)]
   C2<double> we[E - 1];                               // register-digit stage     tw_M[k lane]
   C2<double> wl[NST > 1 ? (NST - 1) * (E - 1) : 1];   // lane-digit stages (the last one has none)
@@ -78,14 +84,14 @@ struct WaveFftD {
 
   // tw: exp(-2 pi i m / N), m < N (global or LDS)
   __device__ __forceinline__ void init(const C2<double>* tw, int lane_) {
-    lane = lane_;
+    lane = lane_ & (LANES - 1);      // position inside the line
 #pragma unroll
     for (int kq = 1; kq < Q; ++kq)
 #pragma unroll
-      for (int e = 0; e < E; ++e) wq[(kq - 1) * E + e] = tw[(kq * (lane + 64 * e)) % N];
+      for (int e = 0; e < E; ++e) wq[(kq - 1) * E + e] = tw[(kq * (lane + LANES * e)) % N];
 #pragma unroll
     for (int k = 1; k < E; ++k) we[k - 1] = tw[(Q * k * lane) % N];
-    int msize = 64;
+    int msize = LANES;
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st) {
       const int msub = msize / E;
@@ -100,8 +106,8 @@ struct WaveFftD {
     const int qd = j / E, e = j - qd * E;
     int perm;
     if (E == 4) perm = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
-    else perm = (int)(__builtin_bitreverse32((unsigned)lane) >> 26);
-    return qd + Q * (perm + 64 * e);
+    else perm = (int)(__builtin_bitreverse32((unsigned)lane) >> (32 - LB));
+    return qd + Q * (perm + LANES * e);
   }
   template <int SGN>
   static __device__ __forceinline__ C2<double> tmul(C2<double> a, C2<double> w) {
@@ -119,7 +125,7 @@ struct WaveFftD {
       wx_pair<LO>(b[0], b[1]);
       wx_pair<LO>(b[2], b[3]);
     } else {
-      wx_pair<5 - ST>(b[0], b[1]);
+      wx_pair<LB - 1 - ST>(b[0], b[1]);
     }
   }
   template <int ST, int SGN>
@@ -164,7 +170,8 @@ struct WaveFftD {
       stage_fwd<0, -1>(b);
       stage_fwd<1, -1>(b);
       stage_fwd<2, -1>(b);
-      if constexpr (NST > 3) { stage_fwd<3, -1>(b); stage_fwd<4, -1>(b); stage_fwd<5, -1>(b); }
+      if constexpr (NST > 3) { stage_fwd<3, -1>(b); stage_fwd<4, -1>(b); }
+      if constexpr (NST > 5) stage_fwd<5, -1>(b);
     }
   }
   // digit-reversed in -> natural order out (unnormalised inverse transform, e^{+2 pi i nk/N})
@@ -172,7 +179,8 @@ struct WaveFftD {
 #pragma unroll
     for (int qd = 0; qd < Q; ++qd) {
       C2<double>* b = &a[qd * E];
-      if constexpr (NST > 3) { stage_inv<5, +1>(b); stage_inv<4, +1>(b); stage_inv<3, +1>(b); }
+      if constexpr (NST > 5) stage_inv<5, +1>(b);
+      if constexpr (NST > 3) { stage_inv<4, +1>(b); stage_inv<3, +1>(b); }
       stage_inv<2, +1>(b);
       stage_inv<1, +1>(b);
       stage_inv<0, +1>(b);

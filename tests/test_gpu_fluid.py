@@ -157,7 +157,7 @@ def test_padded_equals_unpadded_for_band_limited_data(pkg):
     assert np.abs(outs[0] - outs[1]).max() <= 1e-11 * np.abs(outs[0]).max()
 
 
-@pytest.mark.parametrize("n", [128, 256, 384, 512, 768])
+@pytest.mark.parametrize("n", [64, 128, 192, 256, 384, 512, 768])
 def test_wave_fft_engine_matches_numpy(pkg, n):
     """the register-resident one-line-per-wave FFT (csrc/wave_fft.hpp) the fluid kernels are built on: forward and
     unnormalised inverse against numpy.fft (= FFTW's conventions), fp64 <= 1e-13 relative"""
