@@ -60,11 +60,20 @@ class CircularArraySARTTrajectory:
     def _slots(self, start, n, cap):
         return (torch.arange(start, start + n, device=self.device) % cap)
 
+    def _put(self, dst, start, src, cap):
+        """rows start .. start+n-1 (mod cap) of a circular trace; one contiguous copy unless the block wraps"""
+        n = src.shape[0]
+        lo = start % cap
+        if lo + n <= cap:
+            dst[lo:lo + n].copy_(src)
+        else:
+            dst.index_copy_(0, self._slots(start, n, cap), src.to(dst.dtype))
+
     def push_sa(self, s, a):
         n = s.shape[0]
-        idx = self._slots(self.n_sa, n, self.capacity + self.stride)
-        self.state.index_copy_(0, idx, s.to(torch.float32))
-        self.action.index_copy_(0, idx, a.to(torch.float32))
+        cap = self.capacity + self.stride
+        self._put(self.state, self.n_sa, s, cap)
+        self._put(self.action, self.n_sa, a, cap)
         self.n_sa += n
 
     def pop_sa(self, n):
@@ -72,9 +81,8 @@ class CircularArraySARTTrajectory:
 
     def push_rt(self, r, t):
         n = r.shape[0]
-        idx = self._slots(self.n_rt, n, self.capacity)
-        self.reward.index_copy_(0, idx, r.to(torch.float32))
-        self.terminal.index_copy_(0, idx, t.to(torch.float32))
+        self._put(self.reward, self.n_rt, r, self.capacity)
+        self._put(self.terminal, self.n_rt, t, self.capacity)
         self.n_rt += n
 
     def sample_slots(self, rng, batch_size):
@@ -87,6 +95,15 @@ class CircularArraySARTTrajectory:
         lg = base + inds
         return (lg % (self.capacity + self.stride), lg % self.capacity,
                 (lg + self.stride) % (self.capacity + self.stride))
+
+    def sample_slots_many(self, rng, batch_size, loops):
+        """`loops` independent pde_sample draws in one vectorised call -> int array [3, loops, batch_size]
+        (rows: slots of (s, a), of (r, t) and of s')"""
+        hi = len(self) - self.stride
+        inds = rng.integers(0, hi, (loops, batch_size))
+        lg = max(0, self.n_rt - self.capacity) + inds
+        cap1 = self.capacity + self.stride
+        return np.stack([lg % cap1, lg % self.capacity, (lg + self.stride) % cap1])
 
     def sample(self, rng, batch_size):
         """pde_sample / pde_fetch! (src/PDEagent.jl:317-340)"""
@@ -277,9 +294,9 @@ class Agent:
         if p.update_step % p.update_freq != 0:                # :355
             return
         if p.small_update_ok():
-            # all update_loops minibatch updates in ONE launch (pdec_ddpg_update_small); the slots are drawn here, loop
-            # by loop, exactly as the per-loop path draws them
-            slots = np.stack([np.stack(tr.sample_slots(p.rng, p.batch_size)) for _ in range(p.update_loops)], axis=1)
+            # all update_loops minibatch updates in ONE launch (pdec_ddpg_update_small); the slots of every loop are
+            # drawn here (pde_sample, src/PDEagent.jl:317-321) in one vectorised call
+            slots = tr.sample_slots_many(p.rng, p.batch_size, p.update_loops)
             p.update_small(tr, slots)                         # slots: [3, loops, Bu]
             return
         for _ in range(p.update_loops):                       # :357-360
