@@ -330,6 +330,10 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   float* batch = sm;
   float* red0 = batch + (size_t)g.loops * bstride;   // [nw][2 * BUT]
   float* red1 = red0 + nw * 2 * BUT;
+  // five exchanges per update, two buffers: the parity flips from one update to the next, so an exchange never reuses
+  // the buffer of the exchange right before it (a fast wave cannot overwrite partials a slow wave is still summing)
+  float* redb[2] = {red0, red1};
+  int rp = 0;
   for (int idx = tid; idx < g.loops * ns * Bu; idx += nt) {
     const int it = idx / (ns * Bu), rem = idx - it * (ns * Bu), k = rem / Bu, c = rem - k * Bu;
     batch[it * bstride + rem] = g.state[(size_t)g.i_sn[it * Bu + c] * ns + k];
@@ -390,7 +394,8 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
         if (k < ns) z += aw1t[k] * bsn[k * Bu + (c < Bu ? c : 0)];
       v[c] = (isA && c < Bu) ? aw2t * fmaxf(z, 0.f) : 0.f;
     }
-    s2_reduce<2 * BUT>(v, Bu, red0, nw, tid);
+    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    rp ^= 1;
     float an[BUT];
 #pragma unroll
     for (int c = 0; c < BUT; ++c) an[c] = tanhf(v[c] + ab2t);
@@ -404,7 +409,8 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
         else if (k == ns) z += cw1t[k] * an[c];
       v[c] = (isC && c < Bu) ? cw2t * fmaxf(z, 0.f) : 0.f;
     }
-    s2_reduce<2 * BUT>(v, Bu, red1, nw, tid);
+    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    rp ^= 1;
     float qt[BUT];
 #pragma unroll
     for (int c = 0; c < BUT; ++c) qt[c] = v[c] + cb2t;
@@ -420,7 +426,8 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       h[c] = (isC && c < Bu) ? fmaxf(z, 0.f) : 0.f;
       v[c] = cw2 * h[c];
     }
-    s2_reduce<2 * BUT>(v, Bu, red0, nw, tid);
+    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    rp ^= 1;
     float dq[BUT];
     {
       float rbar = 0.f;
@@ -480,7 +487,8 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       ha[c] = (isA && c < Bu) ? fmaxf(z, 0.f) : 0.f;
       v[c] = aw2 * ha[c];
     }
-    s2_reduce<2 * BUT>(v, Bu, red1, nw, tid);
+    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    rp ^= 1;
     float ao[BUT];
 #pragma unroll
     for (int c = 0; c < BUT; ++c) ao[c] = tanhf(v[c] + ab2);
@@ -508,15 +516,16 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
           for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
       if ((tid & 63) == 0)
 #pragma unroll
-        for (int i = 0; i < 2 * BUT; ++i) red0[(tid >> 6) * 2 * BUT + i] = v[i];
+        for (int i = 0; i < 2 * BUT; ++i) redb[rp][(tid >> 6) * 2 * BUT + i] = v[i];
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 2 * BUT; ++i) {
         float acc = 0.f;
         if ((i < BUT ? i : i - BUT) < Bu)
-          for (int w = 0; w < nw; ++w) acc += red0[w * 2 * BUT + i];
+          for (int w = 0; w < nw; ++w) acc += redb[rp][w * 2 * BUT + i];
         v[i] = acc;
       }
+      rp ^= 1;
     }
     {
       float s = 0.f;
