@@ -279,13 +279,27 @@ struct Small2Args {
   int nC, nA;              // hidden widths
 };
 
+// sum over the 64 lanes of a wave, result in every lane: four DPP steps inside each row of 16 lanes, then the four row
+// sums through v_readlane (no LDS crossbar round trips, unlike __shfl_xor = ds_bpermute_b32)
+__device__ __forceinline__ float s2_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane^1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane^2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 template <int N>
 __device__ __forceinline__ void s2_reduce(float (&v)[N], int n, float* buf, int nw, int tid) {
   // sum v[0..n) over the workgroup; result in every thread.  buf: [nw][N] (the caller alternates two buffers)
 #pragma unroll
   for (int i = 0; i < N; ++i)
-    if (i < n)
-      for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    if (i < n) v[i] = s2_wave_sum(v[i]);
   if ((tid & 63) == 0)
 #pragma unroll
     for (int i = 0; i < N; ++i)
@@ -512,8 +526,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       // both halves in one exchange: entries [0, Bu) and [BUT, BUT + Bu)
 #pragma unroll
       for (int i = 0; i < 2 * BUT; ++i)
-        if ((i < BUT ? i : i - BUT) < Bu)
-          for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+        if ((i < BUT ? i : i - BUT) < Bu) v[i] = s2_wave_sum(v[i]);
       if ((tid & 63) == 0)
 #pragma unroll
         for (int i = 0; i < 2 * BUT; ++i) redb[rp][(tid >> 6) * 2 * BUT + i] = v[i];
