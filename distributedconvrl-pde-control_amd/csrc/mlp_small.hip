@@ -270,7 +270,7 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g_in) 
 // 2-layer nets (the reference's `drop_middle_layer = true` shape, src/PDEagent.jl:30-41): one THREAD per hidden unit.
 // A thread keeps its unit's weights (first-layer row, bias, output weight), their ADAM moments and the target copies in
 // REGISTERS for all `loops` updates; forward, backward, ADAM and Polyak of a unit are thread-local, and only the
-// output-layer sums cross threads (DPP/shuffle inside a wave, one LDS exchange + one barrier across waves).  Six barriers
+// output-layer sums cross threads (DPP inside a wave, one LDS exchange + one barrier across waves).  Three barriers
 // per update instead of ~35, no weight traffic at all between the first load and the final write-back.
 #define S2_BU 4            // most minibatch columns the register-resident kernel holds (reference: batch_size = 3)
 
@@ -314,6 +314,26 @@ __device__ __forceinline__ void s2_reduce(float (&v)[N], int n, float* buf, int 
     }
 }
 
+// the same for two groups of n values: entries [0, n) and [H, H + n) of v (H = N / 2), one exchange
+template <int N>
+__device__ __forceinline__ void s2_reduce2(float (&v)[N], int n, float* buf, int nw, int tid) {
+  constexpr int H = N / 2;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if ((i < H ? i : i - H) < n) v[i] = s2_wave_sum(v[i]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < N; ++i) buf[(tid >> 6) * N + i] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float a = 0.f;
+    if ((i < H ? i : i - H) < n)
+      for (int w = 0; w < nw; ++w) a += buf[w * N + i];
+    v[i] = a;
+  }
+}
+
 // Flux ADAM (fp64 arithmetic, no FMA contraction) + Polyak of one parameter held in registers.  The two bias-correction
 // divisors 1 - beta^t are the same for every parameter of an update, so their reciprocals are taken once per update
 // (i1, i2) and multiplied in: m * (1/c) instead of m / c differs from Flux's quotient by at most one fp64 ulp, far below
@@ -344,7 +364,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   float* batch = sm;
   float* red0 = batch + (size_t)g.loops * bstride;   // [nw][2 * BUT]
   float* red1 = red0 + nw * 2 * BUT;
-  // five exchanges per update, two buffers: the parity flips from one update to the next, so an exchange never reuses
+  // three exchanges per update, two buffers: the parity flips from one update to the next, so an exchange never reuses
   // the buffer of the exchange right before it (a fast wave cannot overwrite partials a slow wave is still summing)
   float* redb[2] = {red0, red1};
   int rp = 0;
@@ -399,49 +419,53 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
     const float* bt = br + Bu;
     if (it == 0) __syncthreads();          // the batches are staged
     float v[2 * BUT];
-    // ---- a' = At(s')                                                            :385
+    // Three exchanges per update: {a' = At(s'), A(s)} -> {qt = Ct([s'; a']), q = C([s; a])} -> critic update ->
+    // {q of the updated critic on [s; A(s)], da}.  The behaviour actor's forward does not depend on the critic update, so
+    // it shares the first exchange with the target actor's (src/PDEagent.jl:385 and :403).
+    float ha[BUT];
 #pragma unroll
     for (int c = 0; c < BUT; ++c) {
-      float z = ab1t;
+      float zt = ab1t, z = ab1;
 #pragma unroll
       for (int k = 0; k < KA; ++k)
-        if (k < ns) z += aw1t[k] * bsn[k * Bu + (c < Bu ? c : 0)];
-      v[c] = (isA && c < Bu) ? aw2t * fmaxf(z, 0.f) : 0.f;
+        if (k < ns) {
+          zt += aw1t[k] * bsn[k * Bu + (c < Bu ? c : 0)];
+          z += aw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
+        }
+      const bool on = isA && c < Bu;
+      ha[c] = on ? fmaxf(z, 0.f) : 0.f;
+      v[c] = on ? aw2t * fmaxf(zt, 0.f) : 0.f;
+      v[BUT + c] = aw2 * ha[c];
     }
-    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    s2_reduce2<2 * BUT>(v, Bu, redb[rp], nw, tid);
     rp ^= 1;
-    float an[BUT];
+    float an[BUT], ao[BUT];
 #pragma unroll
-    for (int c = 0; c < BUT; ++c) an[c] = tanhf(v[c] + ab2t);
-    // ---- qt = Ct([s'; a'])                                                      :386
-#pragma unroll
-    for (int c = 0; c < BUT; ++c) {
-      float z = cb1t;
-#pragma unroll
-      for (int k = 0; k < KC; ++k)
-        if (k < ns) z += cw1t[k] * bsn[k * Bu + (c < Bu ? c : 0)];
-        else if (k == ns) z += cw1t[k] * an[c];
-      v[c] = (isC && c < Bu) ? cw2t * fmaxf(z, 0.f) : 0.f;
-    }
-    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
-    rp ^= 1;
-    float qt[BUT];
-#pragma unroll
-    for (int c = 0; c < BUT; ++c) qt[c] = v[c] + cb2t;
-    // ---- q = C([s; a]), critic loss and gradients                              :388-400
+    for (int c = 0; c < BUT; ++c) { an[c] = tanhf(v[c] + ab2t); ao[c] = tanhf(v[BUT + c] + ab2); }
+    // ---- qt = Ct([s'; a'])  :386   and   q = C([s; a])  :392
     float h[BUT];
 #pragma unroll
     for (int c = 0; c < BUT; ++c) {
-      float z = cb1;
+      float zt = cb1t, z = cb1;
 #pragma unroll
       for (int k = 0; k < KC; ++k)
-        if (k < ns) z += cw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
-        else if (k == ns) z += cw1[k] * ba[c < Bu ? c : 0];
-      h[c] = (isC && c < Bu) ? fmaxf(z, 0.f) : 0.f;
-      v[c] = cw2 * h[c];
+        if (k < ns) {
+          zt += cw1t[k] * bsn[k * Bu + (c < Bu ? c : 0)];
+          z += cw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
+        } else if (k == ns) {
+          zt += cw1t[k] * an[c];
+          z += cw1[k] * ba[c < Bu ? c : 0];
+        }
+      const bool on = isC && c < Bu;
+      h[c] = on ? fmaxf(z, 0.f) : 0.f;
+      v[c] = on ? cw2t * fmaxf(zt, 0.f) : 0.f;
+      v[BUT + c] = cw2 * h[c];
     }
-    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    s2_reduce2<2 * BUT>(v, Bu, redb[rp], nw, tid);
     rp ^= 1;
+    float qt[BUT];
+#pragma unroll
+    for (int c = 0; c < BUT; ++c) { qt[c] = v[c] + cb2t; v[c] = v[BUT + c]; }     // v[c] = q partial sum (without b2)
     float dq[BUT];
     {
       float rbar = 0.f;
@@ -491,21 +515,6 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       bpc1 *= g.b2;
     }
     // ---- actor: -mean(C([s; A(s)])) with the updated critic                     :402-412
-    float ha[BUT];
-#pragma unroll
-    for (int c = 0; c < BUT; ++c) {
-      float z = ab1;
-#pragma unroll
-      for (int k = 0; k < KA; ++k)
-        if (k < ns) z += aw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
-      ha[c] = (isA && c < Bu) ? fmaxf(z, 0.f) : 0.f;
-      v[c] = aw2 * ha[c];
-    }
-    s2_reduce<2 * BUT>(v, Bu, redb[rp], nw, tid);
-    rp ^= 1;
-    float ao[BUT];
-#pragma unroll
-    for (int c = 0; c < BUT; ++c) ao[c] = tanhf(v[c] + ab2);
     // critic forward on [s; A(s)]: q for the reported loss and da[c] = sum_f W1c[f][ns] relu'(h) w2 (-1/Bu) in ONE exchange
 #pragma unroll
     for (int c = 0; c < BUT; ++c) {
@@ -522,24 +531,8 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
         if (k == ns) wns = cw1[k];
       v[BUT + c] = (on && z > 0.f) ? wns * cw2 * (-invB) : 0.f;
     }
-    {
-      // both halves in one exchange: entries [0, Bu) and [BUT, BUT + Bu)
-#pragma unroll
-      for (int i = 0; i < 2 * BUT; ++i)
-        if ((i < BUT ? i : i - BUT) < Bu) v[i] = s2_wave_sum(v[i]);
-      if ((tid & 63) == 0)
-#pragma unroll
-        for (int i = 0; i < 2 * BUT; ++i) redb[rp][(tid >> 6) * 2 * BUT + i] = v[i];
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 2 * BUT; ++i) {
-        float acc = 0.f;
-        if ((i < BUT ? i : i - BUT) < Bu)
-          for (int w = 0; w < nw; ++w) acc += redb[rp][w * 2 * BUT + i];
-        v[i] = acc;
-      }
-      rp ^= 1;
-    }
+    s2_reduce2<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    rp ^= 1;
     {
       float s = 0.f;
       for (int c = 0; c < Bu; ++c) s += v[c] + cb2;
