@@ -71,7 +71,7 @@ class PDEenv:
         # rings: the last `history` transitions (s_t, a_t, r_t, done_t, s_{t+1}) stay valid while the NEXT
         # step is in flight, so an update on another stream can read them without a copy
         self.history = max(1, int(history))
-        self._state_ring = [torch.empty(self._sshape, **kw) for _ in range(self.history + 2)]
+        self._state_ring = [torch.empty(self._sshape, **kw) for _ in range(self.history + 3)]
         self._reward_ring = [torch.zeros((self.B, setup.reward_len), **kw) for _ in range(self.history + 1)]
         self._flag_ring = [torch.zeros(self.B, dtype=torch.int32, device=self.device) for _ in range(self.history + 1)]
         self._si = self._ri = 0
@@ -201,6 +201,23 @@ class PDEenv:
         self.p = self.prepare_action(self.action0)
         self.steps, self.time = 0, 0.0
         self.reward.zero_()
+        self._done.zero_()
+        self._done_stale = False
+
+    def reset_episode(self):
+        """reset!(env) for a pipelined caller: like reset(), but the initial state goes into the NEXT slot of the state
+        ring, so the (s, s') tensors of the transitions still in flight (e.g. an update running on another stream) stay
+        intact, and nothing is allocated or synchronised"""
+        self.y.copy_(self.y0)
+        self._si = (self._si + 1) % len(self._state_ring)
+        st = self._state_ring[self._si]
+        _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(self.y), None, _lib.ptr(st)))
+        self.state, self.prev_state = st, None
+        if getattr(self, "_action_reset", None) is None:
+            self._action_reset = self.action0.clone()
+            self._adopted.add(self._action_reset.data_ptr())      # read-only from now on
+        self._action_prev = self.action = self._action_reset
+        self.steps, self.time = 0, 0.0
         self._done.zero_()
         self._done_stale = False
 

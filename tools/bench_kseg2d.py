@@ -84,6 +84,7 @@ def full(args):
     env.set_terminal_out(term)
     off = [0]
     k = [0]
+    EPISODE = 50
 
     def step():
         a = acts[k[0] % 2]
@@ -93,8 +94,13 @@ def full(args):
         off[0] += (cols + 3) // 4
         s_t = env.state
         env(a.view(env._ashape), adopt=True)
+        end = k[0] % EPISODE == 0
+        if end:
+            term.fill_(1.0)             # time-out terminal (done = time >= te, src/PDEenv.jl:227)
         policy.update(dict(state=s_t.view(cols, ns), action=env.action.view(cols, 1), reward=env.reward.view(cols),
                            terminal=term, next_state=env.state.view(cols, ns)))
+        if end:
+            env.reset_episode()         # lock-stepped episodes: the chemotaxis model blows up in finite time under random forcing
 
     for _ in range(3):
         step()
