@@ -20,7 +20,10 @@
 
 namespace pdec {
 
-constexpr int K2_TX = 64, K2_TY = 64, K2_NT = 512;
+constexpr int K2_TX = 64;
+// tile height / workgroup size per dtype: fp32 64 rows x 512 threads (128 VGPRs -> two workgroups per CU); fp64 needs
+// ~250 VGPRs per thread, so 32 rows x 256 threads give two independent workgroups per CU instead of one big one
+template <class T> struct K2Tile { static constexpr int TY = sizeof(T) == 4 ? 64 : 32, NT = sizeof(T) == 4 ? 512 : 256; };
 
 template <class T>
 struct K2Dev {
@@ -84,9 +87,10 @@ struct alignas(16) QuadT {  // four consecutive scalars of one plane = two cell 
 // action table (p_in = action [B][A]; p = agent_power * action[cell_act]: the [ny][nx] int table is shared by all
 // trajectories and stays in L2, so the per-sub-step HBM reads drop from 3 to 2 scalars per cell)
 template <class T, int NSUB, int MODE>
-__global__ __launch_bounds__(K2_NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<T>* __restrict__ y_in,
+__global__ __launch_bounds__(K2Tile<T>::NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<T>* __restrict__ y_in,
                                                            const T* __restrict__ p_in, C2<T>* __restrict__ y_out,
                                                            int32_t* __restrict__ done, int last) {
+  constexpr int K2_TY = K2Tile<T>::TY, K2_NT = K2Tile<T>::NT;
   constexpr int H = 4 * NSUB, RX = K2_TX + 2 * H, RY = K2_TY + 2 * H, SW = RX / 4, NSTRIP = SW * RY;
   constexpr int NS = (NSTRIP + K2_NT - 1) / K2_NT, RXP = RX + 4;
   extern __shared__ __align__(16) unsigned char k2_smem[];
@@ -323,11 +327,12 @@ static K2Dev<T> k2_dev(const Kseg2dEnv& E) {
 
 template <int NSUB>
 static constexpr size_t k2_lds(size_t pair_bytes) {   // two planes [RY][RX + 4] of T
-  return (size_t)(K2_TY + 8 * NSUB) * (K2_TX + 8 * NSUB + 4) * pair_bytes;
+  return (size_t)((pair_bytes == 8 ? 64 : 32) + 8 * NSUB) * (K2_TX + 8 * NSUB + 4) * pair_bytes;
 }
 
 template <class T, int NSUB, int MODE>
 static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_out, int32_t* done, int last) {
+  constexpr int K2_TY = K2Tile<T>::TY, K2_NT = K2Tile<T>::NT;
   const dim3 grid(((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2_TY - 1) / K2_TY) * E.cfg.B);
   hipLaunchKernelGGL((kseg2d_rk4_kernel<T, NSUB, MODE>), grid, dim3(K2_NT), k2_lds<NSUB>(2 * sizeof(T)), E.stream, k2_dev<T>(E),
                      (const C2<T>*)y_in, (const T*)p, (C2<T>*)y_out, done, last);
