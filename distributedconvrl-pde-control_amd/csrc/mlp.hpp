@@ -68,6 +68,8 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
                      uint64_t seed, uint64_t offset, void* actions_out);
 
 // mlp_mfma2.hip: the same passes for the reference-shaped 2-layer nets [ns, h, 1] / [ns+1, H, 1] (flat parameters, no image)
+// mean of r[0..n) in a fixed order, one block; *out = device scalar owned by C (mlp_mfma2.hip)
+int launch_rmean(Mlp* C, const float* r, int n, float** out);
 bool fused2_supported(const Mlp* A, const Mlp* C);
 bool fused2_net_supported(const Mlp* M);
 bool fused2_act_supported(const Mlp* A, int cols);

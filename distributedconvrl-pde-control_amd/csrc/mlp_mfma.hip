@@ -202,6 +202,7 @@ struct FusedArgs {
   float gamma;
   int quirk;
   float* slab;                // chunk-major partial gradients, see store_pass
+  const float* rbar_dev;      // != null: batch-mean reward already reduced by launch_rmean (batches beyond 32768 columns)
   unsigned long long* stamps; // diagnostic only (PDEC_STAMPS=1): [gridDim.x][16] s_memtime at phase boundaries
 };
 
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   // mean reward for the reference's (1xBu).+(Bu) broadcast: every workgroup reduces all of r in the
   // same fixed order, so the value is identical everywhere
   float rsum = 0.f;
-  if (g.quirk) {   // 16-B loads, 8 in flight per lane: the L2 latency is paid per batch, not per element
+  if (g.quirk && !g.rbar_dev) {   // 16-B loads, 8 in flight per lane: the L2 latency is paid per batch, not per element
     const int n4 = ((reinterpret_cast<uintptr_t>(g.r) & 15) == 0) ? g.Bu / 4 : 0;
     const f32x4* r4 = reinterpret_cast<const f32x4*>(g.r);
     int i = tid;
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   }
   // the target critic's weight image lands in LDS while the target actor and the first critic layer run
   dma_copy(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
-  const float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads (small images visible)
+  float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads (small images visible)
+  if (g.rbar_dev) rbar = g.rbar_dev[0];
   STAMP(1);
 
   float x[4];
@@ -945,6 +947,11 @@ int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const vo
   g.s = (const float*)s; g.a = (const float*)a; g.r = (const float*)r; g.t = (const float*)t; g.sn = (const float*)sn;
   g.Bu = Bu; g.ns = A->dims[0]; g.na = 1; g.gamma = (float)gamma; g.quirk = quirk;
   g.slab = C->fslab.as<float>();
+  if (quirk && Bu > 256 * FCOLS) {     // every workgroup summing all of r itself does not scale (C3: 131072 rewards): reduce once
+    float* rb = nullptr;
+    if ((rc = launch_rmean(C, (const float*)r, Bu, &rb))) return rc;
+    g.rbar_dev = rb;
+  }
   if (mt == 9 && mta == 2) rc = launch_critic<9, 2>(C, g, grid);
   else if (mt == 9 && mta == 1) rc = launch_critic<9, 1>(C, g, grid);
   else if (mt == 2 && mta == 2) rc = launch_critic<2, 2>(C, g, grid);

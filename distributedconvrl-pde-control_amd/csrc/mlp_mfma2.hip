@@ -861,6 +861,15 @@ int fused2_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap) {
   return PDEC_OK;
 }
 
+int launch_rmean(Mlp* C, const float* r, int n, float** out) {
+  float* rb = C->scratch.as<float>() + 40;      // device scalar behind the generic path's statistics and losses
+  ProfScope ps(C, "ddpg_rmean");
+  hipLaunchKernelGGL(rmean_kernel, dim3(1), dim3(1024), 0, C->stream, r, n, rb);
+  PDEC_HIP(hipGetLastError());
+  *out = rb;
+  return PDEC_OK;
+}
+
 int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
                         const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,
                         const AdamPolyak* apply) {
@@ -874,9 +883,9 @@ int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const v
   g.Bu = Bu; g.ns = A->dims[0]; g.gamma = (float)gamma; g.quirk = quirk;
   g.slab = C->fslab.as<float>();
   if (quirk) {
-    float* rb = C->scratch.as<float>() + 40;      // device scalar behind the generic path's statistics and losses
-    ProfScope ps(C, "ddpg2_rmean");
-    hipLaunchKernelGGL(rmean_kernel, dim3(1), dim3(1024), 0, C->stream, (const float*)r, Bu, rb);
+    float* rb = nullptr;
+    int rcm = launch_rmean(C, (const float*)r, Bu, &rb);
+    if (rcm) return rcm;
     g.rbar = rb;
   }
   int rc = dispatch2(C, g, grid, false, mt, mta);

@@ -87,7 +87,7 @@ def test_adam_polyak_match_flux_semantics(pkg):
 
 
 @pytest.mark.parametrize("quirk", [1, 0])
-@pytest.mark.parametrize("prec,Bu", [("f64", 300), ("f32", 4096), ("f32", 1000), ("f32", 77)])
+@pytest.mark.parametrize("prec,Bu", [("f64", 300), ("f32", 4096), ("f32", 1000), ("f32", 77), ("f32", 40000)])
 def test_ddpg_update_matches_oracle(pkg, quirk, prec, Bu):
     """Whole update (src/PDEagent.jl:363-418): losses, all four networks after one and two
     updates.  quirk=1 is the reference's (1xBu).+(Bu) reward broadcast."""
