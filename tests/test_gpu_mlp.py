@@ -243,9 +243,11 @@ def test_update_async_and_split_sequence_agree(pkg, quirk, ns, sa, sc, drop, Bu)
 
 
 @pytest.mark.parametrize("quirk", [1, 0])
-@pytest.mark.parametrize("ns,na,sa,sc,drop", [(1, 1, 0.6, 7.0, True), (12, 1, 2.0, 17.0, True), (9, 1, 1.8, 17.0, True),
-                                             (15, 1, 1.0, 25.0, True), (3, 1, 1.6, 7.0, False), (8, 8, 4.8, 56.0, True)])
-def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop):
+@pytest.mark.parametrize("ns,na,sa,sc,drop,Bu", [(1, 1, 0.6, 7.0, True, 3), (12, 1, 2.0, 17.0, True, 3), (9, 1, 1.8, 17.0, True, 3),
+                                                (15, 1, 1.0, 25.0, True, 3), (3, 1, 1.6, 7.0, False, 3), (8, 8, 4.8, 56.0, True, 3),
+                                                (1, 1, 0.6, 7.0, True, 4), (12, 1, 2.0, 17.0, True, 1), (5, 1, 1.0, 10.0, True, 2),
+                                                (9, 1, 1.8, 17.0, True, 7)])
+def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop, Bu):
     """pdec_ddpg_update_small: the reference's update shape (update_loops x minibatch of batch_size = 3 drawn from the
     replay traces, src/PDEagent.jl:317-418) in one launch == the oracle's update applied loop by loop on the same slots"""
     from oracle import nn
@@ -258,7 +260,7 @@ def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop):
     At, PAt = make_net(pkg, rng, da, aa, dtype, 16)
     Ct, PCt = make_net(pkg, rng, dc, ac, dtype, 16)
     optA, optC = nn.Adam(PA, 5e-4), nn.Adam(PC, 1e-3)
-    slots_n, loops, Bu = 500, 4, 3
+    slots_n, loops = 500, 4
     S = rng.standard_normal((slots_n, ns)).astype(npdt)
     Aa = rng.uniform(-1, 1, (slots_n, na)).astype(npdt)
     R = -rng.uniform(0, 1, slots_n).astype(npdt)
