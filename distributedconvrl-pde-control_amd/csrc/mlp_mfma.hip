@@ -146,10 +146,18 @@ __device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MT
     }
     const float* wrow0 = W + (16 * mo + lr) * ldw + 4 * q;
     const float* wrow1 = wrow0 + 16 * ldw;
+    // operand reads run ONE block ahead of the MFMAs that consume them (explicit double buffer): left to itself the
+    // scheduler issues each pair of ds_read_b128 right before its 8 MFMAs and the wave eats the LDS latency every time
+    f32x4 wa = *reinterpret_cast<const f32x4*>(wrow0);
+    f32x4 wb = *reinterpret_cast<const f32x4*>(wrow1);
 #pragma unroll
     for (int m = 0; m < MTI; ++m) {
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(wrow0 + 16 * m);
-      const f32x4 wb = *reinterpret_cast<const f32x4*>(wrow1 + 16 * m);
+      f32x4 wan = wa, wbn = wb;
+      if (m + 1 < MTI) {
+        wan = *reinterpret_cast<const f32x4*>(wrow0 + 16 * (m + 1));
+        wbn = *reinterpret_cast<const f32x4*>(wrow1 + 16 * (m + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
       acc0 = mfma4(wa[0], in[m][0], acc0);
       acc1 = mfma4(wb[0], in[m][0], acc1);
       acc0 = mfma4(wa[1], in[m][1], acc0);
@@ -158,6 +166,9 @@ __device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MT
       acc1 = mfma4(wb[2], in[m][2], acc1);
       acc0 = mfma4(wa[3], in[m][3], acc0);
       acc1 = mfma4(wb[3], in[m][3], acc1);
+      __builtin_amdgcn_sched_barrier(0);
+      wa = wan;
+      wb = wbn;
     }
     out[mo] = acc0;
     out[mo + 1] = acc1;
