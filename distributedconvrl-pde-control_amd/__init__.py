@@ -13,5 +13,5 @@ from .agent import (Agent, CustomDDPGPolicy, CircularArraySARTTrajectory, ZeroPo
                     create_agent, PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE,
                     POST_EPISODE_STAGE, POST_EXPERIMENT_STAGE)
 from .hook import PDEhook  # noqa: F401
-from .run import run, StopAfterEpisode, StopAfterEpisodeWithMinSteps  # noqa: F401
+from .run import run, testrun, StopAfterEpisode, StopAfterEpisodeWithMinSteps  # noqa: F401
 from . import julia_compat, distributed, checkpoint  # noqa: F401

@@ -201,3 +201,21 @@ def test_rollout_equals_step_by_step_loop(pkg, case):
     envs[1].y[B - 1].fill_(1e3)
     out2 = envs[1].rollout(actor, 2, learning=False)
     assert out2["done_step"].tolist()[B - 1] == 0 and bool(envs[1].done[B - 1])
+
+
+def test_testrun_helper_equals_policy_rollout(pkg):
+    """pkg.testrun (evaluation episode as one device-side rollout) == stepping the noise-free policy by hand"""
+    setup = pkg.KSSetup.KS22()
+    env = pkg.PDEenv(setup, B=2, dtype=torch.float64)
+    agent = pkg.create_agent(setup=setup, B=2, rng=np.random.default_rng(4), start_steps=-1)   # no warm-up policy
+    out = pkg.testrun(agent, env, steps=10)
+    ref = pkg.PDEenv(setup, B=2, dtype=torch.float64)
+    ref.reset()
+    total = torch.zeros_like(ref.reward)
+    for _ in range(10):
+        a = agent.policy(ref, learning=False)
+        ref(a)
+        total += ref.reward
+    assert torch.allclose(out["reward_sum"], total, rtol=0, atol=1e-12)
+    assert torch.allclose(env.y, ref.y, rtol=0, atol=1e-12)
+    assert out["episode_reward"].shape == (2,) and out["y"].shape[0] == 10
