@@ -1,0 +1,245 @@
+# PDEenvHIP.jl -- Julia binding of libpdeconv.so (include/pdeconv.h), the file a maintainer of
+# janstenner/DistributedConvRL-PDE-Control drops into `src/` (see INTEGRATION.md).
+#
+# The reference has no FFI; its seam is the set of closures `PDEenv` calls (`do_step`, `featurize`,
+# `prepare_action`, `reward_function`: src/PDEenv.jl:195-241) and the NN wrapper (src/custom_nna.jl:7-27,
+# `RLBase.update!(policy, batch)` at src/PDEagent.jl:363).  Every function below is a thin `ccall`; nothing is
+# computed in Julia.  Julia is not installed in the build image, so this file is NOT executed there: its struct
+# mirror, the symbol names and the argument counts of every `ccall` are checked against include/pdeconv.h by
+# tests/test_host_logic.py::test_julia_glue_matches_the_c_abi, and the identical C ABI is exercised by the Python
+# ctypes host and the GPU tests.
+module PDEenvHIP
+
+using Flux
+import ReinforcementLearning: RLBase
+
+const LIB = get(ENV, "PDECONV_LIB", joinpath(@__DIR__, "..", "libpdeconv.so"))
+
+const F32, F64 = Cint(0), Cint(1)
+const KS_CNAB2, KSEG_RK4, KS_RK4_FD, FLUID_RK4, KSEG2D_RK4 = Cint(0), Cint(1), Cint(2), Cint(3), Cint(4)
+
+# mirror of `struct pdec_env_cfg` (include/pdeconv.h): same fields, same order, same C types
+struct EnvCfg
+    pde_kind::Cint
+    dtype::Cint
+    B::Cint
+    N::Cint
+    n_species::Cint
+    S::Cint
+    A::Cint
+    window::Cint
+    temporal_steps::Cint
+    mono::Cint
+    K::Cint
+    check_max_value::Cint
+    Lx::Cdouble
+    dt::Cdouble
+    mu::Cdouble
+    max_value::Cdouble
+    sensor_scale::Cdouble
+    agent_power::Cdouble
+    reward_in_scale::Cdouble
+    reward_offset::Cdouble
+    reward_power::Cdouble
+    reward_denom::Cdouble
+    action_punish::Cdouble
+    delta_action_punish::Cdouble
+    ifpad::Cint
+    sensors_per_axis::Cint
+    nu::Cdouble
+    Ny::Cint
+    integrator::Cint
+end
+
+# keyword constructor: every field by name, so that a field added to the C struct cannot silently shift the rest
+function EnvCfg(; pde_kind = KS_CNAB2, dtype = F64, B = 1, N, n_species = 1, S, A, window = 1, temporal_steps = 1,
+                mono = 0, K, check_max_value = 1, Lx, dt, mu = 0.0, max_value, sensor_scale, agent_power,
+                reward_in_scale, reward_offset = 0.0, reward_power, reward_denom, action_punish, delta_action_punish,
+                ifpad = 0, sensors_per_axis = 0, nu = 0.0, Ny = 0, integrator = 0)
+    EnvCfg(pde_kind, dtype, B, N, n_species, S, A, window, temporal_steps, mono, K, check_max_value, Lx, dt, mu,
+           max_value, sensor_scale, agent_power, reward_in_scale, reward_offset, reward_power, reward_denom,
+           action_punish, delta_action_punish, ifpad, sensors_per_axis, nu, Ny, integrator)
+end
+
+check(rc) = rc == 0 || error(unsafe_string(ccall((:pdec_last_error, LIB), Cstring, ())))
+init(dev = 0) = check(ccall((:pdec_init, LIB), Cint, (Cint,), dev))
+shutdown() = check(ccall((:pdec_shutdown, LIB), Cint, ()))
+destroy(h::UInt64) = check(ccall((:pdec_destroy, LIB), Cint, (UInt64,), h))
+
+# ---- device memory helpers (pdec_malloc / pdec_memcpy_*)
+function device_alloc(bytes::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pdec_malloc, LIB), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, bytes))
+    p[]
+end
+device_free(p::Ptr{Cvoid}) = check(ccall((:pdec_free, LIB), Cint, (Ptr{Cvoid},), p))
+function device_upload(a::Array)
+    p = device_alloc(sizeof(a))
+    check(ccall((:pdec_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), p, a, sizeof(a)))
+    p
+end
+device_download!(a::Array, p::Ptr{Cvoid}) =
+    (check(ccall((:pdec_memcpy_d2h, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), a, p, sizeof(a))); a)
+
+# ---- environment ------------------------------------------------------------------------------------------------
+# gaussians :: Vector{Vector{Float64}} as built by prepare_gaussians (scripts/KS/setup/KSSetup.jl:111-113)
+function env_create(cfg::EnvCfg, gaussians, gaussians_actuators, actuators_to_sensors)
+    h = Ref{UInt64}(0)
+    G = collect(reduce(hcat, gaussians))                 # column-major [N, S] == row-major [S][N]
+    Ga = collect(reduce(hcat, gaussians_actuators))
+    a2s = Int32.(actuators_to_sensors .- 1)
+    check(ccall((:pdec_env_create, LIB), Cint,
+                (Ref{UInt64}, Ref{EnvCfg}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}), h, cfg, G, Ga, a2s))
+    h[]
+end
+
+# the configuration of scripts/KS/setup/KSSetup.jl from its globals
+ks_cfg(; nx, Lx, dt, oversampling, mu, max_value, agent_power, action_punish, delta_action_punish, n_sensors,
+       n_actuators, window_size = 1, temporal_steps = 1, B = 1, dtype = F64) =
+    EnvCfg(pde_kind = KS_CNAB2, dtype = dtype, B = B, N = nx, S = n_sensors, A = n_actuators, window = window_size,
+           temporal_steps = temporal_steps, K = oversampling, Lx = Lx, dt = dt, mu = mu, max_value = max_value,
+           sensor_scale = 1 / max_value, agent_power = agent_power, reward_in_scale = 6.0, reward_power = 1.3,
+           reward_denom = 3 * max_value, action_punish = action_punish, delta_action_punish = delta_action_punish)
+
+# do_step(env) -> y_new                               replaces scripts/KS/setup/KSSetup.jl:130-160
+function do_step(h::UInt64, y::Array{Float64}, p::Array{Float64})
+    ynew = similar(y)
+    done = Ref{Int32}(0)
+    check(ccall((:pdec_pde_step_host, LIB), Cint,
+                (UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}), h, y, p, ynew, done))
+    ynew
+end
+
+# the whole (env::PDEenv)(action) body in one launch    replaces src/PDEenv.jl:196-222
+function env_step!(h::UInt64, env, action)
+    ynew = similar(env.y)
+    p = zeros(size(env.y)[end])
+    state = similar(env.state)
+    reward = zeros(size(env.state, 2))
+    done = Ref{Int32}(0)
+    check(ccall((:pdec_env_step_host, LIB), Cint,
+                (UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Ref{Int32}),
+                h, env.y, action, env.action, env.state, ynew, p, state, reward, done))
+    ynew, p, state, reward, done[] != 0
+end
+
+# 2-D fluid: gaussians[i] are the `sparse` thresholded bumps of scripts/Fluid/setup/FluidSetup.jl:139-161, passed as
+# the dense BW x BH box around the periodic support of each (boxes [S][BW][BH], origin (j0, i0), 0-based)
+function fluid_env_create(cfg::EnvCfg, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s)
+    h = Ref{UInt64}(0)
+    check(ccall((:pdec_fluid_env_create, LIB), Cint,
+                (Ref{UInt64}, Ref{EnvCfg}, Cint, Cint, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}),
+                h, cfg, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s))
+    h[]
+end
+# do_step(env) (FluidSetup.jl:163-172): env.y, env.p are ComplexF64[ny, nx], passed as they lie (re, im interleaved)
+function fluid_do_step(h::UInt64, y::Matrix{ComplexF64}, p::Matrix{ComplexF64})
+    ynew = similar(y)
+    check(ccall((:pdec_pde_step_host, LIB), Cint, (UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}),
+                h, y, p, ynew, C_NULL))
+    ynew
+end
+# generate_random_init() (FluidSetup.jl:386-394 -> ic(3)/ic(4), src/fluid_rk4.jl:72-120): the random draws stay in
+# Julia, the 9-image Taylor-vortex sums and the fft2 run on the GPU.  vort: 4 x nv (x0, y0, a0, U_max), y0_dev: device
+fluid_ic!(h::UInt64, vort::Matrix{Float64}, y0_dev::Ptr{Cvoid}) =
+    check(ccall((:pdec_fluid_ic, LIB), Cint, (UInt64, Ptr{Cdouble}, Cint, Ptr{Cvoid}), h, vort, size(vort, 2), y0_dev))
+
+# Keller-Segel on a 2-D grid (BASELINE.json configs[3]; the reference script is 1-D): sensor centres on a tensor grid
+# (0-based cells), (2 half_window + 1)^2 boxes of ones as in prepare_rectangles (KellerSegelSetup.jl:112-126)
+function kseg2d_env_create(cfg::EnvCfg, ny, sensor_x::Vector{Int32}, sensor_y::Vector{Int32}, half_window, a2s::Vector{Int32})
+    h = Ref{UInt64}(0)
+    check(ccall((:pdec_kseg2d_env_create, LIB), Cint,
+                (Ref{UInt64}, Ref{EnvCfg}, Cint, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Int32}),
+                h, cfg, ny, length(sensor_x), length(sensor_y), sensor_x, sensor_y, half_window, a2s))
+    h[]
+end
+
+# ---- the NN seam: a model type usable inside CustomNeuralNetworkApproximator ---------------------------------------
+mutable struct HipMLP
+    h::UInt64
+    dims::Vector{Int32}
+    acts::Vector{Int32}
+end
+nparams(m::HipMLP) = sum(m.dims[i] * m.dims[i + 1] + m.dims[i + 1] for i in 1:length(m.acts))
+function HipMLP(chain::Flux.Chain; max_cols = 1)        # upload an existing Flux Chain(Dense...)
+    dims = Int32[size(chain[1].weight, 2); [size(l.weight, 1) for l in chain]...]
+    acts = Int32[l.σ === relu ? 1 : l.σ === tanh ? 2 : 0 for l in chain]
+    flat = reduce(vcat, [vcat(vec(l.weight), l.bias) for l in chain])      # Flux.params order, W column-major
+    h = Ref{UInt64}(0)
+    check(ccall((:pdec_mlp_create, LIB), Cint, (Ref{UInt64}, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Cvoid}, Cint),
+                h, F32, length(acts), dims, acts, Float32.(flat), max_cols))
+    HipMLP(h[], dims, acts)
+end
+function unflatten(m::HipMLP, flat::Vector{Float32})
+    out, o = Any[], 0
+    for i in 1:length(m.acts)
+        nin, nout = m.dims[i], m.dims[i + 1]
+        push!(out, reshape(flat[o+1:o+nin*nout], Int(nout), Int(nin))); o += nin * nout
+        push!(out, flat[o+1:o+nout]); o += nout
+    end
+    out
+end
+function (m::HipMLP)(x::AbstractMatrix)                 # app(x), src/custom_nna.jl:13; x is [in, cols]
+    xs = Float32.(x)
+    cols = size(xs, 2)
+    y = Matrix{Float32}(undef, m.dims[end], cols)
+    dx = device_upload(xs)
+    dy = device_alloc(sizeof(y))
+    check(ccall((:pdec_mlp_forward, LIB), Cint, (UInt64, Ptr{Cvoid}, Cint, Ptr{Cvoid}), m.h, dx, cols, dy))
+    device_download!(y, dy)
+    device_free(dx); device_free(dy)
+    y
+end
+function Flux.params(m::HipMLP)
+    flat = Vector{Float32}(undef, nparams(m))
+    check(ccall((:pdec_mlp_get_params, LIB), Cint, (UInt64, Ptr{Cvoid}), m.h, flat))
+    unflatten(m, flat)
+end
+Base.copyto!(dst::HipMLP, src::HipMLP) = check(ccall((:pdec_mlp_copy, LIB), Cint, (UInt64, UInt64), dst.h, src.h))
+function Base.deepcopy(m::HipMLP)                       # PDEhook snapshots the actor (src/PDEhook.jl:37-38)
+    h = Ref{UInt64}(0)
+    check(ccall((:pdec_mlp_create, LIB), Cint, (Ref{UInt64}, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Cvoid}, Cint),
+                h, F32, length(m.acts), m.dims, m.acts, C_NULL, 1))
+    c = HipMLP(h[], copy(m.dims), copy(m.acts))
+    copyto!(c, m)
+    c
+end
+
+# RLBase.update!(policy, batch) -- Zygote cannot differentiate through ccall, so the method at src/PDEagent.jl:363 is
+# overridden with the fused call (same losses, ADAM, Polyak).  `CustomDDPGPolicy` / `CustomNeuralNetworkApproximator`
+# are the reference's own types (src/PDEagent.jl:121, src/custom_nna.jl:7), defined in Main before this file is included.
+function ddpg_update!(policy, batch)
+    s, a, r, t, snext = batch                            # Float32; s [ns,Bu], a [na,Bu], r [1,Bu], t [Bu]
+    al = Ref{Cdouble}(0)
+    cl = Ref{Cdouble}(0)
+    Bu = size(s, 2)
+    ds, da, dr, dt, dsn = device_upload.((Array(s), Array(a), vec(Array(r)), Float32.(t), Array(snext)))
+    check(ccall((:pdec_ddpg_update, LIB), Cint,
+                (UInt64, UInt64, UInt64, UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint,
+                 Cdouble, Cdouble, Cint, Cdouble, Cdouble, Ref{Cdouble}, Ref{Cdouble}),
+                policy.behavior_actor.model.h, policy.behavior_critic.model.h, policy.target_actor.model.h,
+                policy.target_critic.model.h, ds, da, dr, dt, dsn, Bu, policy.y, policy.p, 1,
+                policy.behavior_actor.optimizer.eta, policy.behavior_critic.optimizer.eta, al, cl))
+    foreach(device_free, (ds, da, dr, dt, dsn))
+    policy.actor_loss = al[]
+    policy.critic_loss = cl[]
+end
+# in Main, after including src/PDEagent.jl:
+#   RLBase.update!(p::CustomDDPGPolicy{<:CustomNeuralNetworkApproximator{PDEenvHIP.HipMLP}}, batch::NamedTuple{SARTS}) =
+#       PDEenvHIP.ddpg_update!(p, batch)
+
+# ---- multi-GPU (one Julia process per GPU; the reference itself is single-process) -----------------------------------
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:pdec_comm_unique_id, LIB), Cint, (Ptr{Cvoid},), id))
+    id
+end
+function comm_create(nranks, rank, id::Vector{UInt8})
+    c = Ref{UInt64}(0)
+    check(ccall((:pdec_comm_create, LIB), Cint, (Ref{UInt64}, Cint, Cint, Ptr{Cvoid}), c, nranks, rank, id))
+    c[]
+end
+allreduce_grads(comm::UInt64, m::HipMLP) = check(ccall((:pdec_allreduce_grads, LIB), Cint, (UInt64, UInt64), comm, m.h))
+
+end # module

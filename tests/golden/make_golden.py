@@ -104,10 +104,12 @@ def main():
         a2 = a.reshape(a.shape[0], -1) if a.ndim == 2 else a.reshape(1, -1)
         kw[f"buf_{i}_shape"] = np.array(a.shape)
         kw[f"buf_{i}_head"] = np.ascontiguousarray(a2[:, :4096])
-    bools = [fa.array(o) for o in fa.objs.values() if o.cls == 0 and o.size == 1 and o.dims and o.data_off]
-    for i, b in enumerate(bools):
-        kw[f"terminal_{i}_shape"] = np.array(b.shape)
-        kw[f"terminal_{i}_head"] = np.ascontiguousarray(b.reshape(-1)[:4096])
+    # the Bool terminal trace is stored as a 1-byte bitfield (datatype class 4)
+    bools = [o for o in fa.objs.values() if o.cls == 4 and o.size == 1 and o.dims and o.data_off]
+    for i, o in enumerate(bools):
+        b = np.frombuffer(fa.buf[o.data_off:o.data_off + o.data_size], dtype=np.uint8)
+        kw[f"terminal_{i}_shape"] = np.array(o.dims)
+        kw[f"terminal_{i}_head"] = np.ascontiguousarray(b[:4096])
     # ADAM hyper-parameters: byte search for [eta, 0.9, 0.999, 1e-8] Float64 quadruples
     pat = np.array([0.9, 0.999, 1e-8]).tobytes()
     etas, pos = [], 0

@@ -27,6 +27,62 @@ def test_c_abi_exports_every_declared_symbol(pkg):
     assert declared == bound, declared ^ bound
 
 
+def _c_decls():
+    hdr = open(os.path.join(ROOT, "include", "pdeconv.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(pdec_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return hdr, decls
+
+
+def test_julia_glue_matches_the_c_abi(pkg):
+    """julia/PDEenvHIP.jl cannot be executed here (no Julia in the image), so its contract with include/pdeconv.h is
+    checked textually: the EnvCfg struct mirror has the C struct's fields in order and type (and so has the ctypes
+    mirror), the keyword constructor passes exactly those fields in that order, every `ccall` names a declared
+    symbol and passes as many arguments as the C prototype has parameters."""
+    hdr, decls = _c_decls()
+    body = re.search(r"typedef struct pdec_env_cfg \{(.*?)\} pdec_env_cfg;", hdr, flags=re.S).group(1)
+    c_fields = re.findall(r"\b(int|double)\s+([A-Za-z_0-9]+)\s*;", body)
+    assert len(c_fields) == 29
+    jl = open(os.path.join(ROOT, "julia", "PDEenvHIP.jl")).read()
+    jbody = re.search(r"^struct EnvCfg\n(.*?)^end", jl, flags=re.S | re.M).group(1)
+    j_fields = re.findall(r"^\s*([A-Za-z_0-9]+)::(Cint|Cdouble)\s*$", jbody, flags=re.M)
+    assert [(n, {"Cint": "int", "Cdouble": "double"}[t]) for n, t in j_fields] == [(n, t) for t, n in c_fields]
+    py_fields = [(n, "int" if t is ctypes.c_int else "double") for n, t in pkg._lib.EnvCfg._fields_]
+    assert py_fields == [(n, t) for t, n in c_fields]
+    assert ctypes.sizeof(pkg._lib.EnvCfg) == 12 * 4 + 12 * 8 + 2 * 4 + 8 + 2 * 4
+    # the keyword constructor forwards every field positionally in the struct's order
+    ctor = re.search(r"function EnvCfg\(;.*?\n    EnvCfg\((.*?)\)\nend", jl, flags=re.S).group(1)
+    assert [a.strip() for a in ctor.replace("\n", " ").split(",")] == [n for _, n in c_fields]
+    # every ccall: declared symbol, matching arity (argument-type tuple and actual arguments)
+    calls = re.findall(r"ccall\(\(:(pdec_[a-z0-9_]+), LIB\),\s*(\w+),\s*\((.*?)\)\s*(?:,|\))", jl, flags=re.S)
+    assert len(calls) >= 20
+    for name, ret, tup in calls:
+        assert name in decls, name
+        n = len([a for a in tup.replace("\n", " ").split(",") if a.strip()])
+        assert n == decls[name], (name, n, decls[name])
+        assert ret == ("Cstring" if name == "pdec_last_error" else "Cint"), name
+    for extra in ("KSSetupHIP.jl",):
+        for name in re.findall(r":(pdec_[a-z0-9_]+)", open(os.path.join(ROOT, "julia", extra)).read()):
+            assert name in decls
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two fresh rank processes and prints ONE line with
+    the rank count it observed (--launch-check: rendezvous only, so it runs without a GPU)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    import json
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_observed"] == 2 and d["self_launched"] is True
+
+
 def test_product_does_not_import_oracle():
     """the product path must not route through the oracle or any CPU fallback"""
     pdir = os.path.join(ROOT, "distributedconvrl-pde-control_amd")

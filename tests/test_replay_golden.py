@@ -1,0 +1,136 @@
+"""The reference's own replay buffer (scripts/KS/KS22/saves/agent.jld2, first 4096 rows of the four traces of its
+CircularArraySARTTrajectory, tests/golden/ks22_agent.npz) as a pin for
+  * reward_function (scripts/KS/setup/KSSetup.jl:162-178): r[i] is a function of the NEXT state's sensor value, of
+    a[i] and of a[i] - a[i - A],
+  * the trajectory glue (src/PDEagent.jl:237-340): next state at +A, one row per actuator, the dummy row of an episode
+    end popped at the next PRE_EPISODE, the terminal flag on the last step of every 51-step episode.
+CPU tests: the oracle and the product's host glue.  The GPU half (pdec_reward / pdec_featurize / the device-side
+pushes) is in tests/test_gpu_agent.py."""
+import numpy as np
+import torch
+
+from util import load_golden
+
+A = 8               # KS22: 8 actuators sharing the policy (scripts/KS/KS22/KS22.jl:2-21)
+EP = 51 * A         # rows per episode: te / dt + 1 = 51 control steps
+
+
+def replay_head():
+    g = load_golden("ks22_agent.npz")
+    s = g["buf_0_head"][0]
+    a = g["buf_1_head"][0]
+    r = g["buf_2_head"][0]
+    t = g["terminal_0_head"].astype(np.float32)
+    assert tuple(g["buf_0_shape"]) == (1, 150001) and tuple(g["buf_2_shape"]) == (1, 150000)
+    assert tuple(g["terminal_0_shape"]) == (150000,)
+    return s, a, r, t
+
+
+def ks22_cfg():
+    from oracle import ks
+    return ks.KSConfig(192, 22.0, np.arange(1, 193, 24), sigma_sensors=0.7, sigma_actuators=0.7)
+
+
+def field_with_sensors(cfg, sensors_scaled):
+    """a field y whose sensor read-out <y, g_i> / max_value equals `sensors_scaled` (minimum-norm solution)"""
+    G = cfg.gaussians
+    return G.T @ np.linalg.solve(G @ G.T, cfg.max_value * np.asarray(sensors_scaled, dtype=np.float64))
+
+
+def transitions():
+    """(step index k, s_next [A], a [A], a_prev [A], r [A]) of every control step whose next state is still in the
+    buffer head: not the last step of an episode (its s' row was the POST_EPISODE dummy, popped and overwritten by
+    the next episode's first state); the first step of an episode has delta_action = action - action0 = action."""
+    s, a, r, t = replay_head()
+    out = []
+    for k in range((len(r) - A) // A):
+        i = k * A
+        step_in_ep = k % 51
+        if step_in_ep == 50:
+            continue
+        a_prev = np.zeros(A, np.float32) if step_in_ep == 0 else a[i - A:i]
+        out.append((k, s[i + A:i + 2 * A], a[i:i + A], a_prev, r[i:i + A]))
+    return out
+
+
+def test_terminal_layout_is_one_flag_per_actuator_on_step_51():
+    s, a, r, t = replay_head()
+    idx = np.nonzero(t)[0]
+    expect = np.concatenate([np.arange(EP - A, EP) + e * EP for e in range(len(t) // EP + 1)])
+    assert np.array_equal(idx, expect[expect < len(t)])
+
+
+def test_oracle_reward_matches_the_reference_replay_rows():
+    """A17 + A22: oracle.ks.reward_function(y', a, a - a_prev) == the reference's stored Float32 reward, with y' any
+    field whose sensors are the stored NEXT state (row i + A of the state trace)"""
+    from oracle import ks
+    cfg = ks22_cfg()
+    worst = 0.0
+    rows = transitions()
+    assert len(rows) > 480
+    for k, sn, a, ap, r in rows:
+        y = field_with_sensors(cfg, sn)
+        assert np.abs(ks.featurize(cfg, y)[0] - sn).max() < 1e-12
+        ro = ks.reward_function(cfg, y, a[None].astype(np.float64), (a - ap)[None].astype(np.float64))
+        worst = max(worst, np.abs(ro - r).max())
+    # the stored traces are Float32 (src/PDEagent.jl:112-117): half an ulp of |r| <~ 1 is 6e-8; the stored state is
+    # itself rounded, which moves |180 s|^1.3 / 90 by up to ~2e-7
+    assert worst < 1e-6, worst
+
+
+def test_wrong_next_state_offset_is_rejected():
+    """the pin has teeth: reading the next state at +A-1 or +A+1 instead of +A does not reproduce the rewards"""
+    from oracle import ks
+    cfg = ks22_cfg()
+    s, a, r, t = replay_head()
+    for off in (A - 1, A + 1):
+        errs = []
+        for k in range(1, 40):
+            i = k * A
+            y = field_with_sensors(cfg, s[i + off:i + off + A])
+            ro = ks.reward_function(cfg, y, a[None, i:i + A].astype(np.float64), (a[i:i + A] - a[i - A:i])[None].astype(np.float64))
+            errs.append(np.abs(ro - r[i:i + A]).max())
+        assert max(errs) > 1e-3
+
+
+class _FakeEnv:
+    """what Agent's stage methods read of a PDEenv (src/PDEagent.jl:254-314)"""
+
+    def __init__(self):
+        self.B = 1
+        self.state = torch.zeros(1, A, 1)
+        self.reward = torch.zeros(1, A)
+        self.done = torch.zeros(1, dtype=torch.bool)
+        self._ashape = (1, A, 1)
+        self.dtype, self.device = torch.float32, torch.device("cpu")
+
+
+def test_trajectory_glue_rebuilds_the_reference_buffer(pkg):
+    """Drive the product's Agent stages (PRE_EPISODE pop, PRE_ACT push of (s, a), POST_ACT push of (r, terminal),
+    POST_EPISODE dummy push; src/PDEagent.jl:237-314) with the reference's own stream of states / actions / rewards:
+    the four traces must come out identical to the head of the reference's saved buffer, and pde_sample's next state
+    must sit A rows further (src/PDEagent.jl:317-340)."""
+    s, a, r, t = replay_head()
+    n_ep = len(r) // EP
+    tr = pkg.CircularArraySARTTrajectory(150000, 1, 1, A, torch.device("cpu"))
+    agent = pkg.Agent(policy=type("P", (), dict(reset_stage=pkg.agent.POST_EPISODE_STAGE, update_step=0,
+                                                  update_after=10 ** 9, update_freq=1))(), trajectory=tr)
+    agent._maybe_update = lambda: None
+    env = _FakeEnv()
+    for e in range(n_ep):
+        agent(pkg.agent.PRE_EPISODE_STAGE, env)
+        for k in range(51):
+            i = e * EP + k * A
+            env.state = torch.as_tensor(s[i:i + A]).reshape(1, A, 1)
+            agent(pkg.agent.PRE_ACT_STAGE, env, torch.as_tensor(a[i:i + A]).reshape(1, A, 1))
+            env.reward = torch.as_tensor(r[i:i + A]).reshape(1, A)
+            env.done = torch.tensor([k == 50])
+            agent(pkg.agent.POST_ACT_STAGE, env)
+        env.state = torch.full((1, A, 1), 123.0)          # the state after the last step: pushed as a dummy, popped next
+        agent(pkg.agent.POST_EPISODE_STAGE, env)
+    n = n_ep * EP
+    assert len(tr) == n and tr.n_sa == n + A
+    assert np.array_equal(tr.state[:n, 0].numpy(), s[:n]) and np.array_equal(tr.action[:n, 0].numpy(), a[:n])
+    assert np.array_equal(tr.reward[:n].numpy(), r[:n]) and np.array_equal(tr.terminal[:n].numpy(), t[:n])
+    i_s, i_rt, i_sn = tr.sample_slots(np.random.default_rng(0), 256)
+    assert np.array_equal(i_sn, i_s + A) and np.array_equal(i_rt, i_s) and i_s.max() < n - A

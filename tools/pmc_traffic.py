@@ -64,7 +64,10 @@ def main():
         if f is not None and w is not None:
             e["hbm_bytes_per_launch"] = 2 * f * 1024 + w * 1024       # corrected as the guide prescribes
             e["hbm_bytes_per_launch_uncorrected"] = f * 1024 + w * 1024
-    json.dump({"source_files": [os.path.relpath(s) for s in srcs], "kernels": out}, sys.stdout, indent=1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                      # csrc_sha16(): which kernel sources these counters belong to
+    json.dump({"source_files": [os.path.relpath(s) for s in srcs], "csrc_sha16": bench.csrc_sha16(), "kernels": out},
+              sys.stdout, indent=1)
     print()
 
 
