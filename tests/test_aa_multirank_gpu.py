@@ -1,0 +1,127 @@
+"""N > 1 on ONE GPU (the box gpurun gives has a single MI355X): two rank processes share cuda:0, rendezvous over gloo
+on 127.0.0.1, and run the REAL data-parallel code path -- HIP gradient passes into the library's flat gradient
+buffers, `GradReducer.all_reduce` on those device buffers, identical ADAM / Polyak on every rank.
+
+This file sorts first on purpose: the pytest process itself never touches the GPU here (only the rank processes it
+starts do), and starting programs from a process that has already initialised the GPU is not allowed on the GPU
+boxes -- so these tests must run before any other `-m gpu` test initialises it in this process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys, json, importlib
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+rank, world, mode = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[2]
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+pkg = importlib.import_module("distributedconvrl-pde-control_amd")
+setup = pkg.KSSetup.bench_C2(256)
+A_n, ns = setup.n_actuators, setup.state_shape[0]
+Bg = 8 * world                                   # global batch of trajectories, 8 per rank
+cols_g = Bg * A_n
+g = torch.Generator().manual_seed(7)
+full = dict(state=torch.randn(cols_g, ns, generator=g), action=torch.rand(cols_g, 1, generator=g) * 2 - 1,
+            reward=-torch.rand(cols_g, generator=g), terminal=(torch.rand(cols_g, generator=g) < 0.05).float(),
+            next_state=torch.randn(cols_g, ns, generator=g))
+lo, hi = pkg.distributed.shard_range(Bg, world, rank)
+shard = {k: v[lo * A_n:hi * A_n].cuda().contiguous() for k, v in full.items()}
+
+def make(reducer, B):
+    return pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), device="cuda:0", reducer=reducer,
+                            quirk_target_broadcast=False, max_update_cols=cols_g)
+
+red = pkg.distributed.GradReducer(reduce_critic=(mode == "all"))
+assert red.world_size == world
+agent = make(red, hi - lo)
+for _ in range(3):
+    agent.policy.update(shard)
+torch.cuda.synchronize()
+pol = agent.policy
+flat = lambda nna: torch.as_tensor(np.concatenate([p.ravel() for p in nna.params()]))
+mine = {"actor": flat(pol.behavior_actor), "target_actor": flat(pol.target_actor), "critic": flat(pol.behavior_critic)}
+out = {"rank": rank, "mode": mode}
+for k, v in mine.items():
+    got = [torch.zeros_like(v) for _ in range(world)]
+    dist.all_gather(got, v)
+    out[k + "_identical"] = all(torch.equal(x, got[0]) for x in got)
+    out[k + "_finite"] = bool(torch.isfinite(v).all())
+if rank == 0 and mode == "all":
+    # single-process reference: the same three updates on the FULL batch (diagonal TD target, so the mean over the
+    # global batch equals the mean of the shard means)
+    ref = make(None, Bg)
+    fb = {k: v.cuda().contiguous() for k, v in full.items()}
+    for _ in range(3):
+        ref.policy.update(fb)
+    torch.cuda.synchronize()
+    for k, nna in (("actor", ref.policy.behavior_actor), ("critic", ref.policy.behavior_critic)):
+        r = flat(nna)
+        out[k + "_vs_single_rank"] = float((mine[k] - r).abs().max() / r.abs().max())
+    # the all-reduce really happened: one rank's own shard alone gives a different critic
+    solo = make(None, hi - lo)
+    for _ in range(3):
+        solo.policy.update(shard)
+    torch.cuda.synchronize()
+    out["critic_vs_unreduced"] = float((mine["critic"] - flat(solo.policy.behavior_critic)).abs().max())
+dist.barrier()
+if rank == 0:
+    print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def _run_ranks(tmp_path, mode, world=2):
+    script = tmp_path / "rank.py"
+    script.write_text(_WORKER)
+    port = str(29600 + os.getpid() % 1500)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")]
+    assert line, outs[0][0]
+    return json.loads(line[0][7:])
+
+
+def test_two_ranks_policy_gradient_only(tmp_path):
+    """north-star exchange: only the ACTOR gradient is all-reduced (each rank trains its own critic on its shard):
+    actors and target actors stay bit-identical replicas, the critics differ"""
+    r = _run_ranks(tmp_path, "policy")
+    assert r["actor_identical"] and r["target_actor_identical"] and r["actor_finite"] and r["critic_finite"]
+    assert not r["critic_identical"]
+
+
+def test_two_ranks_all_gradients(tmp_path):
+    """SURVEY.md §8e form: actor and critic gradients all-reduced -> every network bit-identical on every rank, and
+    equal (to fp32 summation-order tolerance, 2e-5 relative) to ONE rank updating on the whole batch"""
+    r = _run_ranks(tmp_path, "all")
+    assert r["actor_identical"] and r["target_actor_identical"] and r["critic_identical"]
+    assert r["actor_vs_single_rank"] <= 2e-5 and r["critic_vs_single_rank"] <= 2e-5, r
+    assert r["critic_vs_unreduced"] > 1e-6, r
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` (no launcher): the parent starts two fresh ranks before touching the GPU; with
+    PDEC_BENCH_BACKEND=gloo they share the single device.  One JSON line, n_gpus = 2, both ranks observed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PDEC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "4",
+                        "--batch", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_observed"] == 2 and d["collective_backend"] == "gloo"
+    assert d["config"]["global_batch"] == 128 and d["checks"]["finite"] and d["value"] > 0

@@ -202,3 +202,36 @@ def test_size_limits_are_reported_not_crashed(pkg):
     for nx in (8192, 254 * 7):          # too large for LDS; a prime factor other than 2, 3, 5
         with pytest.raises(pkg.PdecError):
             pkg.PDEenv(pkg.KSSetup.bench_C2(nx), B=1, dtype=torch.float32)
+
+
+def test_config_c3_per_gpu_shard_full_size(pkg):
+    """BASELINE.json configs[2], one GPU's shard at FULL size: KS N = 1024 (Lx = 853.33), A = 256 actuators, B = 512
+    trajectories, fp32, fused (env)(action).  Sampled trajectories (first / odd / last of the batch, both members of a
+    packed pair) against the fp64 oracle at the fp32 tolerance; all 512: finite, no blow-up flag, and with zero
+    forcing the CNAB2 step conserves sum(y) (mode 0 has L = G = 0) -- the size-independent property."""
+    from oracle import ks
+    nx, B = 1024, 512
+    setup = pkg.KSSetup.bench_C2(nx)
+    cfg = ks.KSConfig(nx, setup.Lx, setup.sensor_positions, sigma_sensors=1.0, sigma_actuators=1.0, window_size=3)
+    A = setup.n_actuators
+    assert A == 256 and abs(setup.Lx - 853.3333333333334) < 1e-9
+    rng = np.random.default_rng(3)
+    y0 = setup.generate_random_init(rng, B) * 0.15
+    act_prev, act = rng.uniform(-1, 1, (B, A)), rng.uniform(-1, 1, (B, A))
+    dt = torch.float32
+    env = pkg.PDEenv(setup, B=B, dtype=dt)
+    env.y.copy_(to_dev(y0, dt))
+    env.action.copy_(to_dev(act_prev, dt).reshape(env._ashape))
+    env(to_dev(act, dt).reshape(env._ashape))
+    assert bool(torch.isfinite(env.y).all()) and bool(torch.isfinite(env.state).all()) and int(env.done.sum()) == 0
+    for b in (0, 1, 255, 510, 511):
+        o = ks.env_step(cfg, y0[b], act_prev[b][None], act[b][None], 0.0)
+        assert np.abs(env.y[b].cpu().numpy() - o["y"]).max() <= 3e-5 * max(1.0, np.abs(o["y"]).max())
+        assert np.abs(env.p[b].cpu().numpy() - o["p"]).max() <= 1e-5 * max(1.0, np.abs(o["p"]).max())
+        assert np.abs(env.reward[b].cpu().numpy() - o["reward"]).max() <= 3e-4
+        assert np.abs(env.state[b].cpu().numpy().T - o["state"]).max() <= 3e-4
+    yd = to_dev(y0, dt)
+    out, flags = env.do_step(yd, torch.zeros_like(yd))
+    s0, s1 = yd.double().sum(1), out.double().sum(1)
+    assert float((s1 - s0).abs().max()) <= 2e-3 * float(yd.abs().sum(1).max()) / nx * 30      # fp32 sums of 1024 cells
+    assert int(flags.sum()) == 0
