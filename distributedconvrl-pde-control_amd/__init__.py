@@ -15,3 +15,4 @@ from .agent import (Agent, CustomDDPGPolicy, CircularArraySARTTrajectory, ZeroPo
 from .hook import PDEhook  # noqa: F401
 from .run import run, testrun, StopAfterEpisode, StopAfterEpisodeWithMinSteps  # noqa: F401
 from . import julia_compat, distributed, checkpoint  # noqa: F401
+from .pipeline import TrainPipeline  # noqa: F401

@@ -34,7 +34,7 @@ class EnvCfg(C.Structure):
     ]
 
 
-_vp, _i, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint64
+_vp, _i, _d, _sz, _u64, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint64, C.c_int64
 _pi32 = C.POINTER(C.c_int32)
 _pd = C.POINTER(C.c_double)
 
@@ -79,6 +79,16 @@ SIGNATURES = {
     "pdec_policy_act": [Handle, _vp, _vp, _i, _d, _d, _vp],
     "pdec_rollout": [Handle, Handle, _i, _vp, _vp, _vp, _d, _d, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdec_randn": [Handle, _vp, _sz, _i, _u64, _u64],
+    "pdec_policy_act_rng_dev": [Handle, _vp, _i, _d, _d, _i, _u64, _vp],
+    "pdec_noise_counter_set": [Handle, _u64], "pdec_noise_counter_get": [Handle, C.POINTER(_u64)],
+    "pdec_ddpg_update_small_rng": [Handle] * 4 + [_vp] * 4 + [_i, _i, _u64, _u64, _i64, _i64, _i64, _i, _d, _d, _i, _d, _d, _vp],
+    "pdec_replay_push_sa": [Handle, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _i64, _i],
+    "pdec_replay_push_rt": [Handle, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i64, _i],
+    "pdec_replay_sample": [Handle, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i64, _i64, _u64, _u64, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdec_env_autoreset": [Handle] + [_vp] * 8,
+    "pdec_env_random_init": [Handle, _u64, _u64, _vp],
+    "pdec_capture_begin": [Handle], "pdec_capture_end": [Handle, C.POINTER(Handle)],
+    "pdec_graph_launch": [Handle, _vp], "pdec_graph_num_nodes": [Handle, C.POINTER(_i)],
     "pdec_ddpg_critic_grads": [Handle] * 4 + [_vp] * 5 + [_i, _d, _i, _d, _vp],
     "pdec_ddpg_actor_grads": [Handle, Handle, _vp, _i, _d, _vp],
     "pdec_ddpg_update": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _pd, _pd],
@@ -119,9 +129,16 @@ _inited = set()
 
 
 def init(device=0):
+    """Select `device` for this process.  The design is ONE PROCESS PER GPU: handles carry no device ordinal and every
+    hipMalloc / launch of the library goes to the device selected here, so a second, different ordinal in the same
+    process is refused instead of silently running one GPU's handles on another."""
     lib = load()
+    device = int(device)
     if device not in _inited:
-        check(lib.pdec_init(int(device)))
+        if _inited:
+            raise PdecError(f"libpdeconv is already bound to device {sorted(_inited)[0]} in this process; device {device} "
+                            "needs its own process (one process per GPU, e.g. torch.distributed.run / bench.py --gpus N)")
+        check(lib.pdec_init(device))
         _inited.add(device)
     return lib
 

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .env import _on_stream
 from .nna import create_NNA
 
 PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE, POST_EPISODE_STAGE, POST_EXPERIMENT_STAGE = range(6)
@@ -43,6 +44,10 @@ class CircularArraySARTTrajectory:
     four traces stay aligned after wrap-around (reference quirks)."""
 
     def __init__(self, capacity, ns, na, stride, device, reward_per_column=True):
+        """On a CUDA device the stage operations are library kernels once `bind(model)` has named the handle whose
+        stream they run on (row F1: pdec_replay_push_sa / _push_rt / _sample, one launch per stage); on the CPU
+        (host-logic tests) they are the equivalent torch slice copies."""
+        self._h = None
         self.stride = int(stride)
         self.capacity = max(self.stride, int(capacity) // self.stride * self.stride)
         kw = dict(dtype=torch.float32, device=device)
@@ -57,6 +62,11 @@ class CircularArraySARTTrajectory:
     def __len__(self):       # length(t) = length(t[:terminal])
         return min(self.n_rt, self.capacity)
 
+    def bind(self, model):
+        """run the stage kernels on `model`'s stream (a HipMLP of the agent)"""
+        self._h, self._lib, self.stream = model.handle, model.lib, model.stream
+        return self
+
     def _slots(self, start, n, cap):
         return (torch.arange(start, start + n, device=self.device) % cap)
 
@@ -70,10 +80,19 @@ class CircularArraySARTTrajectory:
             dst.index_copy_(0, self._slots(start, n, cap), src.to(dst.dtype))
 
     def push_sa(self, s, a):
+        """PRE_ACT push of one (s, a) column per actuator (src/PDEagent.jl:254-274); a = None: the zero-action dummy of
+        POST_EPISODE (:291-314)"""
         n = s.shape[0]
         cap = self.capacity + self.stride
-        self._put(self.state, self.n_sa, s, cap)
-        self._put(self.action, self.n_sa, a, cap)
+        if self._h is not None and s.is_cuda and s.is_contiguous() and (a is None or (a.is_contiguous() and a.dtype == s.dtype)):
+            _lib.check(self._lib.pdec_replay_push_sa(self._h, _lib.ptr(self.state), _lib.ptr(self.action), cap,
+                                                     self.state.shape[1], self.action.shape[1], self.n_sa % cap, _lib.ptr(s),
+                                                     _lib.ptr(a), n, _lib.dtype_code(s.dtype)))
+        else:
+            if a is None:
+                a = torch.zeros((n, self.action.shape[1]), device=s.device)
+            self._put(self.state, self.n_sa, s, cap)
+            self._put(self.action, self.n_sa, a, cap)
         self.n_sa += n
 
     def pop_sa(self, n):
@@ -84,6 +103,32 @@ class CircularArraySARTTrajectory:
         self._put(self.reward, self.n_rt, r, self.capacity)
         self._put(self.terminal, self.n_rt, t, self.capacity)
         self.n_rt += n
+
+    def push_rt_flags(self, r, done_flags, cols_per_traj, timeout):
+        """POST_ACT push (src/PDEagent.jl:276-289) straight from the env step's outputs: r [n] and the per-trajectory
+        int32 blow-up flags (terminal of a column = its trajectory's flag, or 1 everywhere on a time-out)"""
+        n = r.shape[0]
+        if self._h is not None and r.is_cuda and r.is_contiguous():
+            _lib.check(self._lib.pdec_replay_push_rt(self._h, _lib.ptr(self.reward), _lib.ptr(self.terminal), self.capacity,
+                                                     self.n_rt % self.capacity, _lib.ptr(r), _lib.ptr(done_flags),
+                                                     int(cols_per_traj), int(bool(timeout)), n, _lib.dtype_code(r.dtype)))
+            self.n_rt += n
+        else:
+            t = torch.ones(n) if timeout else (done_flags != 0).to(torch.float32).repeat_interleave(cols_per_traj)
+            self.push_rt(r, t.to(r.device))
+
+    def sample_device(self, seed, offset, batch_size):
+        """pde_sample + pde_fetch! (src/PDEagent.jl:317-340) in one launch: indices from the Philox stream (seed, offset)"""
+        kw = dict(dtype=torch.float32, device=self.device)
+        ns, na = self.state.shape[1], self.action.shape[1]
+        out = dict(state=torch.empty((batch_size, ns), **kw), action=torch.empty((batch_size, na), **kw),
+                   reward=torch.empty(batch_size, **kw), terminal=torch.empty(batch_size, **kw),
+                   next_state=torch.empty((batch_size, ns), **kw))
+        _lib.check(self._lib.pdec_replay_sample(
+            self._h, _lib.ptr(self.state), _lib.ptr(self.action), _lib.ptr(self.reward), _lib.ptr(self.terminal), ns, na,
+            self.capacity, self.stride, len(self), self.n_rt, int(seed), int(offset), int(batch_size), _lib.ptr(out["state"]),
+            _lib.ptr(out["action"]), _lib.ptr(out["reward"]), _lib.ptr(out["terminal"]), _lib.ptr(out["next_state"]), None))
+        return out
 
     def sample_slots(self, rng, batch_size):
         """pde_sample (src/PDEagent.jl:317-321): inds in 1:length(t)-stride -> slots (i_s, i_rt, i_sn) of the (s, a),
@@ -133,6 +178,10 @@ class CustomDDPGPolicy:
         self.reducer = reducer                            # data-parallel gradient all-reduce (or None)
         self.use_small_update = True                      # minibatch updates of <= 16 transitions: one launch for all loops
         self._noise_seed, self._noise_off = int(noise_seed), 0
+        # minibatch indices: "device" = drawn inside the update kernels from the Philox stream (sample_seed, offset),
+        # "host" = drawn from self.rng as pde_sample does and handed over as index arrays
+        self.sampling = "device"
+        self._sample_seed, self._sample_off = int(noise_seed) ^ 0x5DEECE66D, 0
         m = behavior_actor.model
         self.lib, self.device = m.lib, m.device
         self._losses = torch.zeros(2, dtype=m.dtype, device=m.device)
@@ -247,6 +296,18 @@ class CustomDDPGPolicy:
             float(oc.eta), C.c_void_p(L.data_ptr())))
         self._slots_keepalive = d
 
+    def update_small_rng(self, tr):
+        """the same with pde_sample inside the kernel (pdec_ddpg_update_small_rng): the host passes seed + offset"""
+        A, Cn, At, Ct = (self.behavior_actor.model, self.behavior_critic.model, self.target_actor.model,
+                         self.target_critic.model)
+        oc, oa = self.behavior_critic.optimizer, self.behavior_actor.optimizer
+        _lib.check(self.lib.pdec_ddpg_update_small_rng(
+            A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(tr.state), _lib.ptr(tr.action), _lib.ptr(tr.reward),
+            _lib.ptr(tr.terminal), int(self.update_loops), int(self.batch_size), self._sample_seed, self._sample_off,
+            len(tr), tr.n_rt, tr.capacity, tr.stride, float(self.y), float(self.p), int(self.quirk), float(oa.eta),
+            float(oc.eta), C.c_void_p(self._losses.data_ptr())))
+        self._sample_off += (self.update_loops * self.batch_size + 3) // 4
+
     def losses(self):
         """(actor_loss, critic_loss) of the last update (synchronises)"""
         v = self._losses.cpu().numpy()
@@ -264,6 +325,11 @@ class Agent:
         if len(args) == 1:                    # agent(env) -> action
             return self.policy(args[0])
         stage, env = args[0], args[1]
+        # the torch ops of the stages run on the networks' stream, like the library kernels they are ordered with
+        with _on_stream(getattr(self.trajectory, "stream", None)):
+            self._stage(stage, env, args)
+
+    def _stage(self, stage, env, args):
         p, tr = self.policy, self.trajectory
         if stage == PRE_EPISODE_STAGE:        # :237-252 pop the dummy (s, a) of the previous episode
             if len(tr) > 0 and tr.n_sa > tr.n_rt:
@@ -276,13 +342,16 @@ class Agent:
         elif stage == POST_ACT_STAGE:         # :276-289
             r = env.reward.reshape(-1)
             cols_per_env = r.shape[0] // env.B
-            t = env.done.to(torch.float32).repeat_interleave(cols_per_env)
-            tr.push_rt(r, t)
+            flags = getattr(env, "_done_flags", None)
+            if flags is not None:             # the env step's own outputs go straight into the traces (one launch)
+                tr.push_rt_flags(r, flags, cols_per_env, env.time >= env.te)
+            else:
+                tr.push_rt(r, env.done.to(torch.float32).repeat_interleave(cols_per_env))
         elif stage == POST_EPISODE_STAGE:     # :215-224, :291-314
             if stage == p.reset_stage:
                 p.update_step = 0
             s = env.state.reshape(-1, env.state.shape[-1])
-            tr.push_sa(s, torch.zeros((s.shape[0], tr.action.shape[1]), device=s.device))
+            tr.push_sa(s, None)
         elif stage == POST_EXPERIMENT_STAGE:
             if stage == p.reset_stage:
                 p.update_step = 0
@@ -293,14 +362,21 @@ class Agent:
             return
         if p.update_step % p.update_freq != 0:                # :355
             return
+        on_device = p.sampling == "device" and getattr(tr, "_h", None) is not None
         if p.small_update_ok():
-            # all update_loops minibatch updates in ONE launch (pdec_ddpg_update_small); the slots of every loop are
-            # drawn here (pde_sample, src/PDEagent.jl:317-321) in one vectorised call
-            slots = tr.sample_slots_many(p.rng, p.batch_size, p.update_loops)
-            p.update_small(tr, slots)                         # slots: [3, loops, Bu]
+            # all update_loops minibatch updates in ONE launch; the slots of every loop (pde_sample,
+            # src/PDEagent.jl:317-321) are drawn inside the kernel from the Philox stream, or here from the host rng
+            if on_device:
+                p.update_small_rng(tr)
+            else:
+                p.update_small(tr, tr.sample_slots_many(p.rng, p.batch_size, p.update_loops))   # slots: [3, loops, Bu]
             return
         for _ in range(p.update_loops):                       # :357-360
-            p.update(tr.sample(p.rng, p.batch_size))
+            if on_device:
+                p.update(tr.sample_device(p._sample_seed, p._sample_off, p.batch_size))
+                p._sample_off += (p.batch_size + 3) // 4
+            else:
+                p.update(tr.sample(p.rng, p.batch_size))
 
 
 def create_agent(*, setup, B=1, rng=None, dtype=torch.float32, device="cuda:0", start_policy=None, mono=None,
@@ -334,4 +410,5 @@ def create_agent(*, setup, B=1, rng=None, dtype=torch.float32, device="cuda:0", 
         quirk_target_broadcast=overrides.get("quirk_target_broadcast", True),
         noise_seed=overrides.get("noise_seed", 0))
     trajectory = CircularArraySARTTrajectory(g("trajectory_length") * B, ns, na, stride, torch.device(device))
+    trajectory.bind(behavior_critic.model)         # stage kernels on the networks' stream (row F1)
     return Agent(policy, trajectory)

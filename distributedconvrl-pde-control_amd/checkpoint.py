@@ -51,7 +51,10 @@ def _adam_state(model):
     return m, v, np.array([bp[0], bp[1]])
 
 
-def save_agent(path, agent):
+def save_agent(path, agent, with_trajectory=True):
+    """what `FileIO.save(".../agent.jld2", "agent", agent)` keeps (scripts/KS/setup/KSSetup.jl:391-402): the four networks,
+    their ADAM states, the replay trajectory, plus the positions of the build's counter-based random streams -- a resumed
+    run continues the exploration noise and the minibatch sampling where the saved one stopped"""
     p = agent.policy
     kw = {}
     for name in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
@@ -63,6 +66,20 @@ def save_agent(path, agent):
         kw[f"{name}/dims"] = np.array(model.dims)
     kw["update_step"] = np.array(p.update_step)
     kw["act_noise"] = np.array(p.act_noise)
+    # exploration-noise and minibatch-sampling streams (counter-based: seed + offset is the whole state), the host rng
+    kw["noise_seed_off"] = np.array([p._noise_seed, p._noise_off], dtype=np.uint64)
+    kw["sample_seed_off"] = np.array([p._sample_seed, p._sample_off], dtype=np.uint64)
+    import json
+    kw["rng_state"] = np.array(json.dumps(p.rng.bit_generator.state, default=int))
+    if with_trajectory:                 # the replay traces, as FileIO.save of the whole Agent keeps them
+        tr = agent.trajectory
+        n_sa, n_rt = min(tr.n_sa, tr.capacity + tr.stride), min(tr.n_rt, tr.capacity)
+        kw["trajectory/counters"] = np.array([tr.n_sa, tr.n_rt, tr.capacity, tr.stride], dtype=np.int64)
+        full = tr.n_rt >= tr.capacity
+        kw["trajectory/state"] = (tr.state if full else tr.state[:n_sa]).cpu().numpy()
+        kw["trajectory/action"] = (tr.action if full else tr.action[:n_sa]).cpu().numpy()
+        kw["trajectory/reward"] = (tr.reward if full else tr.reward[:n_rt]).cpu().numpy()
+        kw["trajectory/terminal"] = (tr.terminal if full else tr.terminal[:n_rt]).cpu().numpy()
     np.savez_compressed(path, **kw)
 
 
@@ -82,4 +99,23 @@ def load_agent(path, agent):
         _lib.check(model.lib.pdec_adam_set_state(model.handle, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), bp))
     p.update_step = int(z["update_step"])
     p.act_noise = float(z["act_noise"])
+    if "noise_seed_off" in z.files:
+        p._noise_seed, p._noise_off = (int(x) for x in z["noise_seed_off"])
+        p._sample_seed, p._sample_off = (int(x) for x in z["sample_seed_off"])
+        import json
+        st = json.loads(str(z["rng_state"]))
+        try:
+            p.rng.bit_generator.state = st
+        except (ValueError, TypeError):
+            pass                          # a different bit generator than the one that was saved: keep the current stream
+    if "trajectory/counters" in z.files:
+        import torch
+        tr = agent.trajectory
+        n_sa, n_rt, cap, stride = (int(x) for x in z["trajectory/counters"])
+        if (cap, stride) != (tr.capacity, tr.stride):
+            raise _lib.PdecError(f"checkpoint {path}: trajectory capacity/stride {cap}/{stride}, agent has {tr.capacity}/{tr.stride}")
+        for name in ("state", "action", "reward", "terminal"):
+            a = torch.as_tensor(z[f"trajectory/{name}"], device=tr.device)
+            getattr(tr, name)[:a.shape[0]].copy_(a)
+        tr.n_sa, tr.n_rt = n_sa, n_rt
     return agent

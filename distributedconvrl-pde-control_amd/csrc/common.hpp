@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
     }                                  \
   } while (0)
 
-enum class Kind { Env, Mlp, Comm };
+enum class Kind { Env, Mlp, Comm, Graph };
 
 struct ProfEntry {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

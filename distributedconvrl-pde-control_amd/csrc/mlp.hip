@@ -178,8 +178,10 @@ __global__ void dz_init_kernel(T* __restrict__ dz, const T* __restrict__ dy, int
 // Flux, so the broadcast promotes), stored back in T.
 template <class T>
 __global__ void adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, int n,
-                            double eta, double b1, double b2, double eps, double omb1p, double omb2p) {
+                            double eta, double b1, double b2, double eps, BpArgs bp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double omb1p = 1.0 - bp.cur[0], omb2p = 1.0 - bp.cur[1];
+  if (i == 0) bp_advance(bp, b1, b2);
   if (i >= n) return;
   const double gi = (double)g[i];
   const T mt = (T)(b1 * (double)m[i] + (1.0 - b1) * gi);
@@ -218,8 +220,13 @@ __global__ void act_noise_clamp_kernel(const T* __restrict__ H, const T* __restr
 
 // ---- counter-based normals: Philox4x32-10 + Box-Muller (philox4x32 in mlp.hpp; replaces randn(rng), PDEagent.jl:201)
 template <class T>
-__global__ void randn_kernel(T* __restrict__ dst, size_t n, uint64_t seed, uint64_t offset) {
+__global__ void randn_kernel(T* __restrict__ dst, size_t n, uint64_t seed, uint64_t offset, const uint64_t* ctr_cur = nullptr,
+                             uint64_t* ctr_next = nullptr, uint64_t ctr_inc = 0) {
   const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;  // 4 normals per thread
+  if (ctr_cur) {       // device-resident counter (pdec_policy_act_rng_dev)
+    offset += *ctr_cur;
+    if (q == 0) *ctr_next = offset + ctr_inc;
+  }
   if (q * 4 >= n) return;
   const uint64_t ctr = offset + q;
   uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
@@ -355,7 +362,7 @@ int Mlp::init(int dtype_, int L_, const int32_t* dims_, const int32_t* acts_, in
   PDEC_HIP(slabs.alloc((size_t)nsplit_max * maxw * ts));
   PDEC_HIP(dy.alloc((size_t)dims[L] * max_cols * ts));
   PDEC_HIP(scratch.alloc(64 * 8));
-  bp[0] = bp[1] = -1.0;  // beta powers initialised on the first adam step (Flux: Float64[beta1, beta2])
+  bp_init = false;       // beta powers initialised on the first adam step (Flux: Float64[beta1, beta2])
   return PDEC_OK;
 }
 
@@ -435,6 +442,21 @@ int Mlp::backward(const void* dy, int ldy, int cols, bool want_dw, bool want_dx,
   return PDEC_OK;
 }
 
+}  // namespace pdec
+
+namespace pdec {
+int bp_begin(Mlp* M, double beta1, double beta2, BpArgs* out) {
+  if (!M->bp_init) {
+    if (!M->bpd.p) PDEC_HIP(M->bpd.alloc(4 * sizeof(double)));
+    const double init[4] = {beta1, beta2, beta1, beta2};
+    PDEC_HIP(hipMemcpy(M->bpd.p, init, sizeof(init), hipMemcpyHostToDevice));   // first step only (never inside a capture)
+    M->bp_sel = 0;
+    M->bp_init = true;
+  }
+  out->cur = M->bpd.as<double>() + 2 * M->bp_sel;
+  out->next = M->bpd.as<double>() + 2 * (M->bp_sel ^ 1);
+  return PDEC_OK;
+}
 }  // namespace pdec
 
 using namespace pdec;
@@ -608,22 +630,23 @@ int pdec_mlp_grad_buffer(pdec_handle h, void** dptr, int* n) {
 
 int pdec_adam_step(pdec_handle h, double eta, double beta1, double beta2, double eps) {
   GET_MLP(M, h);
-  if (M->bp[0] < 0) { M->bp[0] = beta1; M->bp[1] = beta2; }
+  BpArgs bp;
+  int rc = bp_begin(M, beta1, beta2, &bp);
+  if (rc) return rc;
   const int n = M->nparams;
   dim3 grid(cdiv(n, 256)), block(256);
   {
     ProfScope ps(M, "adam");
     if (M->dtype == PDEC_F64)
       hipLaunchKernelGGL((adam_kernel<double>), grid, block, 0, M->stream, M->params.as<double>(), M->grads.as<double>(),
-                         M->m.as<double>(), M->v.as<double>(), n, eta, beta1, beta2, eps, 1.0 - M->bp[0], 1.0 - M->bp[1]);
+                         M->m.as<double>(), M->v.as<double>(), n, eta, beta1, beta2, eps, bp);
     else
       hipLaunchKernelGGL((adam_kernel<float>), grid, block, 0, M->stream, M->params.as<float>(), M->grads.as<float>(),
-                         M->m.as<float>(), M->v.as<float>(), n, eta, beta1, beta2, eps, 1.0 - M->bp[0], 1.0 - M->bp[1]);
+                         M->m.as<float>(), M->v.as<float>(), n, eta, beta1, beta2, eps, bp);
   }
   PDEC_HIP(hipGetLastError());
   M->fw_dirty = true;
-  M->bp[0] *= beta1;
-  M->bp[1] *= beta2;
+  bp_done(M);
   return PDEC_OK;
 }
 
@@ -632,7 +655,13 @@ int pdec_adam_get_state(pdec_handle h, void* m_host, void* v_host, double* beta_
   int rc;
   if (m_host && (rc = get_flat(M, M->m, m_host))) return rc;
   if (v_host && (rc = get_flat(M, M->v, v_host))) return rc;
-  if (beta_pow2) { beta_pow2[0] = M->bp[0]; beta_pow2[1] = M->bp[1]; }
+  if (beta_pow2) {
+    beta_pow2[0] = beta_pow2[1] = -1.0;      // not initialised before the first ADAM step
+    if (M->bp_init) {
+      PDEC_HIP(hipStreamSynchronize(M->stream));
+      PDEC_HIP(hipMemcpy(beta_pow2, M->bpd.as<double>() + 2 * M->bp_sel, 16, hipMemcpyDeviceToHost));
+    }
+  }
   return PDEC_OK;
 }
 
@@ -641,7 +670,16 @@ int pdec_adam_set_state(pdec_handle h, const void* m_host, const void* v_host, c
   int rc;
   if (m_host && (rc = set_flat(M, M->m, m_host))) return rc;
   if (v_host && (rc = set_flat(M, M->v, v_host))) return rc;
-  if (beta_pow2) { M->bp[0] = beta_pow2[0]; M->bp[1] = beta_pow2[1]; }
+  if (beta_pow2) {
+    if (beta_pow2[0] < 0) {
+      M->bp_init = false;
+    } else {
+      if (!M->bpd.p) PDEC_HIP(M->bpd.alloc(4 * sizeof(double)));
+      PDEC_HIP(hipStreamSynchronize(M->stream));
+      PDEC_HIP(hipMemcpy(M->bpd.as<double>() + 2 * M->bp_sel, beta_pow2, 16, hipMemcpyHostToDevice));
+      M->bp_init = true;
+    }
+  }
   return PDEC_OK;
 }
 
@@ -912,23 +950,77 @@ int pdec_ddpg_update_actor_async(pdec_handle hA, pdec_handle hC, pdec_handle hAt
                             losses_dev);
 }
 
+static int policy_act_rng_impl(pdec_handle actor, Mlp* M, const void* state, int cols, double act_noise, double act_limit,
+                               int learning, uint64_t seed, uint64_t offset, void* actions_out, const uint64_t* ctr_cur,
+                               uint64_t* ctr_next, uint64_t ctr_inc) {
+  if (fused_net_supported(M) && M->dims[M->L] == 1 && M->dims[1] <= 31)
+    return fused_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, ctr_cur, ctr_next, ctr_inc);
+  if (fused2_act_supported(M, cols))
+    return fused2_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, ctr_cur, ctr_next, ctr_inc);
+  void* noise = nullptr;
+  const size_t n = (size_t)cols * M->dims[M->L];
+  if (learning || ctr_cur) {
+    if (M->noise.bytes < n * dtype_size(M->dtype)) PDEC_HIP(M->noise.alloc(n * dtype_size(M->dtype)));
+    const dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
+    ProfScope ps(M, "randn");
+    if (M->dtype == PDEC_F64)
+      hipLaunchKernelGGL((randn_kernel<double>), grid, block, 0, M->stream, M->noise.as<double>(), n, seed, offset, ctr_cur, ctr_next, ctr_inc);
+    else
+      hipLaunchKernelGGL((randn_kernel<float>), grid, block, 0, M->stream, M->noise.as<float>(), n, seed, offset, ctr_cur, ctr_next, ctr_inc);
+    PDEC_HIP(hipGetLastError());
+    if (learning) noise = M->noise.p;
+  }
+  return pdec_policy_act(actor, state, noise, cols, act_noise, act_limit, actions_out);
+}
+
 int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
                         int learning, uint64_t seed, uint64_t offset, void* actions_out) {
   GET_MLP(M, actor);
   PDEC_REQUIRE(state && actions_out && cols >= 1, "pdec_policy_act_rng: null/empty");
-  if (fused_net_supported(M) && M->dims[M->L] == 1 && M->dims[1] <= 31)
-    return fused_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out);
-  if (fused2_act_supported(M, cols))
-    return fused2_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out);
-  void* noise = nullptr;
-  if (learning) {
-    const size_t n = (size_t)cols * M->dims[M->L];
-    if (M->noise.bytes < n * dtype_size(M->dtype)) PDEC_HIP(M->noise.alloc(n * dtype_size(M->dtype)));
-    int rc = pdec_randn(actor, M->noise.p, n, M->dtype, seed, offset);
-    if (rc) return rc;
-    noise = M->noise.p;
+  return policy_act_rng_impl(actor, M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, nullptr, nullptr, 0);
+}
+
+static int ensure_noise_ctr(Mlp* M) {
+  if (!M->noise_ctr.p) {
+    PDEC_HIP(M->noise_ctr.alloc(2 * sizeof(uint64_t)));
+    PDEC_HIP(hipMemset(M->noise_ctr.p, 0, 2 * sizeof(uint64_t)));
+    M->nc_sel = 0;
   }
-  return pdec_policy_act(actor, state, noise, cols, act_noise, act_limit, actions_out);
+  return PDEC_OK;
+}
+
+int pdec_policy_act_rng_dev(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
+                            int learning, uint64_t seed, void* actions_out) {
+  GET_MLP(M, actor);
+  PDEC_REQUIRE(state && actions_out && cols >= 1, "pdec_policy_act_rng_dev: null/empty");
+  int rc = ensure_noise_ctr(M);
+  if (rc) return rc;
+  uint64_t* c = M->noise_ctr.as<uint64_t>();
+  const uint64_t inc = learning ? ((uint64_t)cols * M->dims[M->L] + 3) / 4 : 0;   // counters one call consumes (4 normals each)
+  rc = policy_act_rng_impl(actor, M, state, cols, act_noise, act_limit, learning, seed, 0, actions_out, c + M->nc_sel,
+                           c + (M->nc_sel ^ 1), inc);
+  if (rc) return rc;
+  M->nc_sel ^= 1;
+  return PDEC_OK;
+}
+
+int pdec_noise_counter_set(pdec_handle actor, uint64_t value) {
+  GET_MLP(M, actor);
+  int rc = ensure_noise_ctr(M);
+  if (rc) return rc;
+  PDEC_HIP(hipStreamSynchronize(M->stream));
+  PDEC_HIP(hipMemcpy(M->noise_ctr.as<uint64_t>() + M->nc_sel, &value, sizeof(value), hipMemcpyHostToDevice));
+  return PDEC_OK;
+}
+
+int pdec_noise_counter_get(pdec_handle actor, uint64_t* value) {
+  GET_MLP(M, actor);
+  PDEC_REQUIRE(value, "pdec_noise_counter_get: null");
+  int rc = ensure_noise_ctr(M);
+  if (rc) return rc;
+  PDEC_HIP(hipStreamSynchronize(M->stream));
+  PDEC_HIP(hipMemcpy(value, M->noise_ctr.as<uint64_t>() + M->nc_sel, sizeof(*value), hipMemcpyDeviceToHost));
+  return PDEC_OK;
 }
 
 }  // extern "C"

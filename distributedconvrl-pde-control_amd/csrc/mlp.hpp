@@ -12,7 +12,15 @@ struct Mlp : Object {
   std::vector<int> dims, acts;
   std::vector<size_t> w_off, b_off;  // offsets into the flat buffers; W_l row-major [out][in], then b_l
   DevBuf params, grads, m, v;        // flat parameter / gradient / ADAM moment buffers
-  double bp[2];                      // ADAM beta powers (Flux keeps Float64[beta1^t, beta2^t])
+  // ADAM beta powers (Flux keeps Float64[beta1^t, beta2^t] beside the moments) are DEVICE resident and double-buffered:
+  // every ADAM kernel reads slot `bp_sel` and ONE of its threads writes the advanced powers into the other slot, so
+  // no launch argument depends on the step count and a captured HIP graph of the update replays unchanged (the
+  // host only flips bp_sel, which returns to its captured value after an even number of steps).
+  DevBuf bpd;                        // double [2][2]
+  int bp_sel = 0;
+  bool bp_init = false;
+  DevBuf noise_ctr;                  // uint64 [2]: double-buffered exploration-noise counter of pdec_policy_act_rng_dev
+  int nc_sel = 0;
   std::vector<DevBuf> H;             // activations, feature-major [dims[l]][cols]
   DevBuf dz[2];                      // ping-pong dL/dz buffers [maxdim][cols]
   DevBuf dy;                         // dL/dy of the output layer [dims[L]][cols]
@@ -50,6 +58,22 @@ __device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t 
   }
 }
 
+// kernel-side view of the beta powers: read `cur` (every thread that needs it), one thread of the grid writes `next`
+struct BpArgs {
+  const double* cur;
+  double* next;
+};
+// slots for the next ADAM kernel on M (uploads {beta1, beta2} on the first step: Flux initialises the powers with the
+// betas themselves); the caller flips M->bp_sel after enqueueing the kernel (bp_done)
+int bp_begin(Mlp* M, double beta1, double beta2, BpArgs* out);
+inline void bp_done(Mlp* M) { M->bp_sel ^= 1; }
+__device__ __forceinline__ void bp_advance(const BpArgs& a, double b1, double b2, int times = 1) {
+  double p0 = a.cur[0], p1 = a.cur[1];
+  for (int i = 0; i < times; ++i) { p0 *= b1; p1 *= b2; }
+  a.next[0] = p0;
+  a.next[1] = p1;
+}
+
 // mlp_mfma.hip: fused fp32 MFMA DDPG passes (3-layer actor/critic pairs)
 struct AdamPolyak {
   double eta, b1, b2, eps, rho;
@@ -64,8 +88,10 @@ int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const vo
 int fused_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double grad_scale, void* loss_dev,
                       const AdamPolyak* apply);
 int fused_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap);
+// ctr_cur != null: the noise offset is *ctr_cur (+ offset) and one thread writes *ctr_next = that + ctr_inc
 int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning,
-                     uint64_t seed, uint64_t offset, void* actions_out);
+                     uint64_t seed, uint64_t offset, void* actions_out, const uint64_t* ctr_cur = nullptr,
+                     uint64_t* ctr_next = nullptr, uint64_t ctr_inc = 0);
 
 // mlp_mfma2.hip: the same passes for the reference-shaped 2-layer nets [ns, h, 1] / [ns+1, H, 1] (flat parameters, no image)
 // mean of r[0..n) in a fixed order, one block; *out = device scalar owned by C (mlp_mfma2.hip)
@@ -74,7 +100,8 @@ bool fused2_supported(const Mlp* A, const Mlp* C);
 bool fused2_net_supported(const Mlp* M);
 bool fused2_act_supported(const Mlp* A, int cols);
 int fused2_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning, uint64_t seed,
-                      uint64_t offset, void* actions_out);
+                      uint64_t offset, void* actions_out, const uint64_t* ctr_cur = nullptr, uint64_t* ctr_next = nullptr,
+                      uint64_t ctr_inc = 0);
 int fused2_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap);
 int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const void* a, const void* r, const void* t,
                         const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,

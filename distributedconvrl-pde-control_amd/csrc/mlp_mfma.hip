@@ -562,7 +562,8 @@ struct FinishArgs {
   float* fwp;                  // published copy of the updated image (double-buffered: a concurrent acting kernel
                                // keeps reading the other copy), may be null
   FNet lay;
-  double eta, b1, b2, eps, omb1p, omb2p;
+  double eta, b1, b2, eps, omb1p, omb2p;   // omb*p = 1 - beta^t: filled in by the kernel from `bp` (device resident)
+  BpArgs bp;
   float rho, omr;
 };
 
@@ -602,7 +603,13 @@ __device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float g
 // block = 64 chunk elements x 16 slab groups (1024 threads): each thread sums every 16th slab (16 loads in flight,
 // a contiguous 256-B row each), then a fixed-order combine over the groups -> deterministic, so data-parallel
 // replicas stay bit-identical.
-__global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g) {
+__global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g_in) {
+  FinishArgs g = g_in;
+  if (g.apply) {      // the beta powers come from device memory; one thread of the grid writes the advanced pair
+    g.omb1p = 1.0 - g.bp.cur[0];
+    g.omb2p = 1.0 - g.bp.cur[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) bp_advance(g.bp, g.b1, g.b2);
+  }
   __shared__ float part[16][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int K0 = g.K0, H = g.H, MT = g.MT;
@@ -695,8 +702,13 @@ __global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g) {
 template <int MTA>
 __global__ __launch_bounds__(ACT_THREADS) void policy_act_fused_kernel(FNet f, const float* __restrict__ state, int cols, int ns,
                                                                       float act_noise, float lim, int learning, int tanh_out,
-                                                                      uint64_t seed, uint64_t offset, float* __restrict__ out) {
+                                                                      uint64_t seed, uint64_t offset, float* __restrict__ out,
+                                                                      const uint64_t* ctr_cur, uint64_t* ctr_next, uint64_t ctr_inc) {
   extern __shared__ __align__(16) float smem[];
+  if (ctr_cur) {       // noise counter kept on the device (pdec_policy_act_rng_dev): read it, one thread writes the advanced value
+    offset += *ctr_cur;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr_next = offset + ctr_inc;
+  }
   // short latency-critical kernel (the PDE step waits for it): outrank the update passes it may share CUs with
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
@@ -883,12 +895,13 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   g.loss_out = (float*)loss_dev;
   g.apply = ap != nullptr;
   if (ap) {
-    if (M->bp[0] < 0) { M->bp[0] = ap->b1; M->bp[1] = ap->b2; }
+    int rcb = bp_begin(M, ap->b1, ap->b2, &g.bp);
+    if (rcb) return rcb;
     g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
     g.fw = M->fw.as<float>();
     g.fwp = M->fw_pub[M->pub ^ 1].as<float>();       // written now, read by acting kernels enqueued after this launch
     g.lay = make_fnet_layout(M->dims[0], M->dims[1]);
-    g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps; g.omb1p = 1.0 - M->bp[0]; g.omb2p = 1.0 - M->bp[1];
+    g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps;
     if (Mt) {
       g.pt = Mt->params.as<float>(); g.fwt = Mt->fw.as<float>();
       const float r = (float)ap->rho;   // the reference holds p = 0.995f0 and computes (1 - p) in Float32
@@ -903,15 +916,14 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   }
   PDEC_HIP(hipGetLastError());
   if (ap) {
-    M->bp[0] *= ap->b1;
-    M->bp[1] *= ap->b2;
+    bp_done(M);
     M->pub ^= 1;
   }
   return PDEC_OK;
 }
 
 int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning, uint64_t seed,
-                     uint64_t offset, void* actions_out) {
+                     uint64_t offset, void* actions_out, const uint64_t* ctr_cur, uint64_t* ctr_next, uint64_t ctr_inc) {
   int rc = ensure_prepped(A);
   if (rc) return rc;
   FNet f = fnet_of(A);
@@ -930,10 +942,12 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
   const dim3 grid((cols + 63) / 64), block(ACT_THREADS);
   if (mta == 1)
     hipLaunchKernelGGL(policy_act_fused_kernel<1>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
-                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out);
+                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out, ctr_cur, ctr_next,
+                       ctr_inc);
   else
     hipLaunchKernelGGL(policy_act_fused_kernel<2>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
-                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out);
+                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out, ctr_cur, ctr_next,
+                       ctr_inc);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }

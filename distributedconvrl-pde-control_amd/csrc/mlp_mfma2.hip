@@ -552,7 +552,8 @@ struct Finish2Args {
   float* loss_out;
   int apply;
   float *p, *m, *v, *pt;
-  double eta, b1, b2, eps, omb1p, omb2p;
+  double eta, b1, b2, eps, omb1p, omb2p;   // omb*p = 1 - beta^t: filled in by the kernels from `bp` (device resident)
+  BpArgs bp;
   float rho, omr;
 };
 
@@ -572,7 +573,13 @@ __device__ __forceinline__ void finish2_param(const Finish2Args& g, int i, float
 }
 
 // one block per chunk: 64 chunk elements x 16 slab groups, fixed-order combine -> deterministic
-__global__ __launch_bounds__(1024) void finish2_kernel(Finish2Args g) {
+__global__ __launch_bounds__(1024) void finish2_kernel(Finish2Args g_in) {
+  Finish2Args g = g_in;
+  if (g.apply) {      // beta powers from device memory; one thread of the grid writes the advanced pair
+    g.omb1p = 1.0 - g.bp.cur[0];
+    g.omb2p = 1.0 - g.bp.cur[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) bp_advance(g.bp, g.b1, g.b2);
+  }
   __shared__ float part[16][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int K0 = g.K0, H = g.H, MT = g.MT, nR = g.nR;
@@ -642,8 +649,12 @@ __global__ __launch_bounds__(1024) void finish2_kernel(Finish2Args g) {
 }
 
 // ADAM + Polyak from the flat gradient buffer (after an external all-reduce): same arithmetic as the fused finish
-__global__ void apply2_kernel(Finish2Args g, int n) {
+__global__ void apply2_kernel(Finish2Args g_in, int n) {
+  Finish2Args g = g_in;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  g.omb1p = 1.0 - g.bp.cur[0];
+  g.omb2p = 1.0 - g.bp.cur[1];
+  if (i == 0) bp_advance(g.bp, g.b1, g.b2);
   if (i < n) finish2_param(g, i, g.grads[i]);
 }
 
@@ -654,9 +665,14 @@ __global__ void apply2_kernel(Finish2Args g, int n) {
 template <int MTA, int KB>
 __global__ __launch_bounds__(256) void policy_act2_kernel(Net2 n, const float* __restrict__ state, int cols, float act_noise,
                                                           float lim, int learning, int tanh_out, uint64_t seed, uint64_t offset,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, const uint64_t* ctr_cur, uint64_t* ctr_next,
+                                                          uint64_t ctr_inc) {
   constexpr int LDK = 8 * KB + 4, HPa = 16 * MTA;
   extern __shared__ __align__(16) float smem[];
+  if (ctr_cur) {       // device-resident noise counter (pdec_policy_act_rng_dev)
+    offset += *ctr_cur;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr_next = offset + ctr_inc;
+  }
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
   const Lds2 SA = carve2(smem, HPa, LDK);
   // image load with 256 threads (load_net2 assumes FTHREADS): plain row copy, the actor is small
@@ -787,9 +803,10 @@ static int launch_finish2(Mlp* M, Mlp* Mt, int nslab, int MT, int nR, double gra
   g.loss_out = (float*)loss_dev;
   g.apply = ap != nullptr;
   if (ap) {
-    if (M->bp[0] < 0) { M->bp[0] = ap->b1; M->bp[1] = ap->b2; }
+    int rcb = bp_begin(M, ap->b1, ap->b2, &g.bp);
+    if (rcb) return rcb;
     g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
-    g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps; g.omb1p = 1.0 - M->bp[0]; g.omb2p = 1.0 - M->bp[1];
+    g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps;
     if (Mt) {
       g.pt = Mt->params.as<float>();
       const float r = (float)ap->rho;
@@ -802,8 +819,7 @@ static int launch_finish2(Mlp* M, Mlp* Mt, int nslab, int MT, int nR, double gra
   }
   PDEC_HIP(hipGetLastError());
   if (ap) {
-    M->bp[0] *= ap->b1;
-    M->bp[1] *= ap->b2;
+    bp_done(M);
     M->fw_dirty = true;
     if (Mt) Mt->fw_dirty = true;
   }
@@ -818,7 +834,7 @@ bool fused2_act_supported(const Mlp* A, int cols) {
 }
 
 int fused2_policy_act(Mlp* A, const void* state, int cols, double act_noise, double act_limit, int learning, uint64_t seed,
-                      uint64_t offset, void* actions_out) {
+                      uint64_t offset, void* actions_out, const uint64_t* ctr_cur, uint64_t* ctr_next, uint64_t ctr_inc) {
   const Net2 n = net2_of(A);
   const int mta = mt2_of(A->dims[1]), tanh_out = A->acts[1] == PDEC_ACT_TANH;
   const dim3 grid((cols + 63) / 64), block(256);
@@ -826,7 +842,7 @@ int fused2_policy_act(Mlp* A, const void* state, int cols, double act_noise, dou
 #define ACT2(MTA, KB)                                                                                                       \
   hipLaunchKernelGGL((policy_act2_kernel<MTA, KB>), grid, block, (size_t)lds2_floats(16 * MTA, 8 * KB + 4) * 4, A->stream, n, \
                      (const float*)state, cols, (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset,       \
-                     (float*)actions_out)
+                     (float*)actions_out, ctr_cur, ctr_next, ctr_inc)
   if (n.kb <= 2) { if (mta == 1) ACT2(1, 2); else ACT2(2, 2); }
   else if (n.kb <= 5) { if (mta == 1) ACT2(1, 5); else ACT2(2, 5); }
   else { if (mta == 1) ACT2(1, 6); else ACT2(2, 6); }
@@ -841,9 +857,10 @@ int fused2_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap) {
   Finish2Args g{};
   g.grads = M->grads.as<float>();
   g.apply = 1;
-  if (M->bp[0] < 0) { M->bp[0] = ap.b1; M->bp[1] = ap.b2; }
+  int rcb = bp_begin(M, ap.b1, ap.b2, &g.bp);
+  if (rcb) return rcb;
   g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
-  g.eta = ap.eta; g.b1 = ap.b1; g.b2 = ap.b2; g.eps = ap.eps; g.omb1p = 1.0 - M->bp[0]; g.omb2p = 1.0 - M->bp[1];
+  g.eta = ap.eta; g.b1 = ap.b1; g.b2 = ap.b2; g.eps = ap.eps;
   if (Mt) {
     g.pt = Mt->params.as<float>();
     const float r = (float)ap.rho;
@@ -854,8 +871,7 @@ int fused2_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap) {
     hipLaunchKernelGGL(apply2_kernel, dim3((M->nparams + 255) / 256), dim3(256), 0, M->stream, g, M->nparams);
   }
   PDEC_HIP(hipGetLastError());
-  M->bp[0] *= ap.b1;
-  M->bp[1] *= ap.b2;
+  bp_done(M);
   M->fw_dirty = true;
   if (Mt) Mt->fw_dirty = true;
   return PDEC_OK;

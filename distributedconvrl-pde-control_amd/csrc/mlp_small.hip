@@ -32,9 +32,34 @@ struct SmallArgs {
   int lds_params;           // != 0: parameters, moments and gradients of all four networks are staged in LDS for the whole
                             // launch (the layer-to-layer dependency chain then pays LDS, not L2, latency)
   float gamma, rho;
-  double eta_a, eta_c, b1, b2, eps, bp_a0, bp_a1, bp_c0, bp_c1;
+  double eta_a, eta_c, b1, b2, eps;
+  BpArgs bpA, bpC;          // device-resident ADAM beta powers of the actor / critic (read cur, thread 0 writes next)
   float* losses;            // [2]: critic loss, actor loss of the last loop
+  // pde_sample on the device (src/PDEagent.jl:317-321): when smp_on, the slots are not read from i_s / i_rt / i_sn but
+  // drawn here from the Philox counter stream (seed, offset): draw k (= loop * Bu + column) is word k % 4 of counter
+  // offset + k / 4, ind = (word * hi) >> 32 in [0, hi), logical index lg = base + ind,
+  // slots (lg % cap1, lg % cap, (lg + stride) % cap1).  The slot table lives in LDS at float offset smp_lds.
+  int smp_on, smp_lds;
+  uint64_t smp_seed, smp_offset;
+  uint32_t smp_hi;
+  int64_t smp_base;
+  int smp_cap, smp_cap1, smp_stride;
 };
+
+// draw the [loops][Bu] slot tables into LDS (see SmallArgs); every thread then reads them after a barrier
+__device__ __forceinline__ void sm_draw_slots(const SmallArgs& g, int* tab, int tid, int nt) {
+  const int n = g.loops * g.Bu;
+  for (int k = tid; k < n; k += nt) {
+    const uint64_t ctr = g.smp_offset + (uint64_t)(k >> 2);
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    philox4x32(c, (uint32_t)g.smp_seed, (uint32_t)(g.smp_seed >> 32));
+    const uint32_t ind = (uint32_t)(((uint64_t)c[k & 3] * (uint64_t)g.smp_hi) >> 32);
+    const int64_t lg = g.smp_base + (int64_t)ind;
+    tab[k] = (int)(lg % g.smp_cap1);
+    tab[n + k] = (int)(lg % g.smp_cap);
+    tab[2 * n + k] = (int)((lg + g.smp_stride) % g.smp_cap1);
+  }
+}
 
 __device__ __forceinline__ float sm_act(float z, int act) {
   return act == PDEC_ACT_RELU ? fmaxf(z, 0.f) : (act == PDEC_ACT_TANH ? tanhf(z) : z);
@@ -157,8 +182,15 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g_in) 
   float* t = q; q += Bu;
   float* qt = q; q += Bu;
   float* red = q;                         // [4]
-  double bpa0 = g.bp_a0, bpa1 = g.bp_a1, bpc0 = g.bp_c0, bpc1 = g.bp_c1;
+  double bpa0 = g.bpA.cur[0], bpa1 = g.bpA.cur[1], bpc0 = g.bpC.cur[0], bpc1 = g.bpC.cur[1];
   const float omr = 1.0f - g.rho;
+  if (g.smp_on) {
+    int* tab = reinterpret_cast<int*>(sm + g.smp_lds);
+    sm_draw_slots(g, tab, tid, SM_THREADS);
+    const int n = g.loops * Bu;
+    g.i_s = tab; g.i_rt = tab + n; g.i_sn = tab + 2 * n;
+    __syncthreads();
+  }
   // optional LDS residency of the learner state: [A.p | A.pt | A.m | A.v | A.g | C.p | C.pt | C.m | C.v | C.g]
   SmallNet gA = g.A, gC = g.C;     // global-memory views (written back at the end)
   if (g.lds_params) {
@@ -258,6 +290,10 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g_in) 
   if (tid == 0 && g.losses) {
     g.losses[0] = red[0];
     g.losses[1] = red[1];
+  }
+  if (tid == 0) {
+    g.bpA.next[0] = bpa0; g.bpA.next[1] = bpa1;
+    g.bpC.next[0] = bpc0; g.bpC.next[1] = bpc1;
   }
   if (g.lds_params) {
     for (int i = tid; i < gA.nparams; i += SM_THREADS) { gA.p[i] = g.A.p[i]; gA.pt[i] = g.A.pt[i]; gA.m[i] = g.A.m[i]; gA.v[i] = g.A.v[i]; }
@@ -368,17 +404,25 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   // the buffer of the exchange right before it (a fast wave cannot overwrite partials a slow wave is still summing)
   float* redb[2] = {red0, red1};
   int rp = 0;
+  const int *i_s = g.i_s, *i_rt = g.i_rt, *i_sn = g.i_sn;
+  if (g.smp_on) {
+    int* tab = reinterpret_cast<int*>(sm + g.smp_lds);
+    sm_draw_slots(g, tab, tid, nt);
+    const int n = g.loops * g.Bu;
+    i_s = tab; i_rt = tab + n; i_sn = tab + 2 * n;
+    __syncthreads();
+  }
   for (int idx = tid; idx < g.loops * ns * Bu; idx += nt) {
     const int it = idx / (ns * Bu), rem = idx - it * (ns * Bu), k = rem / Bu, c = rem - k * Bu;
-    batch[it * bstride + rem] = g.state[(size_t)g.i_sn[it * Bu + c] * ns + k];
-    batch[it * bstride + ns * Bu + rem] = g.state[(size_t)g.i_s[it * Bu + c] * ns + k];
+    batch[it * bstride + rem] = g.state[(size_t)i_sn[it * Bu + c] * ns + k];
+    batch[it * bstride + ns * Bu + rem] = g.state[(size_t)i_s[it * Bu + c] * ns + k];
   }
   for (int idx = tid; idx < g.loops * Bu; idx += nt) {
     const int it = idx / Bu, c = idx - it * Bu;
     float* b = batch + it * bstride + 2 * ns * Bu;
-    b[c] = g.action[g.i_s[idx]];
-    b[Bu + c] = g.reward[g.i_rt[idx]];
-    b[2 * Bu + c] = g.terminal[g.i_rt[idx]];
+    b[c] = g.action[i_s[idx]];
+    b[Bu + c] = g.reward[i_rt[idx]];
+    b[2 * Bu + c] = g.terminal[i_rt[idx]];
   }
   // ---- this thread's unit: parameters p, moments m/v, target pt
   float cw1[KC], cw1m[KC], cw1v[KC], cw1t[KC], cb1 = 0, cb1m = 0, cb1v = 0, cb1t = 0, cw2 = 0, cw2m = 0, cw2v = 0, cw2t = 0;
@@ -408,7 +452,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
     ab1 = g.A.p[aob1 + tid]; ab1m = g.A.m[aob1 + tid]; ab1v = g.A.v[aob1 + tid]; ab1t = g.A.pt[aob1 + tid];
     aw2 = g.A.p[aow2 + tid]; aw2m = g.A.m[aow2 + tid]; aw2v = g.A.v[aow2 + tid]; aw2t = g.A.pt[aow2 + tid];
   }
-  double bpa0 = g.bp_a0, bpa1 = g.bp_a1, bpc0 = g.bp_c0, bpc1 = g.bp_c1;
+  double bpa0 = g.bpA.cur[0], bpa1 = g.bpA.cur[1], bpc0 = g.bpC.cur[0], bpc1 = g.bpC.cur[1];
   const float omr = 1.0f - g.rho, invB = 1.f / (float)Bu;
   float closs = 0.f, aloss = 0.f;
   for (int it = 0; it < g.loops; ++it) {
@@ -588,6 +632,8 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
     g.C.p[cob2] = cb2; g.C.m[cob2] = cb2m; g.C.v[cob2] = cb2v; g.C.pt[cob2] = cb2t;
     g.A.p[aob2] = ab2; g.A.m[aob2] = ab2m; g.A.v[aob2] = ab2v; g.A.pt[aob2] = ab2t;
     if (g.losses) { g.losses[0] = closs; g.losses[1] = aloss; }
+    g.bpA.next[0] = bpa0; g.bpA.next[1] = bpa1;
+    g.bpC.next[0] = bpc0; g.bpC.next[1] = bpc1;
   }
 }
 
@@ -615,17 +661,23 @@ static int fill_net(SmallNet& n, Mlp* M, Mlp* T) {
 
 using namespace pdec;
 
-extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* state_trace,
-                                      const void* action_trace, const void* reward_trace, const void* terminal_trace,
-                                      const int32_t* idx_s, const int32_t* idx_rt, const int32_t* idx_sn, int loops, int Bu,
-                                      double gamma, double rho, int quirk, double eta_actor, double eta_critic,
-                                      void* losses_dev) {
+struct SmallSampling {     // != null: draw the slots in the kernel (pdec_ddpg_update_small_rng)
+  uint64_t seed, offset;
+  int64_t n_valid, n_rt, capacity;
+  int stride;
+};
+
+static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* state_trace,
+                                  const void* action_trace, const void* reward_trace, const void* terminal_trace,
+                                  const int32_t* idx_s, const int32_t* idx_rt, const int32_t* idx_sn, int loops, int Bu,
+                                  double gamma, double rho, int quirk, double eta_actor, double eta_critic,
+                                  void* losses_dev, const SmallSampling* smp) {
   Mlp* A = lookup_as<Mlp>(hA, Kind::Mlp);
   Mlp* C = lookup_as<Mlp>(hC, Kind::Mlp);
   Mlp* At = lookup_as<Mlp>(hAt, Kind::Mlp);
   Mlp* Ct = lookup_as<Mlp>(hCt, Kind::Mlp);
   if (!A || !C || !At || !Ct) { set_error("pdec_ddpg_update_small: bad network handle"); return PDEC_E_HANDLE; }
-  PDEC_REQUIRE(state_trace && action_trace && reward_trace && terminal_trace && idx_s && idx_rt && idx_sn,
+  PDEC_REQUIRE(state_trace && action_trace && reward_trace && terminal_trace && (smp || (idx_s && idx_rt && idx_sn)),
                "pdec_ddpg_update_small: null argument");
   PDEC_REQUIRE(loops >= 1 && Bu >= 1 && Bu <= 16, "pdec_ddpg_update_small: needs 1 <= Bu <= 16 (got %d)", Bu);
   PDEC_REQUIRE(A->dtype == PDEC_F32 && C->dtype == PDEC_F32 && At->dtype == PDEC_F32 && Ct->dtype == PDEC_F32,
@@ -653,10 +705,18 @@ extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handl
   g.loops = loops; g.Bu = Bu; g.ns = ns; g.na = na; g.quirk = quirk;
   g.gamma = (float)gamma; g.rho = (float)rho;      // Float32 in the reference (y = 0.99f0, p = 0.995f0)
   g.eta_a = eta_actor; g.eta_c = eta_critic; g.b1 = 0.9; g.b2 = 0.999; g.eps = 1e-8;
-  if (A->bp[0] < 0) { A->bp[0] = g.b1; A->bp[1] = g.b2; }
-  if (C->bp[0] < 0) { C->bp[0] = g.b1; C->bp[1] = g.b2; }
-  g.bp_a0 = A->bp[0]; g.bp_a1 = A->bp[1]; g.bp_c0 = C->bp[0]; g.bp_c1 = C->bp[1];
+  if ((rc = bp_begin(A, g.b1, g.b2, &g.bpA)) || (rc = bp_begin(C, g.b1, g.b2, &g.bpC))) return rc;
   g.losses = (float*)losses_dev;
+  const size_t tab_floats = smp ? (size_t)3 * loops * Bu : 0;
+  if (smp) {
+    const int64_t hi = smp->n_valid - smp->stride;           // inds in 1:length(t)-number_actuators (src/PDEagent.jl:318)
+    PDEC_REQUIRE(hi >= 1 && hi < ((int64_t)1 << 32) && smp->capacity >= 1 && smp->stride >= 0,
+                 "pdec_ddpg_update_small_rng: nothing to sample (valid %lld, stride %d)", (long long)smp->n_valid, smp->stride);
+    g.smp_on = 1;
+    g.smp_seed = smp->seed; g.smp_offset = smp->offset; g.smp_hi = (uint32_t)hi;
+    g.smp_base = smp->n_rt > smp->capacity ? smp->n_rt - smp->capacity : 0;      // logical index of the oldest entry
+    g.smp_cap = (int)smp->capacity; g.smp_cap1 = (int)(smp->capacity + smp->stride); g.smp_stride = smp->stride;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ddpg_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -669,7 +729,9 @@ extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handl
     a2.g.lds_params = 0;
     a2.nC = C->dims[1]; a2.nA = A->dims[1];
     const int nt = (std::max(a2.nC, a2.nA) + 63) / 64 * 64, nwv = nt / 64;
-    const size_t lds2 = ((size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * nwv * 2 * S2_BU) * 4;   // reduction rows: at most 2 * S2_BU
+    const size_t lds2f = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * nwv * 2 * S2_BU;   // reduction rows: at most 2 * S2_BU
+    a2.g.smp_lds = (int)lds2f;
+    const size_t lds2 = (lds2f + tab_floats) * 4;
     ProfScope ps(C, "ddpg_small");
 #define S2_LAUNCH(KC, KA, BUT, EX) hipLaunchKernelGGL((ddpg_small2_kernel<KC, KA, BUT, EX>), dim3(1), dim3(nt), lds2, C->stream, a2)
     if (Bu == 3 && ns == 1) S2_LAUNCH(2, 1, 3, true);            // KS22 / KS200 / KS500
@@ -681,14 +743,33 @@ extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handl
     else S2_LAUNCH(16, 15, S2_BU, false);
 #undef S2_LAUNCH
   } else {
+    g.smp_lds = (int)(lds / 4);
+    PDEC_REQUIRE(lds + tab_floats * 4 <= 160 * 1024, "pdec_ddpg_update_small: the slot table does not fit beside the learner state in LDS");
     ProfScope ps(C, "ddpg_small");
-    hipLaunchKernelGGL(ddpg_small_kernel, dim3(1), dim3(SM_THREADS), lds, C->stream, g);
+    hipLaunchKernelGGL(ddpg_small_kernel, dim3(1), dim3(SM_THREADS), lds + tab_floats * 4, C->stream, g);
   }
   PDEC_HIP(hipGetLastError());
-  for (int it = 0; it < loops; ++it) {
-    A->bp[0] *= g.b1; A->bp[1] *= g.b2;
-    C->bp[0] *= g.b1; C->bp[1] *= g.b2;
-  }
+  bp_done(A);
+  bp_done(C);
   A->fw_dirty = C->fw_dirty = At->fw_dirty = Ct->fw_dirty = true;
   return PDEC_OK;
+}
+
+extern "C" int pdec_ddpg_update_small(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* state_trace,
+                                      const void* action_trace, const void* reward_trace, const void* terminal_trace,
+                                      const int32_t* idx_s, const int32_t* idx_rt, const int32_t* idx_sn, int loops, int Bu,
+                                      double gamma, double rho, int quirk, double eta_actor, double eta_critic,
+                                      void* losses_dev) {
+  return ddpg_update_small_impl(hA, hC, hAt, hCt, state_trace, action_trace, reward_trace, terminal_trace, idx_s, idx_rt, idx_sn,
+                                loops, Bu, gamma, rho, quirk, eta_actor, eta_critic, losses_dev, nullptr);
+}
+
+extern "C" int pdec_ddpg_update_small_rng(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* state_trace,
+                                          const void* action_trace, const void* reward_trace, const void* terminal_trace,
+                                          int loops, int Bu, uint64_t seed, uint64_t offset, int64_t n_valid, int64_t n_rt,
+                                          int64_t capacity, int stride, double gamma, double rho, int quirk, double eta_actor,
+                                          double eta_critic, void* losses_dev) {
+  SmallSampling smp{seed, offset, n_valid, n_rt, capacity, stride};
+  return ddpg_update_small_impl(hA, hC, hAt, hCt, state_trace, action_trace, reward_trace, terminal_trace, nullptr, nullptr, nullptr,
+                                loops, Bu, gamma, rho, quirk, eta_actor, eta_critic, losses_dev, &smp);
 }

@@ -24,8 +24,30 @@ def _stream_ptr(stream):
     return C.c_void_p(stream.cuda_stream)
 
 
+class _on_stream:
+    """run the torch ops of a block on the handle's stream, so that they are ordered with the library's kernels
+    (torch streams are non-blocking: work on torch's current stream is NOT ordered with another stream's kernels)"""
+
+    def __init__(self, stream):
+        self.ctx = torch.cuda.stream(stream) if stream is not None else None
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 class PDEenv:
-    def __init__(self, setup, B=1, dtype=torch.float32, device="cuda:0", y0=None, action0=None, stream=None, history=1):
+    def __init__(self, setup, B=1, dtype=torch.float32, device="cuda:0", y0=None, action0=None, stream=None, history=1,
+                 autoreset=None):
+        """autoreset (default: B > 1): a trajectory whose blow-up flag is raised by a step restarts from its initial
+        condition IN that step (y, state, action rows <- y0, featurize(y0), action0; pdec_env_autoreset), its terminal
+        transition having been produced; the reference (B = 1) ends the whole episode instead (src/PDEenv.jl:226-240),
+        which a lock-stepped batch cannot do for one trajectory -- without the reset the blown-up trajectory would feed
+        inf/NaN states into the learner until the time-out."""
         self.setup = setup
         self.B = int(B)
         self.dtype = dtype
@@ -87,6 +109,8 @@ class PDEenv:
         self._done = torch.zeros(self.B, dtype=torch.bool, device=self.device)
         self._done_stale = False
         self.steps, self.time = 0, 0.0
+        self.autoreset = (self.B > 1) if autoreset is None else bool(autoreset)
+        self._state0 = torch.empty(self._sshape, **kw)
         self.reset()
 
     # ---- helpers
@@ -150,11 +174,24 @@ class PDEenv:
         return self.setup.action_shape
 
     def is_terminated(self):
-        """Episode end.  Time-out is common to the lock-stepped batch; a blown-up trajectory
-        (done[b]) ends the episode only when B == 1 (the reference's case)."""
+        """Episode end.  Time-out is common to the lock-stepped batch; a blown-up trajectory (done[b]) ends the episode
+        only when B == 1 (the reference's case) -- with autoreset it has already restarted from its initial condition,
+        without autoreset the batch goes on until every trajectory has blown up."""
         if self.time >= self.te:
             return True
+        if self.B > 1 and self.autoreset:
+            return False
         return bool(self.done.all().item()) if self.B > 1 else bool(self.done[0].item())
+
+    def set_y0(self, y0):
+        """new initial condition (PDEhook's PRE_EPISODE random re-initialisation, src/PDEhook.jl:42-49): env.y0, env.y,
+        env.state and the image a per-trajectory reset restores"""
+        with _on_stream(self.stream):
+            self.y0 = y0 if (isinstance(y0, torch.Tensor) and tuple(y0.shape) == self._yshape and y0.dtype == self.dtype
+                             and y0.is_contiguous()) else self._as_batch(y0, self._yshape)
+            self.y.copy_(self.y0)
+            _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(self.y), None, _lib.ptr(self._state0)))
+            self.state.copy_(self._state0)
 
     # ---- stand-alone closures (each one launch)
     def featurize(self, y=None, prev_state=None):
@@ -191,18 +228,34 @@ class PDEenv:
         _lib.check(self.lib.pdec_rhs_eval(self._h, _lib.ptr(y), _lib.ptr(p), _lib.ptr(out)))
         return out
 
+    def random_init(self, seed, offset, out=None):
+        """generate_random_init() of the 1-D setups on the device (pdec_env_random_init; scripts/KS/setup/KSSetup.jl:288-298,
+        scripts/Keller-Segel/setup/KellerSegelSetup.jl:373-384): fills `out` (default: a new tensor shaped like env.y) from
+        the Philox stream (seed, offset) and returns the number of counters consumed"""
+        out = torch.empty_like(self.y) if out is None else out
+        _lib.check(self.lib.pdec_env_random_init(self._h, int(seed), int(offset), _lib.ptr(out)))
+        self._last_random_init = out
+        nc = 8 if self.setup.y_shape == (self.setup.nx,) else 2 * int(np.ceil(self.setup.Lx / 3))
+        return self.B * ((nc + 3) // 4)
+
     # ---- reset!(env), src/PDEenv.jl:183-193
     def reset(self):
-        self.y.copy_(self.y0)
-        _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(self.y), None, _lib.ptr(self.state)))
-        self.prev_state = None
-        self.action.copy_(self.action0)
-        self._action_prev.copy_(self.action0)
-        self.p = self.prepare_action(self.action0)
-        self.steps, self.time = 0, 0.0
-        self.reward.zero_()
-        self._done.zero_()
-        self._done_stale = False
+        with _on_stream(self.stream):
+            self.y.copy_(self.y0)
+            _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(self.y), None, _lib.ptr(self.state)))
+            self._state0.copy_(self.state)
+            self.prev_state = None
+            if self.action.data_ptr() in self._adopted:      # never write into a caller-owned buffer
+                self.action = torch.empty_like(self.action0)
+            if self._action_prev.data_ptr() in self._adopted:
+                self._action_prev = torch.empty_like(self.action0)
+            self.action.copy_(self.action0)
+            self._action_prev.copy_(self.action0)
+            self.p = self.prepare_action(self.action0)
+            self.steps, self.time = 0, 0.0
+            self.reward.zero_()
+            self._done.zero_()
+            self._done_stale = False
 
     def reset_episode(self):
         """reset!(env) for a pipelined caller: like reset(), but the initial state goes into the NEXT slot of the state
@@ -212,6 +265,7 @@ class PDEenv:
         self._si = (self._si + 1) % len(self._state_ring)
         st = self._state_ring[self._si]
         _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(self.y), None, _lib.ptr(st)))
+        self._state0.copy_(st)
         self.state, self.prev_state = st, None
         if getattr(self, "_action_reset", None) is None:
             self._action_reset = self.action0.clone()
@@ -227,15 +281,17 @@ class PDEenv:
         path); the caller must then leave that buffer untouched until the step AFTER the next one has been
         issued (env.action / env.delta_action read it), e.g. by alternating two buffers."""
         if action.dtype != self.dtype or not action.is_contiguous() or tuple(action.shape) != self._ashape:
-            action = action.to(self.dtype).reshape(self._ashape).contiguous()
+            with _on_stream(self.stream):
+                action = action.to(self.dtype).reshape(self._ashape).contiguous()
             adopt = False
         if adopt:
             self._action_prev, self.action = self.action, action
         else:
             self._action_prev, self.action = self.action, self._action_prev
-            if self.action.data_ptr() == action.data_ptr() or self.action.data_ptr() in self._adopted:
-                self.action = torch.empty_like(action)     # never write into a caller-owned (adopted) buffer
-            self.action.copy_(action)
+            with _on_stream(self.stream):
+                if self.action.data_ptr() == action.data_ptr() or self.action.data_ptr() in self._adopted:
+                    self.action = torch.empty_like(action)     # never write into a caller-owned (adopted) buffer
+                self.action.copy_(action)
         if adopt:
             self._adopted.add(action.data_ptr())
         self._si = (self._si + 1) % len(self._state_ring)
@@ -251,6 +307,12 @@ class PDEenv:
         self.steps += 1
         self.time += self.dt
         self._done_stale = True
+        if self.autoreset:
+            own_action = self.action.data_ptr() not in self._adopted
+            _lib.check(self.lib.pdec_env_autoreset(
+                self._h, _lib.ptr(self._done_flags), _lib.ptr(self.y), _lib.ptr(self.y0), _lib.ptr(self.state),
+                _lib.ptr(self._state0), _lib.ptr(self.action) if own_action else None,
+                _lib.ptr(self.action0) if own_action else None, _lib.ptr(self.reward)))
 
     # ---- T control steps without returning to the host
     def rollout(self, actor, T, act_noise=0.0, act_limit=1.0, learning=False, seed=0, offset=0, log=False):
@@ -262,15 +324,16 @@ class PDEenv:
         y [T, ...], p, action, reward.  env.y / state / action / steps / time advance by T steps."""
         T = int(T)
         kw = dict(dtype=self.dtype, device=self.device)
-        out = dict(reward_sum=torch.zeros((self.B, self.setup.reward_len), **kw),
-                   done_any=torch.zeros(self.B, dtype=torch.int32, device=self.device),
-                   done_step=torch.zeros(self.B, dtype=torch.int32, device=self.device))
-        if log:
-            out.update(y=torch.empty((T,) + self._yshape, **kw), p=torch.empty((T,) + self._pshape, **kw),
-                       action=torch.empty((T,) + self._ashape, **kw),
-                       reward=torch.empty((T, self.B, self.setup.reward_len), **kw))
-        if self.action.data_ptr() in self._adopted:      # never write into a caller-owned buffer
-            self.action = self.action.clone()
+        with _on_stream(self.stream):
+            out = dict(reward_sum=torch.zeros((self.B, self.setup.reward_len), **kw),
+                       done_any=torch.zeros(self.B, dtype=torch.int32, device=self.device),
+                       done_step=torch.zeros(self.B, dtype=torch.int32, device=self.device))
+            if log:
+                out.update(y=torch.empty((T,) + self._yshape, **kw), p=torch.empty((T,) + self._pshape, **kw),
+                           action=torch.empty((T,) + self._ashape, **kw),
+                           reward=torch.empty((T, self.B, self.setup.reward_len), **kw))
+            if self.action.data_ptr() in self._adopted:      # never write into a caller-owned buffer
+                self.action = self.action.clone()
         state = self.state
         _lib.check(self.lib.pdec_rollout(
             self._h, actor.handle, T, _lib.ptr(self.y), _lib.ptr(state), _lib.ptr(self.action), float(act_noise),
@@ -279,8 +342,12 @@ class PDEenv:
             _lib.ptr(out["done_any"]), _lib.ptr(out["done_step"])))
         self.prev_state = None
         self.steps += T
-        self.time += T * self.dt
-        torch.ne(out["done_any"], 0, out=self._done)
+        for _ in range(T):                 # the same floating-point sum as T single steps (50 x 0.1 != 5.0)
+            self.time += self.dt
+        if self.time >= self.te:           # done = time >= te or blow-up (src/PDEenv.jl:227), as after a step
+            self._done.fill_(True)
+        else:
+            torch.ne(out["done_any"], 0, out=self._done)
         self._done_stale = False
         return out
 

@@ -1,6 +1,8 @@
 """PDEhook mirror (src/PDEhook.jl:8-103): reward bookkeeping, best-episode trajectory log
 (`bestDF` rows timestep/action/p/y/reward), best-actor snapshot.  For B > 1 the episode
-reward is the mean over the batch and the logged rows are those of trajectory 0."""
+reward is the mean over the batch and the logged rows are those of trajectory `log_trajectory`
+(default 0; "best" = the trajectory with the highest episode return, chosen on the device at
+the episode's end from rows logged for every trajectory)."""
 import copy
 
 import numpy as np
@@ -11,7 +13,8 @@ from .agent import (PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST
 
 class PDEhook:
     def __init__(self, min_best_episode=0, use_random_init=False, collect_history=False, collect_NNA=True,
-                 collect_bestDF=True, is_display_on_exit=False, error_detection=None, init_rng=None):
+                 collect_bestDF=True, is_display_on_exit=False, error_detection=None, init_rng=None, log_trajectory=0,
+                 init_seed=0):
         self.rewards, self.rewards_compare = [], []
         self.reward, self.ep = 0.0, 1
         self.is_display_on_exit, self.use_random_init = is_display_on_exit, use_random_init
@@ -23,14 +26,22 @@ class PDEhook:
         self.history, self.errored_episodes = [], []
         self.error_detection = error_detection or (lambda y: False)
         self.init_rng = init_rng or np.random.default_rng(0)
-        self._reward_dev, self._rows_dev = None, []
+        self.log_trajectory = log_trajectory
+        self.init_seed, self._init_off = int(init_seed), 0      # Philox stream of the device-side initialisers
+        self._reward_dev, self._rows_dev, self._ret_dev = None, [], None
 
     def _flush(self, env):
         """bring the episode's device-side accumulators to the host (one synchronisation per episode)"""
         if self._reward_dev is not None:
             self.reward += float(self._reward_dev.item())
             self._reward_dev = None
+        pick = None
+        if self.log_trajectory == "best" and self._ret_dev is not None:
+            pick = int(self._ret_dev.argmax().item())            # one scalar per episode crosses to the host
+        self._ret_dev = None
         for steps, a, p, y, r in self._rows_dev:
+            if pick is not None:
+                a, p, y, r = a[pick], p[pick], y[pick], r[pick]
             a, p, y = (t.cpu().numpy().astype(np.float64) for t in (a, p, y))
             if env.is_fluid:
                 y, p = (y[..., 0] + 1j * y[..., 1]).T, (p[..., 0] + 1j * p[..., 1]).T
@@ -47,8 +58,15 @@ class PDEhook:
                 self.bestNNA = copy.deepcopy(agent.policy.behavior_actor)
         elif stage == PRE_EPISODE_STAGE:                        # :42-49
             if self.use_random_init:
-                if hasattr(env.setup, "random_init_device"):   # initialiser kernel (row F4): no host field generation
+                # generate_random_init() as an initialiser kernel (row F4): no host field generation, no upload.
+                # Fluid: pdec_fluid_ic (the random vortex table is drawn on the host, 4 numbers per vortex);
+                # KS / Keller-Segel: pdec_env_random_init (Philox stream (init_seed, offset) on the device)
+                if getattr(env, "is_fluid", False) and hasattr(env.setup, "random_init_device"):
                     env.y0 = env.setup.random_init_device(env, self.init_rng)
+                elif not getattr(env.setup, "is_kseg2d", False) and getattr(env.setup, "device_random_init", True):
+                    y0 = env.y0 if env.y0.data_ptr() != env.y.data_ptr() else env.y0.clone()
+                    self._init_off += env.random_init(self.init_seed, self._init_off, out=y0)
+                    env.y0 = y0
                 else:
                     y0 = env.setup.generate_random_init(self.init_rng, env.B)
                     if y0.ndim == 3:
@@ -56,14 +74,21 @@ class PDEhook:
                     env.y0 = env._as_batch(y0, env._yshape)
                 env.y.copy_(env.y0)
                 env.state.copy_(env.featurize(env.y, env.state if env.setup.temporal_steps > 1 else None))
+                env._state0.copy_(env.state)      # what a per-trajectory reset (autoreset) restores
         elif stage == POST_ACT_STAGE:                           # :51-63
             # accumulated and logged ON THE DEVICE (row F4): no device->host copy or sync per control step; the host
             # values are materialised once per episode in POST_EPISODE_STAGE (send_to_host, PDEhook.jl:58-59)
             r = env.reward.mean()
             self._reward_dev = r if self._reward_dev is None else self._reward_dev + r
             if self.collect_bestDF:
-                self._rows_dev.append((env.steps, env.action[0].clone(), env.p[0].clone(), env.y[0].clone(),
-                                       env.reward[0].clone()))
+                if self.log_trajectory == "best":      # rows of every trajectory stay on the device until the episode's end
+                    rb = env.reward.mean(dim=1)
+                    self._ret_dev = rb if self._ret_dev is None else self._ret_dev + rb
+                    self._rows_dev.append((env.steps, env.action.clone(), env.p.clone(), env.y.clone(), env.reward.clone()))
+                else:
+                    b = int(self.log_trajectory)
+                    self._rows_dev.append((env.steps, env.action[b].clone(), env.p[b].clone(), env.y[b].clone(),
+                                           env.reward[b].clone()))
         elif stage == POST_EPISODE_STAGE:                       # :65-97
             self._flush(env)
             if env.time >= env.te and self.ep >= self.min_best_episode:

@@ -1,0 +1,252 @@
+"""The batched training step as a two-stream pipeline, eager or replayed from captured HIP graphs.
+
+One control step keeps the reference's stage order -- act -> update -> env step (RL.jl's run loop through
+src/PDEagent.jl:175-209, :342-418 and src/PDEenv.jl:195-241):
+
+    env stream:     fork -> act_k (actor forward + exploration noise + clamp) -> env_k (fused env step) -> join
+    update stream:  fork -> update_k (critic half, actor half: 4 launches) on the transition of step k - LAG -> join
+
+The update needs nothing of step k (DDPG is off-policy; the reference samples its minibatches from a 150k-deep replay,
+src/PDEagent.jl:317-340) and act_k reads a published copy of the actor that update_k does not write, so the two
+branches run side by side; act_{k+1} follows update_k (join), exactly as `agent(env)` follows `update!` in the run loop.
+
+Every buffer a step touches is a pure function of the step counter k (rings indexed by k mod 2 / 3 / 6) and every
+per-step scalar lives on the device (noise counter: pdec_policy_act_rng_dev; ADAM beta powers), so the launch arguments
+of step k + 6 are those of step k: six consecutive steps are captured ONCE into HIP graphs (chunks of 24 / 6 / 1 steps,
+pdec_capture_begin / _end) and replayed with one host call per chunk instead of ~12 ctypes calls per step.  The first
+and the last step of an episode (initial-condition pointers, time-out terminal flags; te / dt + 1 = 51 steps in
+scripts/KS/KS22) are issued eagerly.  Eager and replayed runs enqueue the same kernels with the same arguments and are
+bit-identical (tests/test_gpu_agent.py)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PERIOD = 6            # lcm of the ring lengths (2: y / published actor / beta-power and noise-counter slots; 3; 6)
+
+
+class TrainPipeline:
+    def __init__(self, env, agent, lag=2, episode_steps=51, stream_env=None, stream_upd=None, use_graphs=True,
+                 chunks=(24, 6, 1), use_replay=False, noise_seed=1234, reward_partials=False):
+        """env: PDEenv on `stream_env`; agent: create_agent(..., stream=stream_upd).  lag: the update of step k trains on
+        the transition of step k - lag (>= 1).  episode_steps: lock-stepped episodes of that many control steps (0: one
+        endless episode): the last transition is terminal (done = time >= te, src/PDEenv.jl:227) and the next step starts
+        from env.y0 (reset!, :183-193).  use_replay: route the update through the device-resident replay (row F1): every
+        transition is pushed (src/PDEagent.jl:254-289) and the update trains on B * A transitions drawn from it
+        (:317-340) instead of the B * A fresh ones (eager only)."""
+        self.env, self.agent, self.policy = env, agent, agent.policy
+        self.lib = env.lib
+        self.LAG = max(1, int(lag))
+        assert self.LAG in (1, 2), "rings hold the last 3 transitions: lag 1 or 2"
+        self.E = int(episode_steps)
+        self.s_env = stream_env if stream_env is not None else env.stream
+        self.s_upd = stream_upd if stream_upd is not None else self.policy.behavior_critic.model.stream
+        if self.s_env is None or self.s_upd is None:
+            raise _lib.PdecError("TrainPipeline needs explicit (non-default) streams for the environment and the networks")
+        self.serial = self.s_env.cuda_stream == self.s_upd.cuda_stream
+        self.use_replay = bool(use_replay)
+        reducer = self.policy.reducer
+        self.multi_rank = reducer is not None and reducer.world_size > 1
+        self.use_graphs = bool(use_graphs) and not self.use_replay and not self.multi_rank
+        self.chunks = tuple(sorted({int(c) for c in chunks if c == 1 or c % PERIOD == 0} | {1}, reverse=True))
+        setup, B = env.setup, env.B
+        ns, A = setup.state_shape
+        self.cols = B * A
+        self.ns, self.na = ns, setup.action_shape[0]
+        dt, dev = env.dtype, env.device
+        kw = dict(dtype=dt, device=dev)
+        with torch.cuda.stream(self.s_env):
+            self.ybuf = [torch.empty(env._yshape, **kw) for _ in range(2)]
+            self.sring = [torch.empty(env._sshape, **kw) for _ in range(PERIOD)]
+            self.aring = [torch.zeros(env._ashape, **kw) for _ in range(3)]
+            self.rring = [torch.zeros((B, setup.reward_len), **kw) for _ in range(3)]
+            self.fring = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(3)]
+            self.tring = [torch.zeros((B, setup.reward_len), **kw) for _ in range(3)]      # per-column terminal flags
+            self.pbuf = torch.zeros(env._pshape, **kw)
+            self.azero = torch.zeros(env._ashape, **kw)                                    # action0 of a fresh episode
+            self.state0 = torch.empty(env._sshape, **kw)
+        self.ev_fork = torch.cuda.Event()
+        self.ev_join = torch.cuda.Event()
+        self.tick = 0             # control steps issued so far: every buffer of step k is indexed by k mod 2 / 3 / 6
+        self.ep_start = 0         # tick of the first step of the current episode
+        self.noise_seed = int(noise_seed)
+        self.actor = self.policy.behavior_actor.model
+        self._sp_env, self._sp_upd = C.c_void_p(self.s_env.cuda_stream), C.c_void_p(self.s_upd.cuda_stream)
+        self.graphs = {}          # (chunk, pos) -> graph handle
+        self._captured = False
+        self.n_graph_launches = self.n_eager_steps = 0
+        self.reset_from(env.y0)
+
+    # ------------------------------------------------------------------ state
+    def reset_from(self, y0):
+        """(re)start: the next step is the first of an episode from initial condition y0 ([B, ...] device tensor)"""
+        env = self.env
+        with torch.cuda.stream(self.s_env):
+            if y0.data_ptr() != env.y0.data_ptr():
+                env.y0.copy_(y0)
+            _lib.check(self.lib.pdec_featurize(env.handle, _lib.ptr(env.y0), None, _lib.ptr(self.state0)))
+        self.ep_start = self.tick
+
+    @property
+    def y(self):
+        return self.ybuf[self.tick % 2]
+
+    @property
+    def state(self):
+        return self.sring[self.tick % PERIOD]
+
+    # ------------------------------------------------------------------ one step, issued call by call
+    def _issue(self, k):
+        env, pol, lib, L = self.env, self.policy, self.lib, _lib
+        first, last = self._first_last(k)
+        y_in, y_out = self.ybuf[k % 2], self.ybuf[(k + 1) % 2]
+        s_in, s_out = self.sring[k % PERIOD], self.sring[(k + 1) % PERIOD]
+        act, act_prev = self.aring[k % 3], self.aring[(k - 1) % 3]
+        rew, flags, term = self.rring[k % 3], self.fring[k % 3], self.tring[k % 3]
+        with torch.cuda.stream(self.s_env):
+            if first:                                  # reset!(env): this step starts from the initial condition
+                y_in.copy_(env.y0)
+                s_in.copy_(self.state0)
+                act_prev = self.azero
+            self.ev_fork.record(self.s_env)
+        if not self.serial:
+            self.s_upd.wait_event(self.ev_fork)
+        with torch.cuda.stream(self.s_env):
+            # actor forward on all B*A columns + exploration noise (Philox, counter on the device) + clamp: one launch
+            L.check(lib.pdec_set_stream(self.actor.handle, self._sp_env))
+            L.check(lib.pdec_policy_act_rng_dev(self.actor.handle, L.ptr(s_in), self.cols, float(pol.act_noise),
+                                                float(pol.act_limit), 1, self.noise_seed, L.ptr(act)))
+            L.check(lib.pdec_set_stream(self.actor.handle, self._sp_upd))
+            L.check(lib.pdec_env_set_terminal_out(env.handle, L.ptr(term)))
+            L.check(lib.pdec_env_step(env.handle, L.ptr(y_in), L.ptr(act), L.ptr(act_prev), L.ptr(s_in), L.ptr(y_out),
+                                      L.ptr(self.pbuf), L.ptr(s_out), L.ptr(rew), L.ptr(flags)))
+            if last:
+                term.fill_(1.0)                        # time-out: done = time >= te -> terminal transition
+            if self.use_replay:
+                self._replay_push(k, s_in, act, rew, term, s_out, first, last)
+        if self.drain_between:                         # kernel-timing pass: nothing of the env branch overlaps the update
+            torch.cuda.synchronize()
+        with torch.cuda.stream(self.s_upd):
+            j = k - self.LAG
+            if j >= self._first_tick:
+                if self.use_replay:
+                    batch = self._replay_batch()
+                else:
+                    batch = dict(state=self.sring[j % PERIOD].view(self.cols, self.ns), action=self.aring[j % 3].view(self.cols, self.na),
+                                 reward=self.rring[j % 3].view(self.cols), terminal=self.tring[j % 3].view(self.cols),
+                                 next_state=self.sring[(j + 1) % PERIOD].view(self.cols, self.ns))
+                if batch is not None:
+                    pol.update(batch)
+            self.ev_join.record(self.s_upd)
+        if not self.serial:
+            self.s_env.wait_event(self.ev_join)          # act_{k+1} follows update_k, as agent(env) follows update!
+
+    _first_tick = 0
+    drain_between = False
+
+    def _first_last(self, k):
+        """is step k the first / the last of an episode"""
+        e = k - self.ep_start
+        if self.E <= 0:
+            return e == 0, False
+        return e % self.E == 0, e % self.E == self.E - 1
+
+    # ------------------------------------------------------------------ device replay route (row F1)
+    def _replay_push(self, k, s_in, act, rew, term, s_out, first, last):
+        tr = self.agent.trajectory
+        if first and len(tr) > 0 and tr.n_sa > tr.n_rt:
+            tr.pop_sa(tr.stride)                                    # PRE_EPISODE: the dummy (s, a) of the last episode
+        tr.push_sa(s_in.view(self.cols, self.ns), act.view(self.cols, self.na))          # PRE_ACT
+        # POST_ACT: reward and the per-column terminal flags the env step (and the time-out) produced -- two
+        # one-column traces of equal capacity, pushed by the same two-trace kernel as (s, a)
+        _lib.check(self.lib.pdec_replay_push_sa(tr._h, _lib.ptr(tr.reward), _lib.ptr(tr.terminal), tr.capacity, 1, 1,
+                                                tr.n_rt % tr.capacity, _lib.ptr(rew.view(self.cols)),
+                                                _lib.ptr(term.view(self.cols)), self.cols, _lib.dtype_code(rew.dtype)))
+        tr.n_rt += self.cols
+        if last:
+            tr.push_sa(s_out.view(self.cols, self.ns), None)        # POST_EPISODE dummy
+
+    def _replay_batch(self):
+        tr, pol = self.agent.trajectory, self.policy
+        if len(tr) <= tr.stride:
+            return None
+        b = tr.sample_device(pol._sample_seed, pol._sample_off, self.cols)
+        pol._sample_off += (self.cols + 3) // 4
+        return b
+
+    # ------------------------------------------------------------------ graphs
+    def capture(self):
+        """record the chunk graphs (needs >= 3 warm-up steps behind it so that every lazily created buffer exists and
+        the update has transitions to train on); advances the run by len(chunks) periods of eager-equivalent steps"""
+        if not self.use_graphs or self._captured:
+            return
+        if self.E > 0:
+            assert self.E > 2 * PERIOD, "episodes must be longer than two graph periods"
+            self.chunks = tuple(c for c in self.chunks if c <= self.E - 2)
+        while self.tick - self.LAG < self._first_tick + 2:      # lazily created buffers / first-use uploads happen eagerly
+            self._eager()
+        for c in self.chunks:
+            for pos in (range(PERIOD) if c == 1 else (0,)):
+                while not (self.tick % PERIOD == pos and self._interior(self.tick, c)):
+                    self._eager()
+                _lib.check(self.lib.pdec_capture_begin(self.env.handle))
+                try:
+                    for i in range(c):
+                        self._issue(self.tick + i)
+                finally:
+                    h = _lib.Handle()
+                    _lib.check(self.lib.pdec_capture_end(self.env.handle, C.byref(h)))
+                self.graphs[(c, pos)] = h
+                # the capture recorded the steps without running them: replay once so that the run really advances
+                _lib.check(self.lib.pdec_graph_launch(h, self._sp_env))
+                self.tick += c
+        self._captured = True
+
+    def _interior(self, k, n):
+        """steps k .. k+n-1 are neither the first nor the last of an episode (those run eagerly)"""
+        if k - self.LAG < self._first_tick:
+            return False
+        e = k - self.ep_start
+        if self.E <= 0:
+            return e >= 1
+        e %= self.E
+        return e >= 1 and e + n <= self.E - 1
+
+    def _eager(self):
+        self._issue(self.tick)
+        self.tick += 1
+        self.n_eager_steps += 1
+
+    def run(self, n):
+        """issue n control steps (asynchronous: returns when they are enqueued)"""
+        n = int(n)
+        while n > 0:
+            k = self.tick
+            done = False
+            if self._captured:
+                for c in self.chunks:
+                    if c <= n and (c == 1 or k % PERIOD == 0) and self._interior(k, c):
+                        _lib.check(self.lib.pdec_graph_launch(self.graphs[(c, k % PERIOD)], self._sp_env))
+                        self.tick += c
+                        n -= c
+                        self.n_graph_launches += 1
+                        done = True
+                        break
+            if not done:
+                self._eager()
+                n -= 1
+
+    def step(self):
+        self.run(1)
+
+    def sync(self):
+        self.s_env.synchronize()
+        self.s_upd.synchronize()
+
+    def close(self):
+        for h in self.graphs.values():
+            self.lib.pdec_destroy(h)
+        self.graphs = {}
+        self._captured = False

@@ -254,6 +254,14 @@ int pdec_policy_act(pdec_handle actor, const void* state, const void* noise, int
  * learning = 0 -> no noise (`learning=false`, src/PDEagent.jl:199).  One launch for 3-layer fp32 actors. */
 int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
                         int learning, uint64_t seed, uint64_t offset, void* actions_out);
+/* the same with the noise counter kept ON THE DEVICE (one per actor handle): the kernel reads the current counter and
+ * one of its threads stores the advanced value (+ ceil(cols*na/4) when learning), so no launch argument depends on how
+ * many calls came before -- the form a captured HIP graph of the control step replays (pdec_capture_begin).
+ * pdec_noise_counter_set / _get move the counter (they synchronise the actor's stream). */
+int pdec_policy_act_rng_dev(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
+                            int learning, uint64_t seed, void* actions_out);
+int pdec_noise_counter_set(pdec_handle actor, uint64_t value);
+int pdec_noise_counter_get(pdec_handle actor, uint64_t* value);
 /* fill dst[n] with standard normals from a counter-based generator (replaces randn(rng),
  * src/PDEagent.jl:201) */
 int pdec_randn(pdec_handle any_handle, void* dst, size_t n, int dtype, uint64_t seed, uint64_t offset);
@@ -297,6 +305,18 @@ int pdec_ddpg_update_small(pdec_handle A, pdec_handle C, pdec_handle At, pdec_ha
                            const int32_t* idx_sn, int loops, int Bu, double gamma, double rho, int quirk,
                            double eta_actor, double eta_critic, void* losses_dev);
 
+/* the same with pde_sample (src/PDEagent.jl:317-321) INSIDE the kernel: draw k = loop * Bu + column is word k % 4 of the
+ * Philox block (seed; counter offset + k / 4), ind = (word * (n_valid - stride)) >> 32, logical index
+ * max(0, n_rt - capacity) + ind, slots (lg mod (capacity + stride), lg mod capacity, (lg + stride) mod (capacity + stride)).
+ * n_valid = length(trajectory) = min(n_rt, capacity), n_rt = entries ever pushed to the reward / terminal traces,
+ * stride = number of columns one control step pushes (number_actuators x batch).  The host passes a seed and an
+ * offset, no index arrays. */
+int pdec_ddpg_update_small_rng(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
+                               const void* state_trace, const void* action_trace, const void* reward_trace,
+                               const void* terminal_trace, int loops, int Bu, uint64_t seed, uint64_t offset,
+                               int64_t n_valid, int64_t n_rt, int64_t capacity, int stride, double gamma, double rho,
+                               int quirk, double eta_actor, double eta_critic, void* losses_dev);
+
 /* the two halves of pdec_ddpg_update_async as separate calls (critic half: critic pass + ADAM(C) + Polyak(Ct);
  * actor half: actor pass with the updated critic + ADAM(A) + Polyak(At)), so that a caller can order the
  * actor half behind a concurrent reader of the actor's weights on another stream.  losses_dev as above. */
@@ -305,6 +325,50 @@ int pdec_ddpg_update_critic_async(pdec_handle A, pdec_handle C, pdec_handle At, 
                                   int Bu, double gamma, double rho, int quirk, double eta_critic, void* losses_dev);
 int pdec_ddpg_update_actor_async(pdec_handle A, pdec_handle C, pdec_handle At, pdec_handle Ct,
                                  const void* s, int Bu, double rho, double eta_actor, void* losses_dev);
+
+/* ---------------------------------------------------------------- replay ---- */
+/* The trajectory glue of src/PDEagent.jl:237-340 on device-resident traces (fp32, as RL.jl keeps them, :112-117):
+ * state [capacity + stride][ns], action [capacity + stride][na], reward [capacity], terminal [capacity].  The host
+ * keeps only the two entry counters (pop of the dummy (s, a) of an episode end, :237-252, is a counter decrement).
+ * PRE_ACT push of one (s, a) column per actuator (:254-274): rows start .. start+n-1 (mod capacity_rows) of both traces
+ * from s [n][ns], a [n][na] of `dtype`; a == NULL pushes zero actions (the POST_EPISODE dummy, :291-314).  One launch. */
+int pdec_replay_push_sa(pdec_handle any_handle, void* state_trace, void* action_trace, int64_t capacity_rows, int ns, int na,
+                        int64_t start, const void* s, const void* a, int64_t n, int dtype);
+/* POST_ACT push of (r, terminal) (:276-289): r [n] of `dtype`; terminal of column i = done_flags[i / cols_per_traj] != 0
+ * (the env step's per-trajectory flags), or 1 everywhere when force_terminal (time-out, src/PDEenv.jl:227).  One launch. */
+int pdec_replay_push_rt(pdec_handle any_handle, void* reward_trace, void* terminal_trace, int64_t capacity_rows, int64_t start,
+                        const void* r, const int32_t* done_flags, int cols_per_traj, int force_terminal, int64_t n, int dtype);
+/* pde_sample + pde_fetch! (:317-340) for a batch of Bu transitions in one launch: indices from the Philox stream
+ * (seed, offset) exactly as pdec_ddpg_update_small_rng draws them; outputs fp32 s, sn [Bu][ns], a [Bu][na], r, t [Bu];
+ * slots_out (optional) int32 [3][Bu] = the slots used. */
+int pdec_replay_sample(pdec_handle any_handle, const void* state_trace, const void* action_trace, const void* reward_trace,
+                       const void* terminal_trace, int ns, int na, int64_t capacity, int stride, int64_t n_valid, int64_t n_rt,
+                       uint64_t seed, uint64_t offset, int Bu, void* s_out, void* a_out, void* r_out, void* t_out,
+                       void* sn_out, int32_t* slots_out);
+
+/* Batched environments (B > 1; the reference has B = 1 and ends the episode at the first blow-up, src/PDEenv.jl:226-240):
+ * same-step reset of every trajectory whose done flag is raised -- y, state and action rows are overwritten by their
+ * initial images (reset!, :183-193), a non-finite reward becomes 0 -- so that a blown-up trajectory cannot feed inf/NaN
+ * states into the learner for the rest of the lock-stepped episode.  state/state0, action/action0, reward may be NULL. */
+int pdec_env_autoreset(pdec_handle env, const int32_t* done, void* y, const void* y0, void* state, const void* state0,
+                       void* action, const void* action0, void* reward);
+/* generate_random_init() of the 1-D setups (scripts/KS/setup/KSSetup.jl:288-298,
+ * scripts/Keller-Segel/setup/KellerSegelSetup.jl:373-384) on the device, one workgroup per trajectory: y0_out [B][...] in
+ * the environment's layout and dtype; uniforms from the Philox stream (seed, offset) (Julia's global RNG cannot be
+ * reproduced, only the distribution; oracle/rng.py restates this stream).  Consumes B * ceil(n_coefficients / 4) counters. */
+int pdec_env_random_init(pdec_handle env, uint64_t seed, uint64_t offset, void* y0_out);
+
+/* ---------------------------------------------------------------- HIP graphs -- */
+/* Record everything enqueued on the stream of `origin` (pdec_set_stream; not the null stream) -- library calls, and any
+ * other stream that forks from it and joins it again through events -- between _begin and _end into one HIP graph;
+ * pdec_graph_launch replays it with one host call.  Calls that keep their per-step state on the device
+ * (pdec_policy_act_rng_dev, every ADAM step) replay correctly; the double-buffered state they flip on the host returns
+ * to its captured value after an EVEN number of calls, so capture a period with an even number of control steps.
+ * The graph handle is released with pdec_destroy. */
+int pdec_capture_begin(pdec_handle origin);
+int pdec_capture_end(pdec_handle origin, pdec_handle* graph);
+int pdec_graph_launch(pdec_handle graph, void* hip_stream);      /* NULL = the stream it was captured on */
+int pdec_graph_num_nodes(pdec_handle graph, int* n);
 
 /* ---------------------------------------------------------------- multi-GPU ---------- */
 /* One RCCL communicator per process (one process per GPU).  unique_id: 128 bytes from

@@ -219,3 +219,323 @@ def test_testrun_helper_equals_policy_rollout(pkg):
     assert torch.allclose(out["reward_sum"], total, rtol=0, atol=1e-12)
     assert torch.allclose(env.y, ref.y, rtol=0, atol=1e-12)
     assert out["episode_reward"].shape == (2,) and out["y"].shape[0] == 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: per-trajectory reset, device-side replay (row F1), initialiser kernels (F4), graph replay (F2), closed loops
+def test_blown_up_trajectory_does_not_poison_the_learner(pkg):
+    """B > 1: one trajectory is pushed past max_value.  The step raises its flag, pushes ONE terminal transition and
+    restarts that trajectory from its initial condition in the same step (pdec_env_autoreset); every state that
+    reaches the replay stays finite and so do all four networks after the following updates."""
+    setup = pkg.KSSetup.KS22()
+    B = 4
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float64)
+    assert env.autoreset
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), trajectory_length=4000, start_steps=-1,
+                             update_after=1)
+    hook = pkg.PDEhook(collect_bestDF=False)
+    stages = pkg.agent
+    env.reset()
+    agent(stages.PRE_EPISODE_STAGE, env)
+    y0, s0 = env.y0.clone(), env.state.clone()
+    for k in range(8):
+        if k == 2:
+            env.y[2] += 1e6                      # far beyond max_value = 30: the next step blows this trajectory up
+        a = agent(env)
+        agent(stages.PRE_ACT_STAGE, env, a)
+        env(a)
+        agent(stages.POST_ACT_STAGE, env)
+        hook(stages.POST_ACT_STAGE, agent, env)
+        flags = env._done_flags.cpu().numpy()
+        if k == 2:
+            assert flags.tolist() == [0, 0, 1, 0]
+            assert torch.equal(env.y[2], y0[2]) and torch.equal(env.state[2], s0[2])       # restarted in the same step
+            assert not torch.equal(env.y[1], y0[1])
+        else:
+            assert flags.sum() == 0
+        assert bool(torch.isfinite(env.y).all()) and bool(torch.isfinite(env.state).all()) and bool(torch.isfinite(env.reward).all())
+        assert not env.is_terminated()
+    tr = agent.trajectory
+    n = len(tr)
+    assert bool(torch.isfinite(tr.state[:n + tr.stride]).all()) and bool(torch.isfinite(tr.reward[:n]).all())
+    term = tr.terminal[:n].view(-1, B, 8)
+    assert term[2, 2].eq(1).all() and int(term.sum()) == 8          # exactly one terminal transition per actuator
+    for nna in (agent.policy.behavior_actor, agent.policy.behavior_critic, agent.policy.target_actor, agent.policy.target_critic):
+        assert all(np.isfinite(p).all() for p in nna.params())
+    hook._flush(env)
+    assert np.isfinite(hook.reward)
+
+
+def test_device_replay_rebuilds_the_reference_buffer_and_rewards(pkg):
+    """GPU half of tests/test_replay_golden.py (A17 + A22 + F1): the stage kernels (pdec_replay_push_sa / _push_rt) fed with
+    the reference's own stream of states / actions / rewards rebuild the head of its saved replay buffer bit for bit,
+    pdec_replay_sample fetches s' at +A, and pdec_reward on a field with the stored next-state sensors returns the
+    stored reward (Float32 traces: <= 1e-6)."""
+    from test_replay_golden import replay_head, ks22_cfg, field_with_sensors, transitions, A, EP
+    s, a, r, t = replay_head()
+    n_ep = len(r) // EP
+    dev = torch.device("cuda:0")
+    setup = pkg.KSSetup.KS22()
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), trajectory_length=150000)
+    agent._maybe_update = lambda: None
+    tr = agent.trajectory
+    assert tr._h is not None and tr.capacity == 150000 and tr.stride == A
+
+    class Env:
+        B, te, _ashape = 1, 5.0, (1, A, 1)
+    env = Env()
+    st = pkg.agent
+    for e in range(n_ep):
+        agent(st.PRE_EPISODE_STAGE, env)
+        for k in range(51):
+            i = e * EP + k * A
+            env.state = torch.as_tensor(s[i:i + A], device=dev).reshape(1, A, 1).double()      # fp64 env state -> fp32 trace
+            agent(st.PRE_ACT_STAGE, env, torch.as_tensor(a[i:i + A], device=dev).reshape(1, A, 1).double())
+            env.reward = torch.as_tensor(r[i:i + A], device=dev).reshape(1, A).double()
+            env._done_flags = torch.zeros(1, dtype=torch.int32, device=dev)
+            env.time = 5.1 if k == 50 else 0.1 * (k + 1)                                       # time-out on step 51
+            agent(st.POST_ACT_STAGE, env)
+        env.state = torch.full((1, A, 1), 123.0, device=dev, dtype=torch.float64)
+        agent(st.POST_EPISODE_STAGE, env)
+    torch.cuda.synchronize()
+    n = n_ep * EP
+    assert len(tr) == n and tr.n_sa == n + A
+    assert np.array_equal(tr.state[:n, 0].cpu().numpy(), s[:n]) and np.array_equal(tr.action[:n, 0].cpu().numpy(), a[:n])
+    assert np.array_equal(tr.reward[:n].cpu().numpy(), r[:n]) and np.array_equal(tr.terminal[:n].cpu().numpy(), t[:n])
+    # pde_sample / pde_fetch! on the device against the oracle's restatement of the same counter stream
+    from oracle import rng as orng
+    b = tr.sample_device(77, 5, 512)
+    sl = orng.sample_slots(77, 5, 512, len(tr), tr.n_rt, tr.capacity, tr.stride)
+    assert np.array_equal(b["state"][:, 0].cpu().numpy(), s[sl[0]]) and np.array_equal(b["next_state"][:, 0].cpu().numpy(), s[sl[0] + A])
+    assert np.array_equal(b["reward"].cpu().numpy(), r[sl[1]]) and np.array_equal(b["terminal"].cpu().numpy(), t[sl[1]])
+    assert np.array_equal(b["action"][:, 0].cpu().numpy(), a[sl[0]]) and sl[0].max() < n - A
+    # reward_function / featurize kernels against the stored rewards
+    cfg = ks22_cfg()
+    rows = transitions()
+    Bq = len(rows)
+    penv = pkg.PDEenv(setup, B=Bq, dtype=torch.float64, autoreset=False)
+    y = np.stack([field_with_sensors(cfg, sn) for _, sn, _, _, _ in rows])
+    act = np.stack([x[2] for x in rows]).astype(np.float64)
+    actp = np.stack([x[3] for x in rows]).astype(np.float64)
+    yd = torch.as_tensor(y, device=dev)
+    got_s = penv.featurize(yd).cpu().numpy()[:, :, 0]
+    assert np.abs(got_s - np.stack([x[1] for x in rows])).max() <= 1e-12
+    got_r = penv.reward_function(yd, torch.as_tensor(act, device=dev).reshape(penv._ashape),
+                                 torch.as_tensor(actp, device=dev).reshape(penv._ashape)).cpu().numpy()
+    assert np.abs(got_r - np.stack([x[4] for x in rows])).max() <= 1e-6
+
+
+def test_in_kernel_sampling_equals_host_slots_from_the_same_stream(pkg):
+    """pdec_ddpg_update_small_rng (pde_sample inside the kernel, the host passes seed + offset) == pdec_ddpg_update_small
+    fed with the slots the oracle derives from the same Philox stream: identical parameters after 20 x 3 updates, for
+    the register-resident 2-layer kernel (KS22 shapes) and the generic one (3-layer nets), incl. a wrapped buffer"""
+    from oracle import rng as orng
+    for setup, kw in ((pkg.KSSetup.KS22(), {}), (pkg.KSSetup.bench_C2(256), {})):
+        ns, A = setup.state_shape
+        agents = [pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=320) for _ in range(2)]
+        g = torch.Generator().manual_seed(3)
+        for ag in agents:
+            tr = ag.trajectory
+            g.manual_seed(3)
+            for step in range(55):                       # 55 steps into a 320-column buffer (40 / 5 steps): wraps
+                tr.push_sa(torch.randn(A, ns, generator=g).cuda(), (torch.rand(A, 1, generator=g) * 2 - 1).cuda())
+                tr.push_rt(-torch.rand(A, generator=g).cuda(), (torch.rand(A, generator=g) < 0.1).float().cuda())
+            tr.push_sa(torch.randn(A, ns, generator=g).cuda(), None)
+        p0, p1 = agents[0].policy, agents[1].policy
+        tr = agents[0].trajectory
+        assert tr.n_rt > tr.capacity
+        p0._sample_seed, p0._sample_off = 4242, 17
+        p0.update_small_rng(tr)
+        slots = orng.sample_slots(4242, 17, p1.update_loops * p1.batch_size, len(tr), tr.n_rt, tr.capacity, tr.stride)
+        p1.update_small(agents[1].trajectory, slots.reshape(3, p1.update_loops, p1.batch_size))
+        torch.cuda.synchronize()
+        assert p0._sample_off == 17 + (p1.update_loops * p1.batch_size + 3) // 4
+        for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+            for x, y in zip(getattr(p0, n).model.params(), getattr(p1, n).model.params()):
+                assert np.array_equal(x, y), n
+        assert p0.losses() == p1.losses()
+
+
+def test_random_init_kernels_match_the_oracle_stream(pkg):
+    """pdec_env_random_init (generate_random_init of KSSetup.jl:288-298 / KellerSegelSetup.jl:373-384 as a kernel) against
+    the oracle's formulas evaluated with the coefficients of the same Philox stream (oracle/rng.py)"""
+    from oracle import rng as orng
+    B = 5
+    setup = pkg.KSSetup.KS22()
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float64)
+    y = torch.empty_like(env.y)
+    used = env.random_init(11, 3, out=y)
+    assert used == B * 2
+    a = orng.random_init_coefficients(11, 3, B, 8)
+    xx = setup.dx * np.arange(1, setup.nx + 1)
+    ref = sum(a[:, i - 1:i] * np.sin(i * xx / (2 * np.pi))[None] for i in range(1, 9))
+    ref = ref * 30 / np.linalg.norm(ref, axis=1, keepdims=True)
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-12 and abs(np.linalg.norm(ref[0]) - 30) < 1e-12
+    ks = pkg.KellerSegelSetup()
+    env2 = pkg.PDEenv(ks, B=B, dtype=torch.float32)
+    y2 = torch.empty_like(env2.y)
+    nsin = int(np.ceil(ks.Lx / 3))
+    assert env2.random_init(9, 0, out=y2) == B * ((2 * nsin + 3) // 4)
+    a = orng.random_init_coefficients(9, 0, B, 2 * nsin)
+    xx = ks.dx * np.arange(1, ks.nx + 1)
+    ref = np.ones((B, ks.nx, 2))
+    for i in range(1, nsin + 1):
+        sn = np.sin(i * xx / (2 * np.pi * (ks.Lx / 22)))
+        ref[:, :, 0] += a[:, i - 1:i] * sn[None]
+        ref[:, :, 1] += a[:, nsin + i - 1:nsin + i] * sn[None]
+    assert np.abs(y2.cpu().numpy() - ref).max() <= 3e-7
+    # PDEhook's PRE_EPISODE re-initialisation uses the kernel and keeps env.y0 / y / state consistent
+    hook = pkg.PDEhook(use_random_init=True, init_seed=5)
+    hook(pkg.agent.PRE_EPISODE_STAGE, None, env)
+    from oracle import ks as oks
+    cfg = oks.KSConfig(192, 22.0, np.arange(1, 193, 24), sigma_sensors=0.7, sigma_actuators=0.7)
+    assert torch.equal(env.y, env.y0) and abs(float(env.y[0].norm()) - 30) < 1e-9
+    assert np.abs(env.state[1].cpu().numpy().T - oks.featurize(cfg, env.y[1].cpu().numpy())).max() <= 1e-12
+
+
+def _make_pipeline(pkg, use_graphs, B=64, E=17, lag=2, two_layer=False):
+    setup = pkg.KSSetup.bench_C2(256, drop_middle_layer=True) if two_layer else pkg.KSSetup.bench_C2(256)
+    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+    y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
+                             noise_seed=7, trajectory_length=1)
+    agent.policy.act_noise = 0.3
+    torch.cuda.synchronize()
+    return pkg.TrainPipeline(env, agent, lag=lag, episode_steps=E, stream_env=s_env, stream_upd=s_upd, use_graphs=use_graphs,
+                             chunks=(6, 1), noise_seed=99)
+
+
+@pytest.mark.parametrize("lag,two_layer", [(2, False), (1, False), (2, True)])
+def test_graph_replay_is_bit_identical_to_the_eager_pipeline(pkg, lag, two_layer):
+    """row F2: the two-stream control step replayed from captured HIP graphs (chunks of 6 and 1 steps, first / last step
+    of each 17-step episode eager) against the same pipeline issued call by call: identical PDE states, actions and
+    all four networks after 60 steps, i.e. across episode boundaries, partial chunks and both slot parities"""
+    pe = _make_pipeline(pkg, False, lag=lag, two_layer=two_layer)
+    pg = _make_pipeline(pkg, True, lag=lag, two_layer=two_layer)
+    pg.run(5)
+    pg.capture()
+    n0 = pg.tick
+    pe.run(n0)
+    for n in (1, 7, 20, 32):
+        pe.run(n)
+        pg.run(n)
+    pe.sync(); pg.sync()
+    assert pe.tick == pg.tick and pg.n_graph_launches > 0 and len(pg.graphs) == 7
+    assert torch.equal(pe.y, pg.y) and torch.equal(pe.state, pg.state)
+    for k in range(3):
+        assert torch.equal(pe.aring[k], pg.aring[k]) and torch.equal(pe.rring[k], pg.rring[k]) and torch.equal(pe.tring[k], pg.tring[k])
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        for x, y in zip(getattr(pe.policy, n).model.params(), getattr(pg.policy, n).model.params()):
+            assert np.array_equal(x, y), n
+    assert bool(torch.isfinite(pg.y).all()) and pe.policy.losses() == pg.policy.losses()
+    import ctypes as C
+    nn_ = C.c_int()
+    pkg._lib.check(pg.lib.pdec_graph_num_nodes(pg.graphs[(6, 0)], C.byref(nn_)))
+    assert nn_.value >= 6 * 6            # act, env step and the four update launches of each of the six steps
+    pg.close()
+
+
+def test_pipeline_step_matches_the_oracle_rollout(pkg):
+    """the pipelined step against the ORACLE (src/PDEagent.jl:175-209 + src/PDEenv.jl:195-241): with exploration noise
+    and learning rates at zero the networks stay fixed, and 12 replayed control steps from the oracle's initial states
+    must follow the oracle's closed loop (actor forward -> clamp -> prepare_action -> CNAB2 -> reward -> featurize),
+    fp32 <= 2e-5 per step on y (teacher-forced comparison: the oracle restarts every step from the device state)"""
+    from oracle import ks, nn
+    pg = _make_pipeline(pkg, True, B=6, E=0)
+    pol = pg.policy
+    pol.act_noise = 0.0
+    for nna in (pol.behavior_actor, pol.behavior_critic):
+        nna.optimizer.eta = 0.0
+    setup = pg.env.setup
+    cfg = ks.KSConfig(256, setup.Lx, setup.sensor_positions, sigma_sensors=1.0, sigma_actuators=1.0, window_size=3)
+    P = [p.astype(np.float64) for p in pol.behavior_actor.params()]
+    acts = [nn.RELU, nn.RELU, nn.TANH]
+    pg.run(4)
+    pg.capture()
+    for _ in range(12):
+        pg.sync()
+        k = pg.tick
+        y = pg.y.cpu().numpy().astype(np.float64)
+        a_prev = pg.aring[(k - 1) % 3].cpu().numpy().astype(np.float64)[:, :, 0]
+        pg.run(1)
+        pg.sync()
+        y1 = pg.y.cpu().numpy()
+        a1 = pg.aring[k % 3].cpu().numpy()[:, :, 0]
+        for b in range(6):
+            a = np.clip(nn.forward(P, acts, ks.featurize(cfg, y[b])), -1, 1)
+            assert np.abs(a1[b] - a[0]).max() <= 2e-5
+            o = ks.env_step(cfg, y[b], a_prev[b][None], a1[b][None].astype(np.float64), 0.0)
+            assert np.abs(y1[b] - o["y"]).max() <= 2e-5
+            assert np.abs(pg.rring[k % 3][b].cpu().numpy() - o["reward"]).max() <= 1e-5
+            assert np.abs(pg.state[b].cpu().numpy().T - o["state"]).max() <= 1e-5
+    assert pg.n_graph_launches >= 12
+    pg.close()
+
+
+def test_rollout_follows_the_oracle_closed_loop(pkg):
+    """pdec_rollout (T steps in one call) against an ORACLE rollout, not against the per-step HIP loop: the reference-trained
+    KS22 actor (hook.bestNNA), noise-free, 50 control steps from the golden initial state in fp64 -- every logged row
+    (y, p, action, reward) equals the oracle's closed loop to 1e-8, and so does the return"""
+    from oracle import ks, nn
+    from util import ks_pair
+    setup, cfg, g = ks_pair(pkg, "ks22")
+    env = pkg.PDEenv(setup, B=2, dtype=torch.float64, y0=np.stack([g["y"][0], g["y"][7]]), autoreset=False)
+    best = [g["best_W1"], g["best_b1"], g["best_W2"], g["best_b2"]]
+    actor = pkg.HipMLP([1, 6, 1], ["relu", "tanh"], best, dtype=torch.float64, max_cols=16)
+    out = env.rollout(actor, 50, learning=False, log=True)
+    torch.cuda.synchronize()
+    P = [b.astype(np.float64) for b in best]
+    for b, row in enumerate((0, 7)):
+        y, a_prev, ret = g["y"][row].copy(), np.zeros((1, 8)), 0.0
+        for k in range(50):
+            a = np.clip(nn.forward(P, [nn.RELU, nn.TANH], ks.featurize(cfg, y)), -1, 1)
+            o = ks.env_step(cfg, y, a_prev, a, 0.0)
+            y, a_prev = o["y"], a
+            ret += o["reward"].mean()
+            assert np.abs(out["action"][k, b, :, 0].cpu().numpy() - a[0]).max() <= 1e-9
+            assert np.abs(out["y"][k, b].cpu().numpy() - y).max() <= 1e-8
+            assert np.abs(out["p"][k, b].cpu().numpy() - o["p"]).max() <= 1e-9
+            assert np.abs(out["reward"][k, b].cpu().numpy() - o["reward"]).max() <= 1e-9
+        assert abs(float(out["reward_sum"][b].mean()) - ret) <= 1e-8
+
+
+def test_reference_trained_keller_segel_actor_closed_loop(pkg):
+    """row F3: the actor the reference trained for Keller-Segel10_16 (hook.bestNNA 12 -> 20 -> 1, fixture from
+    scripts/Keller-Segel/Keller-Segel10_16/saves/hook.jld2) driven closed-loop on this path from a golden state: 30
+    control steps of policy -> (env)(action) with the temporal state stack (KellerSegelSetup.jl:265-316) follow the
+    oracle's loop (fixed 32 RK4 sub-steps on both sides) to 1e-9, per-step and as a device-side rollout"""
+    from oracle import keller_segel as kg, nn
+    from util import load_golden
+    g = load_golden("kseg_hook.npz")
+    setup, cfg = pkg.KellerSegelSetup(), kg.KSegConfig()
+    best = [g["best_W1"], g["best_b1"], g["best_W2"], g["best_b2"]]
+    y0 = g["y_t"][3]
+    mem = np.ascontiguousarray(np.swapaxes(y0, 0, 1))[None]
+    env = pkg.PDEenv(setup, B=1, dtype=torch.float64, y0=mem)
+    env2 = pkg.PDEenv(setup, B=1, dtype=torch.float64, y0=mem)
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), dtype=torch.float32)
+    pkg.checkpoint.load_actor(agent.policy.behavior_actor, best)
+    agent.policy.start_steps = -1
+    P = [b.astype(np.float64) for b in best]
+    y, state, a_prev, rets = y0.copy(), kg.featurize(cfg, y0, None), np.zeros((1, 16)), []
+    assert np.abs(env.state[0].cpu().numpy().T - state).max() <= 1e-13
+    T = 30
+    for k in range(T):
+        a = np.clip(nn.forward(P, [nn.RELU, nn.TANH], state), -1, 1)
+        p = kg.prepare_action(cfg, a)
+        y = kg.do_step(cfg, y, p, 32)
+        r = kg.reward_function(cfg, y, a, a - a_prev)
+        state, a_prev = kg.featurize(cfg, y, state), a
+        rets.append(r)
+        act = agent.policy(env, learning=False)
+        env(act)
+        assert np.abs(env.action_julia() - a).max() <= 1e-9
+        assert np.abs(env.y_julia() - y).max() <= 1e-9
+        assert np.abs(env.reward[0].cpu().numpy() - r).max() <= 1e-9
+        assert np.abs(env.state[0].cpu().numpy().T - state).max() <= 1e-9
+    actor64 = agent.policy._actor_for(torch.float64, 16)
+    out = env2.rollout(actor64, T, learning=False, log=True)
+    torch.cuda.synchronize()
+    assert np.abs(out["reward"][:, 0].cpu().numpy() - np.stack(rets)).max() <= 1e-9
+    assert np.abs(np.swapaxes(env2.y[0].cpu().numpy(), 0, 1) - y).max() <= 1e-9

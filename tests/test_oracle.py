@@ -238,3 +238,19 @@ def test_kseg2d_oracle_reduces_to_pinned_1d():
     out = k2.do_step(c, y, p)
     outT = k2.do_step(c, np.swapaxes(y, 1, 2), p.T)
     assert np.abs(np.swapaxes(outT, 1, 2) - out).max() <= 1e-13
+
+
+def test_philox_stream_known_answer_and_derived_draws():
+    """oracle/rng.py (the counter stream that replaces Julia's RNGs on the device): Philox4x32-10 known answer of the
+    Random123 distribution (counter 0, key 0), and the derived draws -- uniform slot indices stay inside
+    [0, n_valid - stride) with s' one stride further, normals have unit variance"""
+    from oracle import rng
+    w = rng.philox4x32(np.array([0], dtype=np.uint64), 0)[0]
+    assert [int(x) for x in w] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert np.array_equal(rng.words(3, 10, 7), rng.philox4x32(np.array([10, 11], dtype=np.uint64), 3).reshape(-1)[:7])
+    sl = rng.sample_slots(5, 0, 4000, n_valid=800, n_rt=2000, capacity=800, stride=8)
+    lg = (sl[1] - (2000 - 800) % 800) % 800          # position relative to the oldest entry
+    assert lg.min() >= 0 and lg.max() < 800 - 8 and np.array_equal(sl[2], (sl[0] + 8) % 808)
+    assert len(np.unique(lg)) > 700
+    z = rng.randn(1, 0, 200000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
