@@ -81,6 +81,7 @@ SIGNATURES = {
     "pdec_randn": [Handle, _vp, _sz, _i, _u64, _u64],
     "pdec_policy_act_rng_dev": [Handle, _vp, _i, _d, _d, _i, _u64, _vp],
     "pdec_noise_counter_set": [Handle, _u64], "pdec_noise_counter_get": [Handle, C.POINTER(_u64)],
+    "pdec_reward_mean": [Handle, _vp, _i, _vp], "pdec_ddpg_set_reward_mean": [Handle, _vp],
     "pdec_ddpg_update_small_rng": [Handle] * 4 + [_vp] * 4 + [_i, _i, _u64, _u64, _i64, _i64, _i64, _i, _d, _d, _i, _d, _d, _vp],
     "pdec_replay_push_sa": [Handle, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _i64, _i],
     "pdec_replay_push_rt": [Handle, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i64, _i],
@@ -89,6 +90,7 @@ SIGNATURES = {
     "pdec_env_random_init": [Handle, _u64, _u64, _vp],
     "pdec_capture_begin": [Handle], "pdec_capture_end": [Handle, C.POINTER(Handle)],
     "pdec_graph_launch": [Handle, _vp], "pdec_graph_num_nodes": [Handle, C.POINTER(_i)],
+    "pdec_event_create": [C.POINTER(Handle)], "pdec_event_record": [Handle, _vp], "pdec_stream_wait_event": [_vp, Handle],
     "pdec_ddpg_critic_grads": [Handle] * 4 + [_vp] * 5 + [_i, _d, _i, _d, _vp],
     "pdec_ddpg_actor_grads": [Handle, Handle, _vp, _i, _d, _vp],
     "pdec_ddpg_update": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _pd, _pd],

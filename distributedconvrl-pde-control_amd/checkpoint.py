@@ -7,7 +7,12 @@
 * `load_actor(nna_or_model, params)`: `copyto!(actor, hook.bestNNA)` (src/plotting.jl:29).
 * `save_agent` / `load_agent`: native `.npz` checkpoint of the four networks plus their ADAM state
   (moments and beta powers), i.e. what `FileIO.save(".../agent.jld2", "agent", agent)` keeps of the
-  learner; writing JLD2 itself is not provided (the reference's `load()` would need Julia types)."""
+  learner.
+* `save_agent_jld2` / `save_actor_jld2`: the same arrays as plain datasets in a JLD2 container (jld2.write_arrays), which
+  JLD2.jl reads back as ordinary Julia arrays; julia/load_agent_arrays.jl rebuilds the Flux chains and ADAM states from
+  them, so a build-trained agent reaches the reference's `load()` / `plot_heat` path (scripts/KS/setup/KSSetup.jl:378-402,
+  src/plotting.jl:26-31).  (The reference's own files serialise whole Julia structs -- `Agent`, `PDEhook` with their
+  committed datatypes; reproducing that type graph without Julia is out of reach, plain arrays are the interchange form.)"""
 import numpy as np
 
 from . import _lib
@@ -119,3 +124,37 @@ def load_agent(path, agent):
             getattr(tr, name)[:a.shape[0]].copy_(a)
         tr.n_sa, tr.n_rt = n_sa, n_rt
     return agent
+
+
+def _net_arrays(prefix, model, with_adam=True):
+    """{name: array} of one network in Julia shapes: `<prefix>_W1` [out, in], `<prefix>_b1`, ... (+ ADAM moments)"""
+    out = {}
+    params = model.params()
+    for li in range(len(params) // 2):
+        out[f"{prefix}_W{li + 1}"] = np.asarray(params[2 * li], dtype=np.float32)
+        out[f"{prefix}_b{li + 1}"] = np.asarray(params[2 * li + 1], dtype=np.float32)
+    if with_adam:
+        m, v, bp = _adam_state(model)
+        out[f"{prefix}_adam_m"], out[f"{prefix}_adam_v"] = m.astype(np.float32), v.astype(np.float32)
+        out[f"{prefix}_adam_beta_pow"] = np.asarray(bp, dtype=np.float64)
+    out[f"{prefix}_dims"] = np.asarray(model.dims, dtype=np.int64)
+    out[f"{prefix}_acts"] = np.asarray(model.acts, dtype=np.int64)        # 0 identity, 1 relu, 2 tanh
+    return out
+
+
+def save_agent_jld2(path, agent):
+    """the four networks + ADAM states of `agent` as plain arrays in a JLD2 file (see the module docstring)"""
+    from .jld2 import write_arrays
+    p = agent.policy
+    arrays = {}
+    for name in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        arrays.update(_net_arrays(name, getattr(p, name).model))
+    arrays["hyper"] = np.array([p.y, p.p, p.act_limit, p.act_noise, p.behavior_actor.optimizer.eta,
+                                p.behavior_critic.optimizer.eta], dtype=np.float64)
+    write_arrays(path, arrays)
+
+
+def save_actor_jld2(path, nna, name="bestNNA"):
+    """one actor (e.g. PDEhook.bestNNA, src/PDEhook.jl:68-75) as `<name>_W1`, `<name>_b1`, ..."""
+    from .jld2 import write_arrays
+    write_arrays(path, _net_arrays(name, getattr(nna, "model", nna), with_adam=False))

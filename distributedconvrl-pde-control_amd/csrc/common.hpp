@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -36,7 +37,7 @@ void set_error(const char* fmt, ...);
     }                                  \
   } while (0)
 
-enum class Kind { Env, Mlp, Comm, Graph };
+enum class Kind { Env, Mlp, Comm, Graph, Event };
 
 struct ProfEntry {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -79,6 +80,16 @@ struct ProfScope {
   }
 };
 
+// Host-side slot selectors of double-buffered device state (ADAM beta powers, noise counter, published actor image)
+// flip once per launch that uses them.  A launch recorded into a HIP graph flips them at CAPTURE time only, so a
+// replay has to repeat the flips: while a capture is open every flip is logged, and pdec_graph_launch re-applies the
+// ones that occurred an odd number of times.
+void note_flip(int* selector);
+inline void flip(int& selector) {
+  selector ^= 1;
+  note_flip(&selector);
+}
+
 pdec_handle register_object(std::unique_ptr<Object> o);
 Object* lookup(pdec_handle h);
 template <class T>
@@ -86,6 +97,19 @@ T* lookup_as(pdec_handle h, Kind k) {
   Object* o = lookup(h);
   if (!o || o->kind != k) return nullptr;
   return static_cast<T*>(o);
+}
+
+// wave priority from a launch argument (s_setprio takes an immediate)
+__device__ __forceinline__ void set_wave_prio(int p) {
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 3) __builtin_amdgcn_s_setprio(3);
+}
+// wave priorities, overridable for experiments: PDEC_PRIO_KS (KS env-step kernel, default 1), PDEC_PRIO_MFMA (fused
+// 3-layer DDPG passes, default 2)
+inline int env_prio(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : dflt;
 }
 
 inline size_t dtype_size(int dt) { return dt == PDEC_F64 ? 8 : 4; }

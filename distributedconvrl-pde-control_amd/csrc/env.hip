@@ -612,10 +612,12 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
                                    T* __restrict__ reward_out, int32_t* __restrict__ done) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = e.N, tid = threadIdx.x, nt = blockDim.x;
-  // This kernel is a long dependent chain (63 FFTs) issued by very few waves; when it shares CUs with the
-  // MFMA-dense update kernels it must win issue arbitration or it is starved (measured 46 -> 155 us).
-  // It uses a few percent of the issue slots, so the priority costs the co-running kernels little.
-  __builtin_amdgcn_s_setprio(3);
+  // This kernel is a long dependent chain (63 FFTs) issued by very few waves.  Beside the f32-MFMA update passes (which
+  // execute on the vector unit) every instruction it issues is taken from them, and their eight waves per workgroup
+  // wait for each other at barriers -- so in the training pipeline, where the UPDATE chain is the critical path and this
+  // step has a whole control step of slack, the passes run at priority 2 and this kernel below them at 1
+  // (r02f, same box: 155 -> 138 us per control step against priority 3 here and 0 there).
+  set_wave_prio(e.prio);
   ENG eng;
   eng.init(smem_raw, e, tid, nt);
   T* act = reinterpret_cast<T*>(reinterpret_cast<C2<T>*>(smem_raw) + ENG::lds_complex(N));  // [2][A] current
@@ -1056,6 +1058,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.dx = (T)(c.Lx / c.N);
   e.hstep = (T)(c.dt / c.K);
   e.rk2 = c.integrator == 1;
+  e.prio = env_prio("PDEC_PRIO_KS", 1);
   e.dist_mu = (T)c.mu;
   e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
   e.Wd = E.Wd; e.Cnt = E.Cnt;

@@ -8,7 +8,7 @@ namespace pdec {
 
 template <class T>
 struct EnvDev {
-  int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species, rk2;
+  int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species, rk2, prio;
   T sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
   T dx, hstep, dist_mu;  // cell size, RK4 sub-step, KS disturbance amplitude (RK4-FD variant)
   // sensor / actuator kernels as circular BAND tables (exact: every non-zero entry of the dense

@@ -94,6 +94,70 @@ __device__ __forceinline__ void gemm_pass(f32x4 (&acc)[NACC], const float* L, co
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// the same product with the tiles of a wave taken in PAIRS whose MFMAs alternate: two independent accumulation chains
+// per wave, so consecutive MFMAs never wait for the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 (issue
+// interval 32).  ldp = leading dimension of both images (8 mod 16 floats: conflict-free ds_read_b128), NT = staged
+// columns / 16.
+template <int NACC, int NT>
+__device__ __forceinline__ void gemm_pass_paired(f32x4 (&acc)[NACC], const float* L, const float* R, int ldp, int nL, int nR,
+                                                 int w, int lr, int q) {
+#pragma unroll
+  for (int pp = 0; pp < NACC; pp += 2) {
+    const int p0 = w + 8 * pp, p1 = p0 + 8;
+    if (p0 < nL * nR) {
+      const int ti0 = p0 / nR, tk0 = p0 - ti0 * nR;
+      const float* l0 = L + (16 * ti0 + lr) * ldp + 4 * q;
+      const float* r0 = R + (16 * tk0 + lr) * ldp + 4 * q;
+      if (pp + 1 < NACC && p1 < nL * nR) {
+        const int ti1 = p1 / nR, tk1 = p1 - ti1 * nR;
+        const float* l1 = L + (16 * ti1 + lr) * ldp + 4 * q;
+        const float* r1 = R + (16 * tk1 + lr) * ldp + 4 * q;
+        f32x4 a0 = acc[pp], a1 = acc[pp + 1 < NACC ? pp + 1 : pp];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 av0 = *reinterpret_cast<const f32x4*>(l0 + 16 * t);
+          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(r0 + 16 * t);
+          const f32x4 av1 = *reinterpret_cast<const f32x4*>(l1 + 16 * t);
+          const f32x4 bv1 = *reinterpret_cast<const f32x4*>(r1 + 16 * t);
+          a0 = mfma4(av0[0], bv0[0], a0);
+          a1 = mfma4(av1[0], bv1[0], a1);
+          a0 = mfma4(av0[1], bv0[1], a0);
+          a1 = mfma4(av1[1], bv1[1], a1);
+          a0 = mfma4(av0[2], bv0[2], a0);
+          a1 = mfma4(av1[2], bv1[2], a1);
+          a0 = mfma4(av0[3], bv0[3], a0);
+          a1 = mfma4(av1[3], bv1[3], a1);
+        }
+        acc[pp] = a0;
+        acc[pp + 1 < NACC ? pp + 1 : pp] = a1;
+      } else {
+        f32x4 a0 = acc[pp];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(l0 + 16 * t);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(r0 + 16 * t);
+          a0 = mfma4(av[0], bv[0], a0);
+          a0 = mfma4(av[1], bv[1], a0);
+          a0 = mfma4(av[2], bv[2], a0);
+          a0 = mfma4(av[3], bv[3], a0);
+        }
+        acc[pp] = a0;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// write a D-layout activation (MT tiles) into a [feature][ldp] LDS image at column cw (any leading dimension)
+template <int MT>
+__device__ __forceinline__ void stage_rows_ld(float* img, int ldp, const f32x4 (&v)[MT], int cw, int q, int ones_row) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * m + 4 * q + r;
+      img[row * ldp + cw] = row == ones_row ? 1.f : v[m][r];
+    }
+}
 // Slab layout (chunk-major): a "chunk" is one accumulator register of one 16x16 output tile = 64 floats in lane
 // order; chunk c of workgroup z lives at ((c * nslab + z) * 64).  A wave therefore stores 256 contiguous bytes
 // per instruction, and the reduction kernel streams one contiguous nslab * 256 B region per chunk.

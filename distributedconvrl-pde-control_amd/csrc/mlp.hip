@@ -1000,7 +1000,7 @@ int pdec_policy_act_rng_dev(pdec_handle actor, const void* state, int cols, doub
   rc = policy_act_rng_impl(actor, M, state, cols, act_noise, act_limit, learning, seed, 0, actions_out, c + M->nc_sel,
                            c + (M->nc_sel ^ 1), inc);
   if (rc) return rc;
-  M->nc_sel ^= 1;
+  flip(M->nc_sel);
   return PDEC_OK;
 }
 

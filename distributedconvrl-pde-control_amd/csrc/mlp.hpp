@@ -19,6 +19,7 @@ struct Mlp : Object {
   DevBuf bpd;                        // double [2][2]
   int bp_sel = 0;
   bool bp_init = false;
+  const void* rbar_ext = nullptr;    // batch-mean reward reduced elsewhere (pdec_ddpg_set_reward_mean), consumed by the next critic pass
   DevBuf noise_ctr;                  // uint64 [2]: double-buffered exploration-noise counter of pdec_policy_act_rng_dev
   int nc_sel = 0;
   std::vector<DevBuf> H;             // activations, feature-major [dims[l]][cols]
@@ -66,7 +67,7 @@ struct BpArgs {
 // slots for the next ADAM kernel on M (uploads {beta1, beta2} on the first step: Flux initialises the powers with the
 // betas themselves); the caller flips M->bp_sel after enqueueing the kernel (bp_done)
 int bp_begin(Mlp* M, double beta1, double beta2, BpArgs* out);
-inline void bp_done(Mlp* M) { M->bp_sel ^= 1; }
+inline void bp_done(Mlp* M) { flip(M->bp_sel); }
 __device__ __forceinline__ void bp_advance(const BpArgs& a, double b1, double b2, int times = 1) {
   double p0 = a.cur[0], p1 = a.cur[1];
   for (int i = 0; i < times; ++i) { p0 *= b1; p1 *= b2; }

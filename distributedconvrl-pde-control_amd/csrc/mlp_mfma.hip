@@ -214,6 +214,7 @@ struct FusedArgs {
   int quirk;
   float* slab;                // chunk-major partial gradients, see store_pass
   const float* rbar_dev;      // != null: batch-mean reward already reduced by launch_rmean (batches beyond 32768 columns)
+  int prio;                   // wave priority of the pass (PDEC_PRIO_MFMA, default 0)
   unsigned long long* stamps; // diagnostic only (PDEC_STAMPS=1): [gridDim.x][16] s_memtime at phase boundaries
 };
 
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   const int ns = g.ns, na = g.na, K0 = ns + na;
   const int col = blockIdx.x * FCOLS + w * 16 + lr;
   const bool valid = col < g.Bu;
+  set_wave_prio(g.prio);
 
   // ---- phase T: target actor + target critic
   STAMP(0);
@@ -372,8 +374,31 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dz1[m][r] = h1[m][r] > 0.f ? dz1[m][r] : 0.f;
-  // ---- pass B: dW2/db2 = dz2 x [h1; 1]^T
+  // ---- pass C first: dW1/db1 = dz1 x [x0; 1]^T in ONE staging round over all 128 columns (dz1 [HP][LDP128] +
+  // x [16][LDP128] fill the big region exactly); dz1 is dead afterwards, which leaves pass B the registers for two
+  // interleaved accumulation chains per wave
   STAMP(7);
+  {
+    constexpr int LDP128 = 136;                 // 8 mod 16 floats, like LDP: conflict-free ds_read_b128 operand reads
+    static_assert(16 * MT * LDP128 + 16 * LDP128 <= wreg_floats(MT, MTA), "pass C images do not fit the big LDS region");
+    float* Lc = Wreg;
+    float* Rc = Wreg + HP * LDP128;
+    const int cw128 = w * 16 + lr;
+    f32x4 accC[((MT + 7) / 8 + 1) & ~1];
+    zero_(accC);
+    __syncthreads();
+    stage_rows_ld<MT>(Lc, LDP128, dz1, cw128, q, -1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = 4 * t + q;
+      Rc[row * LDP128 + cw128] = row == K0 ? 1.f : x[t];
+    }
+    __syncthreads();
+    gemm_pass_paired<((MT + 7) / 8 + 1) & ~1, 8>(accC, Lc, Rc, LDP128, MT, 1, w, lr, q);
+    store_pass(accC, g.slab, nslab, MT + MT * MT, MT, 1, w, l);
+  }
+  // ---- pass B: dW2/db2 = dz2 x [h1; 1]^T, two 64-column halves
+  STAMP(8);
   {
     f32x4 accB[(MT * MT + 7) / 8];
     zero_(accB);
@@ -384,30 +409,9 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
         stage_rows<MT>(Rm, h1, cw, q, g.C.H);
       }
       __syncthreads();
-      gemm_pass(accB, Lm, Rm, MT, MT, w, lr, q);
+      gemm_pass_paired<(MT * MT + 7) / 8, 4>(accB, Lm, Rm, LDP, MT, MT, w, lr, q);
     }
     store_pass(accB, g.slab, nslab, MT, MT, MT, w, l);
-  }
-  // ---- pass C: dW1/db1 = dz1 x [x0; 1]^T (its own staging round: merging it into pass B costs ~50 more live
-  // registers and spills)
-  STAMP(8);
-  {
-    f32x4 accC[(MT + 7) / 8];
-    zero_(accC);
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
-      if ((w >> 2) == half) {
-        stage_rows<MT>(Lm, dz1, cw, q, -1);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int row = 4 * t + q;
-          Rm[row * LDP + cw] = row == K0 ? 1.f : x[t];
-        }
-      }
-      __syncthreads();
-      gemm_pass(accC, Lm, Rm, MT, 1, w, lr, q);
-    }
-    store_pass(accC, g.slab, nslab, MT + MT * MT, MT, 1, w, l);
   }
   STAMP(9);
   {   // the five loss statistics in one fixed-order block reduction
@@ -447,6 +451,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   const int ns = g.ns;
   const int col = blockIdx.x * FCOLS + w * 16 + lr;
   const bool valid = col < g.Bu;
+  set_wave_prio(g.prio);
 
   float xs[4];
 #pragma unroll
@@ -834,7 +839,7 @@ static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
     tmax = std::max(tmax, h[b * 16 + 10]);
   }
   fprintf(stderr, "[pdec stamps] critic pass, mean s_memtime ticks (100 MHz) per phase over %d WGs:", grid);
-  static const char* nm[10] = {"load+rbar", "target", "loadQ", "fwdQ", "passA", "loadW2T", "dz1", "passB", "passC", "stats"};
+  static const char* nm[10] = {"load+rbar", "target", "loadQ", "fwdQ", "passA", "loadW2T", "dz1", "passC", "passB", "stats"};
   for (int k = 0; k < 10; ++k) fprintf(stderr, " %s=%.0f", nm[k], d[k] / grid);
   fprintf(stderr, " | span=%llu\n", tmax - tmin);
   return PDEC_OK;
@@ -917,7 +922,7 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   PDEC_HIP(hipGetLastError());
   if (ap) {
     bp_done(M);
-    M->pub ^= 1;
+    flip(M->pub);
   }
   return PDEC_OK;
 }
@@ -972,11 +977,15 @@ int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const vo
   g.s = (const float*)s; g.a = (const float*)a; g.r = (const float*)r; g.t = (const float*)t; g.sn = (const float*)sn;
   g.Bu = Bu; g.ns = A->dims[0]; g.na = 1; g.gamma = (float)gamma; g.quirk = quirk;
   g.slab = C->fslab.as<float>();
-  if (quirk && Bu > 256 * FCOLS) {     // every workgroup summing all of r itself does not scale (C3: 131072 rewards): reduce once
+  g.prio = env_prio("PDEC_PRIO_MFMA", 2);
+  if (quirk && C->rbar_ext) {          // reduced by the producer of r on its own stream (pdec_reward_mean): nothing to sum here
+    g.rbar_dev = (const float*)C->rbar_ext;
+  } else if (quirk && Bu > 256 * FCOLS) {     // every workgroup summing all of r itself does not scale (C3: 131072 rewards): reduce once
     float* rb = nullptr;
     if ((rc = launch_rmean(C, (const float*)r, Bu, &rb))) return rc;
     g.rbar_dev = rb;
   }
+  C->rbar_ext = nullptr;
   if (mt == 9 && mta == 2) rc = launch_critic<9, 2>(C, g, grid);
   else if (mt == 9 && mta == 1) rc = launch_critic<9, 1>(C, g, grid);
   else if (mt == 2 && mta == 2) rc = launch_critic<2, 2>(C, g, grid);
@@ -996,6 +1005,7 @@ int fused_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double gra
   g.C = fnet_of(C); g.A = fnet_of(A); g.At = g.A; g.Ct = g.C;
   g.s = (const float*)s; g.Bu = Bu; g.ns = A->dims[0]; g.na = 1;
   g.slab = A->fslab.as<float>();
+  g.prio = env_prio("PDEC_PRIO_MFMA", 2);
   // the actor pass is launched on the critic's stream object for profiling labels but must follow
   // ADAM(C); both handles share one stream in every caller (checked by the dispatcher)
   if (mt == 9 && mta == 2) rc = launch_actor<9, 2>(C, g, grid);

@@ -898,12 +898,15 @@ int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const v
   g.s = (const float*)s; g.a = (const float*)a; g.r = (const float*)r; g.t = (const float*)t; g.sn = (const float*)sn;
   g.Bu = Bu; g.ns = A->dims[0]; g.gamma = (float)gamma; g.quirk = quirk;
   g.slab = C->fslab.as<float>();
-  if (quirk) {
+  if (quirk && C->rbar_ext) {          // reduced by the producer of r on its own stream (pdec_reward_mean)
+    g.rbar = (const float*)C->rbar_ext;
+  } else if (quirk) {
     float* rb = nullptr;
     int rcm = launch_rmean(C, (const float*)r, Bu, &rb);
     if (rcm) return rcm;
     g.rbar = rb;
   }
+  C->rbar_ext = nullptr;
   int rc = dispatch2(C, g, grid, false, mt, mta);
   if (rc) return rc;
   return launch_finish2(C, apply ? Ct : nullptr, grid, mt, nR, grad_scale, 0, Bu, quirk, loss_dev, apply);
@@ -925,3 +928,25 @@ int fused2_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double gr
 }
 
 }  // namespace pdec
+
+// batch-mean reward as its own (fixed-order, one block) reduction on the caller's stream: the producer of r -- the env
+// step -- reduces it beside the update, which then reads one scalar instead of every workgroup summing all of r
+extern "C" int pdec_reward_mean(pdec_handle any_handle, const void* r, int n, void* mean_out) {
+  using namespace pdec;
+  Object* o = lookup(any_handle);
+  if (!o) { set_error("pdec_reward_mean: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(r && mean_out && n >= 1, "pdec_reward_mean: null/empty");
+  ProfScope ps(o, "ddpg_rmean");
+  hipLaunchKernelGGL(rmean_kernel, dim3(1), dim3(1024), 0, o->stream, (const float*)r, n, (float*)mean_out);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+extern "C" int pdec_ddpg_set_reward_mean(pdec_handle critic, const void* mean_dev) {
+  using namespace pdec;
+  Mlp* C = lookup_as<Mlp>(critic, Kind::Mlp);
+  if (!C) { set_error("pdec_ddpg_set_reward_mean: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(C->dtype == PDEC_F32, "pdec_ddpg_set_reward_mean: fp32 critics only");
+  C->rbar_ext = mean_dev;
+  return PDEC_OK;
+}

@@ -171,9 +171,25 @@ __global__ void random_init_kernel(T* __restrict__ y, int N, int nsp, int nsin, 
   }
 }
 
+// device-scope events: created without the system-scope fence of a default HIP event (hipEventDisableSystemFence),
+// so a record / wait pair between two streams of the SAME device does not flush and invalidate the caches towards the
+// host -- the cross-stream hand-offs of the control step sit on its critical path
+struct Event : Object {
+  hipEvent_t ev = nullptr;
+  Event() : Object(Kind::Event) {}
+  ~Event() override {
+    if (ev) (void)hipEventDestroy(ev);
+  }
+};
+
+extern std::vector<int*>* g_flip_log;
+
 struct Graph : Object {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  std::vector<int*> odd_flips;      // slot selectors the captured launches flipped an odd number of times
+  bool owed = true;                 // the capture advanced the selectors without running anything: the FIRST launch
+                                    // performs that work and must not advance them again
   Graph() : Object(Kind::Graph) {}
   ~Graph() override {
     if (exec) (void)hipGraphExecDestroy(exec);
@@ -312,7 +328,9 @@ int pdec_capture_begin(pdec_handle origin) {
   if (!o) { set_error("pdec_capture_begin: bad handle"); return PDEC_E_HANDLE; }
   PDEC_REQUIRE(o->stream != nullptr, "pdec_capture_begin: the handle must own a non-null stream (pdec_set_stream): the null stream cannot be captured");
   PDEC_REQUIRE(!o->prof, "pdec_capture_begin: switch the per-kernel event timing off first (pdec_prof_enable(h, 0))");
+  PDEC_REQUIRE(g_flip_log == nullptr, "pdec_capture_begin: another capture is already open");
   PDEC_HIP(hipStreamBeginCapture(o->stream, hipStreamCaptureModeRelaxed));
+  g_flip_log = new std::vector<int*>();
   return PDEC_OK;
 }
 
@@ -321,6 +339,14 @@ int pdec_capture_end(pdec_handle origin, pdec_handle* graph_out) {
   if (!o) { set_error("pdec_capture_end: bad handle"); return PDEC_E_HANDLE; }
   PDEC_REQUIRE(graph_out, "pdec_capture_end: null");
   auto g = std::make_unique<Graph>();
+  if (g_flip_log) {
+    std::map<int*, int> cnt;
+    for (int* p : *g_flip_log) ++cnt[p];
+    for (auto& kv : cnt)
+      if (kv.second & 1) g->odd_flips.push_back(kv.first);
+    delete g_flip_log;
+    g_flip_log = nullptr;
+  }
   PDEC_HIP(hipStreamEndCapture(o->stream, &g->graph));
   PDEC_REQUIRE(g->graph != nullptr, "pdec_capture_end: the capture was invalidated (a forked stream did not join the origin?)");
   PDEC_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
@@ -333,6 +359,29 @@ int pdec_graph_launch(pdec_handle graph, void* hip_stream) {
   Graph* g = lookup_as<Graph>(graph, Kind::Graph);
   if (!g) { set_error("pdec_graph_launch: bad handle"); return PDEC_E_HANDLE; }
   PDEC_HIP(hipGraphLaunch(g->exec, hip_stream ? (hipStream_t)hip_stream : g->stream));
+  if (!g->owed)
+    for (int* p : g->odd_flips) *p ^= 1;    // what the captured calls did to the host-side slot selectors
+  g->owed = false;
+  return PDEC_OK;
+}
+
+int pdec_event_create(pdec_handle* ev) {
+  PDEC_REQUIRE(ev, "pdec_event_create: null");
+  auto e = std::make_unique<Event>();
+  PDEC_HIP(hipEventCreateWithFlags(&e->ev, hipEventDisableTiming | hipEventDisableSystemFence));
+  *ev = register_object(std::move(e));
+  return PDEC_OK;
+}
+int pdec_event_record(pdec_handle ev, void* hip_stream) {
+  Event* e = lookup_as<Event>(ev, Kind::Event);
+  if (!e) { set_error("pdec_event_record: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_HIP(hipEventRecord(e->ev, (hipStream_t)hip_stream));
+  return PDEC_OK;
+}
+int pdec_stream_wait_event(void* hip_stream, pdec_handle ev) {
+  Event* e = lookup_as<Event>(ev, Kind::Event);
+  if (!e) { set_error("pdec_stream_wait_event: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, e->ev, 0));
   return PDEC_OK;
 }
 

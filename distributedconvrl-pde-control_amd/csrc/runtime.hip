@@ -9,6 +9,11 @@ static std::map<pdec_handle, std::unique_ptr<Object>> g_objs;
 static pdec_handle g_next = 0x70de0001ull;
 static bool g_inited = false;
 
+std::vector<int*>* g_flip_log = nullptr;      // non-null while pdec_capture_begin .. pdec_capture_end is open
+void note_flip(int* selector) {
+  if (g_flip_log) g_flip_log->push_back(selector);
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -52,6 +52,12 @@ class PDEhook:
         self._rows_dev = []
 
     def __call__(self, stage, agent, env):
+        # the hook's device ops (clones, accumulators, re-initialisation) are ordered with the env's kernels
+        from .env import _on_stream
+        with _on_stream(getattr(env, "stream", None)):
+            self._call(stage, agent, env)
+
+    def _call(self, stage, agent, env):
         if stage == PRE_EXPERIMENT_STAGE:                       # PDEhook.jl:35-40
             if self.collect_NNA and self.currentNNA is None:
                 self.currentNNA = copy.deepcopy(agent.policy.behavior_actor)

@@ -3,19 +3,22 @@
 One control step keeps the reference's stage order -- act -> update -> env step (RL.jl's run loop through
 src/PDEagent.jl:175-209, :342-418 and src/PDEenv.jl:195-241):
 
-    env stream:     fork -> act_k (actor forward + exploration noise + clamp) -> env_k (fused env step) -> join
-    update stream:  fork -> update_k (critic half, actor half: 4 launches) on the transition of step k - LAG -> join
+    env stream:     wait update_{k-1}  ->  act_k (actor forward + exploration noise + clamp)  ->  env_k (fused env step)
+    update stream:  wait act_{k-1}     ->  update_k (critic half, actor half: 4 launches) on the transition of step k - LAG
 
 The update needs nothing of step k (DDPG is off-policy; the reference samples its minibatches from a 150k-deep replay,
-src/PDEagent.jl:317-340) and act_k reads a published copy of the actor that update_k does not write, so the two
-branches run side by side; act_{k+1} follows update_k (join), exactly as `agent(env)` follows `update!` in the run loop.
+src/PDEagent.jl:317-340) and act_k reads a published copy of the actor that update_k does not write, so update_k runs
+back to back behind update_{k-1} beside act_k / env_k; act_{k+1} follows update_k, exactly as `agent(env)` follows
+`update!` in the run loop.  (update_k must follow act_{k-1}, the last reader of the image its actor half republishes;
+env_{k-LAG}, its batch, precedes act_{k-1} on the env stream.)
 
 Every buffer a step touches is a pure function of the step counter k (rings indexed by k mod 2 / 3 / 6) and every
 per-step scalar lives on the device (noise counter: pdec_policy_act_rng_dev; ADAM beta powers), so the launch arguments
-of step k + 6 are those of step k: six consecutive steps are captured ONCE into HIP graphs (chunks of 24 / 6 / 1 steps,
-pdec_capture_begin / _end) and replayed with one host call per chunk instead of ~12 ctypes calls per step.  The first
-and the last step of an episode (initial-condition pointers, time-out terminal flags; te / dt + 1 = 51 steps in
-scripts/KS/KS22) are issued eagerly.  Eager and replayed runs enqueue the same kernels with the same arguments and are
+of step k + 6 are those of step k: chunks of 24 / 6 / 1 consecutive steps starting at each of the six ring phases are
+captured ONCE into HIP graphs (pdec_capture_begin / _end) and replayed with one host call per chunk instead of ~12 ctypes
+calls per step.  Inside a chunk the cross-stream events above become graph edges; a chunk forks the update branch off
+the env stream at its first step and joins it at its last.  The first and the last step of an episode
+(initial-condition pointers, time-out terminal flags; te / dt + 1 = 51 steps in scripts/KS/KS22) are issued eagerly.  Eager and replayed runs enqueue the same kernels with the same arguments and are
 bit-identical (tests/test_gpu_agent.py)."""
 import ctypes as C
 
@@ -25,6 +28,39 @@ import torch
 from . import _lib
 
 PERIOD = 6            # lcm of the ring lengths (2: y / published actor / beta-power and noise-counter slots; 3; 6)
+
+
+class _Event:
+    """device-scope event of the library (pdec_event_create: no system-scope fence), torch.cuda.Event-like surface"""
+
+    def __init__(self, lib):
+        self.lib, self.h = lib, _lib.Handle()
+        _lib.check(lib.pdec_event_create(C.byref(self.h)))
+
+    def record(self, stream):
+        _lib.check(self.lib.pdec_event_record(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def wait(self, stream):
+        _lib.check(self.lib.pdec_stream_wait_event(C.c_void_p(stream.cuda_stream), self.h))
+
+    def __del__(self):
+        try:
+            self.lib.pdec_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _TorchEvent:
+    """the same surface on a default torch event (diagnostic: PDEC_TORCH_EVENTS=1)"""
+
+    def __init__(self, lib=None):
+        self.ev = torch.cuda.Event()
+
+    def record(self, stream):
+        self.ev.record(stream)
+
+    def wait(self, stream):
+        stream.wait_event(self.ev)
 
 
 class TrainPipeline:
@@ -65,10 +101,19 @@ class TrainPipeline:
             self.fring = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(3)]
             self.tring = [torch.zeros((B, setup.reward_len), **kw) for _ in range(3)]      # per-column terminal flags
             self.pbuf = torch.zeros(env._pshape, **kw)
+            self.rbar = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(3)]  # batch-mean reward of step k
             self.azero = torch.zeros(env._ashape, **kw)                                    # action0 of a fresh episode
             self.state0 = torch.empty(env._sshape, **kw)
-        self.ev_fork = torch.cuda.Event()
-        self.ev_join = torch.cuda.Event()
+        # the reference's reward broadcast (quirk) needs the batch-mean reward: reduced on the env stream
+        # right behind the env step instead of by every workgroup of the critic pass
+        self.pre_rbar = bool(self.policy.quirk) and dt == torch.float32 and not self.use_replay
+        import os
+        Ev = _TorchEvent if os.environ.get("PDEC_TORCH_EVENTS") == "1" else _Event
+        self.ev_fork = Ev(self.lib)
+        self.ev_act = [Ev(self.lib), Ev(self.lib)]                  # act_k issued (env stream)
+        self.ev_upd = [Ev(self.lib), Ev(self.lib)]                  # update_k issued (update stream)
+        self.ev_graph = Ev(self.lib)                                # tail of the last graph launch (env stream)
+        self._after_graph = False
         self.tick = 0             # control steps issued so far: every buffer of step k is indexed by k mod 2 / 3 / 6
         self.ep_start = 0         # tick of the first step of the current episode
         self.noise_seed = int(noise_seed)
@@ -98,32 +143,49 @@ class TrainPipeline:
         return self.sring[self.tick % PERIOD]
 
     # ------------------------------------------------------------------ one step, issued call by call
-    def _issue(self, k):
+    def _issue(self, k, chunk_first=False, chunk_last=False):
+        """enqueue control step k.  chunk_first / chunk_last: first / last step of a chunk being CAPTURED (fork / join of
+        the update branch); both False for a step issued eagerly."""
         env, pol, lib, L = self.env, self.policy, self.lib, _lib
         first, last = self._first_last(k)
         y_in, y_out = self.ybuf[k % 2], self.ybuf[(k + 1) % 2]
         s_in, s_out = self.sring[k % PERIOD], self.sring[(k + 1) % PERIOD]
         act, act_prev = self.aring[k % 3], self.aring[(k - 1) % 3]
         rew, flags, term = self.rring[k % 3], self.fring[k % 3], self.tring[k % 3]
+        capturing = chunk_first or chunk_last or self._capturing
+        if not self.serial:
+            if chunk_first:                       # fork: everything before this chunk is ordered before it on the env stream
+                self.ev_fork.record(self.s_env)
+                self.ev_fork.wait(self.s_upd)
+            elif capturing:
+                self.ev_act[(k - 1) % 2].wait(self.s_upd)
+                self.ev_upd[(k - 1) % 2].wait(self.s_env)
+            else:                                 # eager
+                if self._after_graph:             # the update branch of the graph just launched ran on the env stream
+                    self.ev_graph.wait(self.s_upd)
+                    self._after_graph = False
+                elif k > 0:
+                    self.ev_act[(k - 1) % 2].wait(self.s_upd)
+                    self.ev_upd[(k - 1) % 2].wait(self.s_env)
         with torch.cuda.stream(self.s_env):
             if first:                                  # reset!(env): this step starts from the initial condition
                 y_in.copy_(env.y0)
                 s_in.copy_(self.state0)
                 act_prev = self.azero
-            self.ev_fork.record(self.s_env)
-        if not self.serial:
-            self.s_upd.wait_event(self.ev_fork)
-        with torch.cuda.stream(self.s_env):
             # actor forward on all B*A columns + exploration noise (Philox, counter on the device) + clamp: one launch
             L.check(lib.pdec_set_stream(self.actor.handle, self._sp_env))
             L.check(lib.pdec_policy_act_rng_dev(self.actor.handle, L.ptr(s_in), self.cols, float(pol.act_noise),
                                                 float(pol.act_limit), 1, self.noise_seed, L.ptr(act)))
             L.check(lib.pdec_set_stream(self.actor.handle, self._sp_upd))
+            if not self.serial:
+                self.ev_act[k % 2].record(self.s_env)
             L.check(lib.pdec_env_set_terminal_out(env.handle, L.ptr(term)))
             L.check(lib.pdec_env_step(env.handle, L.ptr(y_in), L.ptr(act), L.ptr(act_prev), L.ptr(s_in), L.ptr(y_out),
                                       L.ptr(self.pbuf), L.ptr(s_out), L.ptr(rew), L.ptr(flags)))
             if last:
                 term.fill_(1.0)                        # time-out: done = time >= te -> terminal transition
+            if self.pre_rbar:
+                L.check(lib.pdec_reward_mean(env.handle, L.ptr(rew), self.cols, L.ptr(self.rbar[k % 3])))
             if self.use_replay:
                 self._replay_push(k, s_in, act, rew, term, s_out, first, last)
         if self.drain_between:                         # kernel-timing pass: nothing of the env branch overlaps the update
@@ -138,11 +200,15 @@ class TrainPipeline:
                                  reward=self.rring[j % 3].view(self.cols), terminal=self.tring[j % 3].view(self.cols),
                                  next_state=self.sring[(j + 1) % PERIOD].view(self.cols, self.ns))
                 if batch is not None:
+                    if self.pre_rbar:
+                        L.check(lib.pdec_ddpg_set_reward_mean(pol.behavior_critic.model.handle, L.ptr(self.rbar[j % 3])))
                     pol.update(batch)
-            self.ev_join.record(self.s_upd)
-        if not self.serial:
-            self.s_env.wait_event(self.ev_join)          # act_{k+1} follows update_k, as agent(env) follows update!
+            if not self.serial:
+                self.ev_upd[k % 2].record(self.s_upd)
+        if chunk_last and not self.serial:
+            self.ev_upd[k % 2].wait(self.s_env)    # join: the graph ends on the env stream
 
+    _capturing = False
     _first_tick = 0
     drain_between = False
 
@@ -188,19 +254,22 @@ class TrainPipeline:
         while self.tick - self.LAG < self._first_tick + 2:      # lazily created buffers / first-use uploads happen eagerly
             self._eager()
         for c in self.chunks:
-            for pos in (range(PERIOD) if c == 1 else (0,)):
+            for pos in range(PERIOD):
                 while not (self.tick % PERIOD == pos and self._interior(self.tick, c)):
                     self._eager()
+                self._sync_streams_for_graph()
                 _lib.check(self.lib.pdec_capture_begin(self.env.handle))
+                self._capturing = True
                 try:
                     for i in range(c):
-                        self._issue(self.tick + i)
+                        self._issue(self.tick + i, chunk_first=(i == 0), chunk_last=(i == c - 1))
                 finally:
+                    self._capturing = False
                     h = _lib.Handle()
                     _lib.check(self.lib.pdec_capture_end(self.env.handle, C.byref(h)))
                 self.graphs[(c, pos)] = h
                 # the capture recorded the steps without running them: replay once so that the run really advances
-                _lib.check(self.lib.pdec_graph_launch(h, self._sp_env))
+                self._launch(h)
                 self.tick += c
         self._captured = True
 
@@ -219,6 +288,17 @@ class TrainPipeline:
         self.tick += 1
         self.n_eager_steps += 1
 
+    def _sync_streams_for_graph(self):
+        """a graph runs wholly on the env stream: order the eager update still queued on the update stream before it"""
+        if not self.serial and not self._after_graph and self.tick > 0:
+            self.ev_upd[(self.tick - 1) % 2].wait(self.s_env)
+
+    def _launch(self, h):
+        _lib.check(self.lib.pdec_graph_launch(h, self._sp_env))
+        if not self.serial:
+            self.ev_graph.record(self.s_env)
+        self._after_graph = True
+
     def run(self, n):
         """issue n control steps (asynchronous: returns when they are enqueued)"""
         n = int(n)
@@ -227,8 +307,9 @@ class TrainPipeline:
             done = False
             if self._captured:
                 for c in self.chunks:
-                    if c <= n and (c == 1 or k % PERIOD == 0) and self._interior(k, c):
-                        _lib.check(self.lib.pdec_graph_launch(self.graphs[(c, k % PERIOD)], self._sp_env))
+                    if c <= n and self._interior(k, c):
+                        self._sync_streams_for_graph()
+                        self._launch(self.graphs[(c, k % PERIOD)])
                         self.tick += c
                         n -= c
                         self.n_graph_launches += 1

@@ -305,6 +305,13 @@ int pdec_ddpg_update_small(pdec_handle A, pdec_handle C, pdec_handle At, pdec_ha
                            const int32_t* idx_sn, int loops, int Bu, double gamma, double rho, int quirk,
                            double eta_actor, double eta_critic, void* losses_dev);
 
+/* The batch-mean reward of the reference's (1 x Bu) .+ (Bu) broadcast (quirk = 1) reduced AHEAD of the
+ * update: pdec_reward_mean(h, r, n, mean_out) sums the fp32 rewards r [n] in a fixed order on h's stream (the producer of
+ * r -- the env step -- does it beside the running update) and pdec_ddpg_set_reward_mean hands the device scalar to the
+ * NEXT critic pass of `critic`, which then does not read r for the mean (one hand-over per update; fp32 fused paths). */
+int pdec_reward_mean(pdec_handle any_handle, const void* r, int n, void* mean_out);
+int pdec_ddpg_set_reward_mean(pdec_handle critic, const void* mean_dev);
+
 /* the same with pde_sample (src/PDEagent.jl:317-321) INSIDE the kernel: draw k = loop * Bu + column is word k % 4 of the
  * Philox block (seed; counter offset + k / 4), ind = (word * (n_valid - stride)) >> 32, logical index
  * max(0, n_rt - capacity) + ind, slots (lg mod (capacity + stride), lg mod capacity, (lg + stride) mod (capacity + stride)).
@@ -362,13 +369,20 @@ int pdec_env_random_init(pdec_handle env, uint64_t seed, uint64_t offset, void* 
 /* Record everything enqueued on the stream of `origin` (pdec_set_stream; not the null stream) -- library calls, and any
  * other stream that forks from it and joins it again through events -- between _begin and _end into one HIP graph;
  * pdec_graph_launch replays it with one host call.  Calls that keep their per-step state on the device
- * (pdec_policy_act_rng_dev, every ADAM step) replay correctly; the double-buffered state they flip on the host returns
- * to its captured value after an EVEN number of calls, so capture a period with an even number of control steps.
+ * (pdec_policy_act_rng_dev, every ADAM step) replay correctly: the slot selectors of their double-buffered device
+ * state, which the captured calls flipped on the host, are flipped again by every pdec_graph_launch after the first
+ * (capturing records the work without running it, so the first launch is the execution the capture stands for).
+ * A graph must be replayed at a step whose buffers are those of the captured one (same ring phase).
  * The graph handle is released with pdec_destroy. */
 int pdec_capture_begin(pdec_handle origin);
 int pdec_capture_end(pdec_handle origin, pdec_handle* graph);
 int pdec_graph_launch(pdec_handle graph, void* hip_stream);      /* NULL = the stream it was captured on */
 int pdec_graph_num_nodes(pdec_handle graph, int* n);
+/* Device-scope events for the hand-offs between two streams of one device (no system-scope cache fence, unlike a
+ * default HIP event): record on one stream, make another stream wait.  Released with pdec_destroy. */
+int pdec_event_create(pdec_handle* ev);
+int pdec_event_record(pdec_handle ev, void* hip_stream);
+int pdec_stream_wait_event(void* hip_stream, pdec_handle ev);
 
 /* ---------------------------------------------------------------- multi-GPU ---------- */
 /* One RCCL communicator per process (one process per GPU).  unique_id: 128 bytes from
