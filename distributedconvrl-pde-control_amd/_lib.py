@@ -80,6 +80,7 @@ SIGNATURES = {
     "pdec_rollout": [Handle, Handle, _i, _vp, _vp, _vp, _d, _d, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdec_randn": [Handle, _vp, _sz, _i, _u64, _u64],
     "pdec_policy_act_rng_dev": [Handle, _vp, _i, _d, _d, _i, _u64, _vp],
+    "pdec_mlp_acts_on_published_copy": [Handle, C.POINTER(_i)],
     "pdec_noise_counter_set": [Handle, _u64], "pdec_noise_counter_get": [Handle, C.POINTER(_u64)],
     "pdec_reward_mean": [Handle, _vp, _i, _vp], "pdec_ddpg_set_reward_mean": [Handle, _vp],
     "pdec_ddpg_update_small_rng": [Handle] * 4 + [_vp] * 4 + [_i, _i, _u64, _u64, _i64, _i64, _i64, _i, _d, _d, _i, _d, _d, _vp],

@@ -135,7 +135,13 @@ struct DevBuf {
     release();
     if (n == 0) return hipSuccess;
     hipError_t e = hipMalloc(&p, n);
-    if (e == hipSuccess) bytes = n;
+    if (e == hipSuccess) {
+      bytes = n;
+      // diagnostic: PDEC_POISON=1 fills every fresh library buffer with 0xFF bytes (NaN as float / double), so that a
+      // read of memory the library never wrote shows up in the results instead of depending on what was there before
+      static const bool poison = getenv("PDEC_POISON") != nullptr;
+      if (poison && (e = hipMemset(p, 0xFF, n)) == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
     return e;
   }
   template <class T>

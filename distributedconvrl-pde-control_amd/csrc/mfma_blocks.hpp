@@ -170,7 +170,9 @@ __device__ __forceinline__ void store_pass(const f32x4 (&acc)[NACC], float* slab
     const int p = w + 8 * pp;
     if (p < nL * nR) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slab[((size_t)(4 * (T0 + p) + r) * nslab + blockIdx.x) * 64 + l] = acc[pp][r];
+      for (int r = 0; r < 4; ++r)      // written once, read once by the reduction kernel: streaming (non-temporal) stores keep
+                                       // the 26 MB of partials from sitting dirty in the XCD's L2 at the kernel boundary
+        __builtin_nontemporal_store(acc[pp][r], &slab[((size_t)(4 * (T0 + p) + r) * nslab + blockIdx.x) * 64 + l]);
     }
   }
 }

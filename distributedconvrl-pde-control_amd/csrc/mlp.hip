@@ -353,6 +353,7 @@ int Mlp::init(int dtype_, int L_, const int32_t* dims_, const int32_t* acts_, in
   PDEC_HIP(hipMemset(grads.p, 0, off * ts));
   PDEC_HIP(hipMemset(m.p, 0, off * ts));
   PDEC_HIP(hipMemset(v.p, 0, off * ts));
+  PDEC_HIP(hipStreamSynchronize(nullptr));     // the memsets are queued on the null stream; later users run on non-blocking streams
   H.resize(L + 1);
   for (int l = 0; l <= L; ++l) PDEC_HIP(H[l].alloc((size_t)dims[l] * max_cols * ts));
   PDEC_HIP(dz[0].alloc((size_t)maxd * max_cols * ts));
@@ -983,7 +984,10 @@ int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double a
 static int ensure_noise_ctr(Mlp* M) {
   if (!M->noise_ctr.p) {
     PDEC_HIP(M->noise_ctr.alloc(2 * sizeof(uint64_t)));
-    PDEC_HIP(hipMemset(M->noise_ctr.p, 0, 2 * sizeof(uint64_t)));
+    // blocking copy, NOT hipMemset: a memset is queued on the null stream and returns; the acting kernel runs on a
+    // non-blocking stream that the null stream does not order, so on a busy device it could read the counter first
+    const uint64_t zero[2] = {0, 0};
+    PDEC_HIP(hipMemcpy(M->noise_ctr.p, zero, sizeof(zero), hipMemcpyHostToDevice));
     M->nc_sel = 0;
   }
   return PDEC_OK;
@@ -1001,6 +1005,13 @@ int pdec_policy_act_rng_dev(pdec_handle actor, const void* state, int cols, doub
                            c + (M->nc_sel ^ 1), inc);
   if (rc) return rc;
   flip(M->nc_sel);
+  return PDEC_OK;
+}
+
+int pdec_mlp_acts_on_published_copy(pdec_handle actor, int* yes) {
+  GET_MLP(M, actor);
+  PDEC_REQUIRE(yes, "pdec_mlp_acts_on_published_copy: null");
+  *yes = (fused_net_supported(M) && M->dims[M->L] == 1 && M->dims[1] <= 31) ? 1 : 0;
   return PDEC_OK;
 }
 

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g_in) {
         for (; z + 240 < g.nslab; z += 256) {
           float v[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = sp[(size_t)(z + 16 * u) * 64];
+          for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(&sp[(size_t)(z + 16 * u) * 64]);
 #pragma unroll
           for (int u = 0; u < 16; ++u) acc += v[u];
         }

@@ -93,9 +93,11 @@ class TrainPipeline:
         self.ns, self.na = ns, setup.action_shape[0]
         dt, dev = env.dtype, env.device
         kw = dict(dtype=dt, device=dev)
+        import os
+        empty = (lambda shape, **k: torch.full(shape, float("nan"), **k)) if os.environ.get("PDEC_POISON") else torch.empty
         with torch.cuda.stream(self.s_env):
-            self.ybuf = [torch.empty(env._yshape, **kw) for _ in range(2)]
-            self.sring = [torch.empty(env._sshape, **kw) for _ in range(PERIOD)]
+            self.ybuf = [empty(env._yshape, **kw) for _ in range(2)]
+            self.sring = [empty(env._sshape, **kw) for _ in range(PERIOD)]
             self.aring = [torch.zeros(env._ashape, **kw) for _ in range(3)]
             self.rring = [torch.zeros((B, setup.reward_len), **kw) for _ in range(3)]
             self.fring = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(3)]
@@ -103,7 +105,7 @@ class TrainPipeline:
             self.pbuf = torch.zeros(env._pshape, **kw)
             self.rbar = [torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(3)]  # batch-mean reward of step k
             self.azero = torch.zeros(env._ashape, **kw)                                    # action0 of a fresh episode
-            self.state0 = torch.empty(env._sshape, **kw)
+            self.state0 = empty(env._sshape, **kw)
         # the reference's reward broadcast (quirk) needs the batch-mean reward: reduced on the env stream
         # right behind the env step instead of by every workgroup of the critic pass
         self.pre_rbar = bool(self.policy.quirk) and dt == torch.float32 and not self.use_replay
@@ -118,6 +120,12 @@ class TrainPipeline:
         self.ep_start = 0         # tick of the first step of the current episode
         self.noise_seed = int(noise_seed)
         self.actor = self.policy.behavior_actor.model
+        yes = C.c_int()
+        _lib.check(self.lib.pdec_mlp_acts_on_published_copy(self.actor.handle, C.byref(yes)))
+        # an actor whose acting kernel reads its parameters in place (2-layer / generic nets) must not be rewritten by the
+        # update's actor half while act_k still runs: that half then waits for act_k (the fused 3-layer path reads a
+        # published copy instead and needs no such edge)
+        self.act_in_place = not bool(yes.value)
         self._sp_env, self._sp_upd = C.c_void_p(self.s_env.cuda_stream), C.c_void_p(self.s_upd.cuda_stream)
         self.graphs = {}          # (chunk, pos) -> graph handle
         self._captured = False
@@ -177,7 +185,7 @@ class TrainPipeline:
             L.check(lib.pdec_policy_act_rng_dev(self.actor.handle, L.ptr(s_in), self.cols, float(pol.act_noise),
                                                 float(pol.act_limit), 1, self.noise_seed, L.ptr(act)))
             L.check(lib.pdec_set_stream(self.actor.handle, self._sp_upd))
-            if not self.serial:
+            if not self.serial and self.LAG >= 2:
                 self.ev_act[k % 2].record(self.s_env)
             L.check(lib.pdec_env_set_terminal_out(env.handle, L.ptr(term)))
             L.check(lib.pdec_env_step(env.handle, L.ptr(y_in), L.ptr(act), L.ptr(act_prev), L.ptr(s_in), L.ptr(y_out),
@@ -188,6 +196,10 @@ class TrainPipeline:
                 L.check(lib.pdec_reward_mean(env.handle, L.ptr(rew), self.cols, L.ptr(self.rbar[k % 3])))
             if self.use_replay:
                 self._replay_push(k, s_in, act, rew, term, s_out, first, last)
+            if not self.serial and self.LAG < 2:
+                # LAG = 1: update_{k+1} trains on the transition env_k is producing, so the event it waits on is
+                # recorded behind the whole env branch, not behind the acting kernel
+                self.ev_act[k % 2].record(self.s_env)
         if self.drain_between:                         # kernel-timing pass: nothing of the env branch overlaps the update
             torch.cuda.synchronize()
         with torch.cuda.stream(self.s_upd):
@@ -202,7 +214,10 @@ class TrainPipeline:
                 if batch is not None:
                     if self.pre_rbar:
                         L.check(lib.pdec_ddpg_set_reward_mean(pol.behavior_critic.model.handle, L.ptr(self.rbar[j % 3])))
-                    pol.update(batch)
+                    if self.act_in_place and not self.serial:
+                        pol.update(batch, before_actor_half=lambda: self.ev_act[k % 2].wait(self.s_upd))
+                    else:
+                        pol.update(batch)
             if not self.serial:
                 self.ev_upd[k % 2].record(self.s_upd)
         if chunk_last and not self.serial:

@@ -260,6 +260,10 @@ int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double a
  * pdec_noise_counter_set / _get move the counter (they synchronise the actor's stream). */
 int pdec_policy_act_rng_dev(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
                             int learning, uint64_t seed, void* actions_out);
+/* 1 when the acting kernels of this actor read a PUBLISHED, double-buffered copy of its weights that a concurrent
+ * update does not write (fp32 3-layer actors on the fused path); 0 when they read the parameters in place -- a caller that
+ * overlaps acting and updating must then order the update's actor half behind the acting kernel. */
+int pdec_mlp_acts_on_published_copy(pdec_handle actor, int* yes);
 int pdec_noise_counter_set(pdec_handle actor, uint64_t value);
 int pdec_noise_counter_get(pdec_handle actor, uint64_t* value);
 /* fill dst[n] with standard normals from a counter-based generator (replaces randn(rng),

@@ -27,12 +27,13 @@ def diff(a, b):
     return out or ["identical"]
 
 
-for serial in (False,):
-    print("== eager vs eager")
-    a, b = _make_pipeline(pkg, False), _make_pipeline(pkg, False)
-    for n in (5, 10, 20):
-        a.run(n); b.run(n)
-        print(a.tick, diff(snap(a), snap(b)))
+for serial in ((False,) if __name__ == '__main__' else ()):
+    if os.environ.get("DBG_SKIP_EE") != "1":
+        print("== eager vs eager")
+        a, b = _make_pipeline(pkg, False), _make_pipeline(pkg, False)
+        for n in (5, 10, 20):
+            a.run(n); b.run(n)
+            print(a.tick, diff(snap(a), snap(b)))
     print("== graph vs eager, step by step after capture")
     pe, pg = _make_pipeline(pkg, False), _make_pipeline(pkg, True)
     pg.run(5)
@@ -48,7 +49,19 @@ for serial in (False,):
         pkg._lib.check(pg.lib.pdec_graph_num_nodes(h, C.byref(n)))
         print("graph", key, "nodes", n.value)
     pe.run(pg.tick)
-    print("after capture", pg.tick, diff(snap(pe), snap(pg)))
-    for i in range(40):
-        pe.run(1); pg.run(1)
+    if os.environ.get("DBG_SYNC", "1") == "1":
+        print("after capture", pg.tick, diff(snap(pe), snap(pg)))
+    import os
+    seq = [int(x) for x in os.environ.get("DBG_SEQ", "").split(",") if x]
+    do_sync = os.environ.get("DBG_SYNC", "1") == "1"
+    if seq:
+        for n in seq:
+            pe.run(n); pg.run(n)
+            if do_sync:
+                print(pg.tick, "e=%d" % ((pg.tick - pg.ep_start) % pg.E), diff(snap(pe), snap(pg)))
+        print("final", pg.tick, diff(snap(pe), snap(pg)))
+        sys.exit(0)
+    step = int(os.environ.get("DBG_STEP", "1"))
+    for i in range(12):
+        pe.run(step); pg.run(step)
         print(pg.tick, "e=%d" % ((pg.tick - pg.ep_start) % pg.E), "graphs", pg.n_graph_launches, "eager", pg.n_eager_steps, diff(snap(pe), snap(pg)))
