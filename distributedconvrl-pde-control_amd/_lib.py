@@ -83,6 +83,7 @@ SIGNATURES = {
     "pdec_mlp_acts_on_published_copy": [Handle, C.POINTER(_i)],
     "pdec_noise_counter_set": [Handle, _u64], "pdec_noise_counter_get": [Handle, C.POINTER(_u64)],
     "pdec_reward_mean": [Handle, _vp, _i, _vp], "pdec_ddpg_set_reward_mean": [Handle, _vp],
+    "pdec_env_set_reward_partials_out": [Handle, _vp, C.POINTER(_i)], "pdec_ddpg_set_reward_partials": [Handle, _vp, _i],
     "pdec_ddpg_update_small_rng": [Handle] * 4 + [_vp] * 4 + [_i, _i, _u64, _u64, _i64, _i64, _i64, _i, _d, _d, _i, _d, _d, _vp],
     "pdec_replay_push_sa": [Handle, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _i64, _i],
     "pdec_replay_push_rt": [Handle, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i64, _i],

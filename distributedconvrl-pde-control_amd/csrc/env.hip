@@ -71,15 +71,19 @@ __device__ __forceinline__ float pow_abs<float>(float d, float p) {
 }
 
 // reward_function for one trajectory: dots = <y, g_s> of the species the reward looks at
+// (returns the sum of the rewards THIS thread wrote, for the optional per-workgroup reward sum)
 template <class T>
-__device__ __forceinline__ void reward_traj(const EnvDev<T>& e, const T* dots, const T* act, const T* actp,
-                                            T* r_out, int tid, int nt) {
+__device__ __forceinline__ T reward_traj(const EnvDev<T>& e, const T* dots, const T* act, const T* actp,
+                                         T* r_out, int tid, int nt) {
+  T mine = 0;
   if (!e.mono) {
     for (int a = tid; a < e.A; a += nt) {
       const int s = e.a2s[a];
       const T d = e.r_in_scale * (dots[s] + e.r_offset * e.gsum[s]);
       const T da = act[a] - actp[a];
-      r_out[a] = -pow_abs<T>(d, e.r_power) / e.r_denom - e.a_pun * act[a] * act[a] - e.da_pun * da * da;
+      const T r = -pow_abs<T>(d, e.r_power) / e.r_denom - e.a_pun * act[a] * act[a] - e.da_pun * da * da;
+      r_out[a] = r;
+      mine += r;
     }
   } else if (tid == 0) {
     T acc = 0;
@@ -90,7 +94,9 @@ __device__ __forceinline__ void reward_traj(const EnvDev<T>& e, const T* dots, c
       acc += -pow_abs<T>(d, e.r_power) / e.r_denom - e.a_pun * act[a] * act[a] - e.da_pun * da * da;
     }
     r_out[0] = acc / (T)e.A;
+    mine = acc / (T)e.A;
   }
+  return mine;
 }
 
 // featurize for one trajectory.  dots: [n_species][S]; state/prev: [A][ns] (or [1][S] mono)
@@ -744,12 +750,26 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   sense_dots<T>(e, [&](int r, int n) { return Rt[2 * n + r]; }, dots, part, tid, nt);
   const int rw = e.mono ? 1 : e.A;             // reward entries per trajectory
   const int sw = e.mono ? e.S : e.A * e.ns;    // state entries per trajectory
-  reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b0 * rw, tid, nt);
+  T rmine = reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b0 * rw, tid, nt);
   featurize_traj<T>(e, dots, state_prev ? state_prev + (size_t)b0 * sw : nullptr, state_out + (size_t)b0 * sw, tid, nt);
   if (has1) {
-    reward_traj<T>(e, dots + e.S, act + e.A, actp + e.A, reward_out + (size_t)b1 * rw, tid, nt);
+    rmine += reward_traj<T>(e, dots + e.S, act + e.A, actp + e.A, reward_out + (size_t)b1 * rw, tid, nt);
     featurize_traj<T>(e, dots + e.S, state_prev ? state_prev + (size_t)b1 * sw : nullptr,
                       state_out + (size_t)b1 * sw, tid, nt);
+  }
+  if (e.rsum_out) {
+    // per-workgroup reward sum (fixed order: lanes by xor-shuffle, then waves in order) for the batch-mean reward of the
+    // DDPG update's reward broadcast -- the critic pass then adds one partial per workgroup instead of re-reading all of r
+    float v = (float)rmine;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = (T)v;
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.f;
+      for (int i = 0; i < (nt + 63) / 64; ++i) tot += (float)red[i];
+      e.rsum_out[blockIdx.x] = tot;
+    }
   }
   if (done && e.check_max == 2) {
     // check_max_value == "reward" (src/PDEenv.jl:232-237): flag on max|reward|
@@ -1064,6 +1084,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.Wd = E.Wd; e.Cnt = E.Cnt;
   e.gsum = E.gsum.as<T>(); e.a2s = E.a2s.as<int>();
   e.term_out = static_cast<T*>(E.term_out);
+  e.rsum_out = E.rsum_out;
   e.c1 = E.c1.as<T>(); e.c2 = E.c2.as<T>(); e.c3 = E.c3.as<T>(); e.c4 = E.c4.as<T>(); e.g = E.g.as<T>();
   e.dhat = E.dhat.as<C2<T>>(); e.tw = E.tw.as<C2<T>>();
   e.fft = E.fft;
@@ -1320,6 +1341,16 @@ int pdec_env_set_terminal_out(pdec_handle h, void* terminal_per_column) {
   PDEC_REQUIRE(E->cfg.pde_kind != PDEC_PDE_FLUID_RK4 || !terminal_per_column,
                "pdec_env_set_terminal_out: not provided for the fluid environment (expand its done[B] flags)");
   E->term_out = terminal_per_column;
+  return PDEC_OK;
+}
+
+int pdec_env_set_reward_partials_out(pdec_handle h, void* partial_sums, int* n_partials) {
+  Env* E = lookup_as<Env>(h, Kind::Env);
+  if (!E) { set_error("pdec_env_set_reward_partials_out: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(E->cfg.pde_kind == PDEC_PDE_KS_CNAB2 || partial_sums == nullptr,
+               "pdec_env_set_reward_partials_out: provided by the fused KS step only (use pdec_reward_mean elsewhere)");
+  E->rsum_out = (float*)partial_sums;
+  if (n_partials) *n_partials = (E->cfg.B + 1) / 2;      // one workgroup integrates two trajectories
   return PDEC_OK;
 }
 

@@ -18,6 +18,7 @@ struct EnvDev {
   const T* GaC;          // [Cnt][N]  GaC[i][n] = ga_{(an0[n]+i) mod A}[n]   (coalesced over n)
   const int* an0;        // [N]       first actuator reaching cell n
   int Wd, Cnt;
+  float* rsum_out;       // optional [ceil(B/2)]: per-workgroup sum of the rewards it wrote (pdec_env_set_reward_partials_out)
   T* term_out;           // optional [B][cols per trajectory]: 1.0 where the trajectory blew up (pdec_env_set_terminal_out)
   const T* gsum;         // [S]     sum of each sensor kernel (reward offset term)
   const int* a2s;        // [A]
@@ -35,6 +36,7 @@ struct Env : Object {
   DevBuf stage;  // staging for the _host wrappers
   DevBuf roll;   // ping-pong buffers of pdec_rollout
   void* term_out = nullptr;
+  float* rsum_out = nullptr;
   FftPlan fft;
   int nthreads = 64;
   int r4_log = 0;        // 4 / 5: N = 256 / 1024 use the register-resident radix-4 FFT engine

@@ -19,6 +19,8 @@ struct Mlp : Object {
   DevBuf bpd;                        // double [2][2]
   int bp_sel = 0;
   bool bp_init = false;
+  const float* rpart_ext = nullptr;  // per-workgroup reward sums of the producer (pdec_ddpg_set_reward_partials), consumed likewise
+  int rpart_n = 0;
   const void* rbar_ext = nullptr;    // batch-mean reward reduced elsewhere (pdec_ddpg_set_reward_mean), consumed by the next critic pass
   DevBuf noise_ctr;                  // uint64 [2]: double-buffered exploration-noise counter of pdec_policy_act_rng_dev
   int nc_sel = 0;

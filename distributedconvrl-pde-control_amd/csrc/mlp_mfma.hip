@@ -213,6 +213,8 @@ struct FusedArgs {
   float gamma;
   int quirk;
   float* slab;                // chunk-major partial gradients, see store_pass
+  const float* rpart;         // != null: per-workgroup reward sums of the producer, nrpart of them (sum / Bu = batch mean)
+  int nrpart;
   const float* rbar_dev;      // != null: batch-mean reward already reduced by launch_rmean (batches beyond 32768 columns)
   int prio;                   // wave priority of the pass (PDEC_PRIO_MFMA, default 0)
   unsigned long long* stamps; // diagnostic only (PDEC_STAMPS=1): [gridDim.x][16] s_memtime at phase boundaries
@@ -267,7 +269,9 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   // mean reward for the reference's (1xBu).+(Bu) broadcast: every workgroup reduces all of r in the
   // same fixed order, so the value is identical everywhere
   float rsum = 0.f;
-  if (g.quirk && !g.rbar_dev) {   // 16-B loads, 8 in flight per lane: the L2 latency is paid per batch, not per element
+  if (g.quirk && g.rpart) {
+    for (int i = tid; i < g.nrpart; i += FTHREADS) rsum += g.rpart[i];
+  } else if (g.quirk && !g.rbar_dev) {   // 16-B loads, 8 in flight per lane: the L2 latency is paid per batch, not per element
     const int n4 = ((reinterpret_cast<uintptr_t>(g.r) & 15) == 0) ? g.Bu / 4 : 0;
     const f32x4* r4 = reinterpret_cast<const f32x4*>(g.r);
     int i = tid;
@@ -570,6 +574,7 @@ struct FinishArgs {
   double eta, b1, b2, eps, omb1p, omb2p;   // omb*p = 1 - beta^t: filled in by the kernel from `bp` (device resident)
   BpArgs bp;
   float rho, omr;
+  int prio;                    // wave priority (the update chain is the critical path: same level as the passes)
 };
 
 // Flux.Optimise.ADAM (Float64 arithmetic, as the broadcast promotes; src/custom_nna.jl:23-24), then
@@ -610,6 +615,7 @@ __device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float g
 // replicas stay bit-identical.
 __global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g_in) {
   FinishArgs g = g_in;
+  set_wave_prio(g.prio);
   if (g.apply) {      // the beta powers come from device memory; one thread of the grid writes the advanced pair
     g.omb1p = 1.0 - g.bp.cur[0];
     g.omb2p = 1.0 - g.bp.cur[1];
@@ -708,14 +714,15 @@ template <int MTA>
 __global__ __launch_bounds__(ACT_THREADS) void policy_act_fused_kernel(FNet f, const float* __restrict__ state, int cols, int ns,
                                                                       float act_noise, float lim, int learning, int tanh_out,
                                                                       uint64_t seed, uint64_t offset, float* __restrict__ out,
-                                                                      const uint64_t* ctr_cur, uint64_t* ctr_next, uint64_t ctr_inc) {
+                                                                      const uint64_t* ctr_cur, uint64_t* ctr_next, uint64_t ctr_inc,
+                                                                      int prio) {
   extern __shared__ __align__(16) float smem[];
   if (ctr_cur) {       // noise counter kept on the device (pdec_policy_act_rng_dev): read it, one thread writes the advanced value
     offset += *ctr_cur;
     if (blockIdx.x == 0 && threadIdx.x == 0) *ctr_next = offset + ctr_inc;
   }
-  // short latency-critical kernel (the PDE step waits for it): outrank the update passes it may share CUs with
-  __builtin_amdgcn_s_setprio(3);
+  // wave priority: PDEC_PRIO_ACT (default 3: short and latency-critical when nothing else holds the PDE step back)
+  set_wave_prio(prio);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
   const int HPa = 16 * MTA, LDWa = HPa + LDWPAD;
   float* sa = smem;                                  // small image
@@ -899,6 +906,7 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   g.grads = M->grads.as<float>(); g.scale = (float)grad_scale; g.mode = mode; g.Bu = Bu; g.quirk = quirk;
   g.loss_out = (float*)loss_dev;
   g.apply = ap != nullptr;
+  g.prio = env_prio("PDEC_PRIO_MFMA", 2);
   if (ap) {
     int rcb = bp_begin(M, ap->b1, ap->b2, &g.bp);
     if (rcb) return rcb;
@@ -944,15 +952,16 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
   PDEC_REQUIRE(A->acts[2] == PDEC_ACT_TANH || A->acts[2] == PDEC_ACT_IDENTITY, "fused act: unsupported output activation");
   PDEC_REQUIRE(mta <= 2 && lds <= 64 * 1024, "fused act: hidden width %d too large", A->dims[1]);
   ProfScope ps(A, "policy_act_fused");
+  const int prio = env_prio("PDEC_PRIO_ACT", 3);
   const dim3 grid((cols + 63) / 64), block(ACT_THREADS);
   if (mta == 1)
     hipLaunchKernelGGL(policy_act_fused_kernel<1>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
                        (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out, ctr_cur, ctr_next,
-                       ctr_inc);
+                       ctr_inc, prio);
   else
     hipLaunchKernelGGL(policy_act_fused_kernel<2>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
                        (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out, ctr_cur, ctr_next,
-                       ctr_inc);
+                       ctr_inc, prio);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
@@ -978,7 +987,9 @@ int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const vo
   g.Bu = Bu; g.ns = A->dims[0]; g.na = 1; g.gamma = (float)gamma; g.quirk = quirk;
   g.slab = C->fslab.as<float>();
   g.prio = env_prio("PDEC_PRIO_MFMA", 2);
-  if (quirk && C->rbar_ext) {          // reduced by the producer of r on its own stream (pdec_reward_mean): nothing to sum here
+  if (quirk && C->rpart_ext) {         // the producer of r left one partial sum per workgroup
+    g.rpart = C->rpart_ext; g.nrpart = C->rpart_n;
+  } else if (quirk && C->rbar_ext) {   // reduced by the producer of r on its own stream (pdec_reward_mean): nothing to sum here
     g.rbar_dev = (const float*)C->rbar_ext;
   } else if (quirk && Bu > 256 * FCOLS) {     // every workgroup summing all of r itself does not scale (C3: 131072 rewards): reduce once
     float* rb = nullptr;
@@ -986,6 +997,7 @@ int fused_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const vo
     g.rbar_dev = rb;
   }
   C->rbar_ext = nullptr;
+  C->rpart_ext = nullptr;
   if (mt == 9 && mta == 2) rc = launch_critic<9, 2>(C, g, grid);
   else if (mt == 9 && mta == 1) rc = launch_critic<9, 1>(C, g, grid);
   else if (mt == 2 && mta == 2) rc = launch_critic<2, 2>(C, g, grid);

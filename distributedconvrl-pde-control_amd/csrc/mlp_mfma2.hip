@@ -246,6 +246,7 @@ struct Fused2Args {
 
 // mean of r in a fixed order (one block): the batch-mean reward of the reference's (1xBu).+(Bu) broadcast
 __global__ __launch_bounds__(1024) void rmean_kernel(const float* __restrict__ r, int n, float* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);      // one short block; beside the update passes (priority 2) it would otherwise starve
   __shared__ float part[1024];
   const int tid = threadIdx.x;
   float acc = 0.f;
@@ -939,6 +940,17 @@ extern "C" int pdec_reward_mean(pdec_handle any_handle, const void* r, int n, vo
   ProfScope ps(o, "ddpg_rmean");
   hipLaunchKernelGGL(rmean_kernel, dim3(1), dim3(1024), 0, o->stream, (const float*)r, n, (float*)mean_out);
   PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+extern "C" int pdec_ddpg_set_reward_partials(pdec_handle critic, const void* partial_sums, int n) {
+  using namespace pdec;
+  Mlp* C = lookup_as<Mlp>(critic, Kind::Mlp);
+  if (!C) { set_error("pdec_ddpg_set_reward_partials: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(C->dtype == PDEC_F32 && n >= 0, "pdec_ddpg_set_reward_partials: fp32 critics only");
+  PDEC_REQUIRE(partial_sums == nullptr || fused_net_supported(C), "pdec_ddpg_set_reward_partials: 3-layer fused critics only");
+  C->rpart_ext = (const float*)partial_sums;
+  C->rpart_n = n;
   return PDEC_OK;
 }
 

@@ -21,6 +21,7 @@ the env stream at its first step and joins it at its last.  The first and the la
 (initial-condition pointers, time-out terminal flags; te / dt + 1 = 51 steps in scripts/KS/KS22) are issued eagerly.  Eager and replayed runs enqueue the same kernels with the same arguments and are
 bit-identical (tests/test_gpu_agent.py)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -65,7 +66,7 @@ class _TorchEvent:
 
 class TrainPipeline:
     def __init__(self, env, agent, lag=2, episode_steps=51, stream_env=None, stream_upd=None, use_graphs=True,
-                 chunks=(24, 6, 1), use_replay=False, noise_seed=1234, reward_partials=False):
+                 chunks=(24, 6, 1), use_replay=False, noise_seed=1234, kick_env_after_critic=None):
         """env: PDEenv on `stream_env`; agent: create_agent(..., stream=stream_upd).  lag: the update of step k trains on
         the transition of step k - lag (>= 1).  episode_steps: lock-stepped episodes of that many control steps (0: one
         endless episode): the last transition is terminal (done = time >= te, src/PDEenv.jl:227) and the next step starts
@@ -109,12 +110,27 @@ class TrainPipeline:
         # the reference's reward broadcast (quirk) needs the batch-mean reward: reduced on the env stream
         # right behind the env step instead of by every workgroup of the critic pass
         self.pre_rbar = bool(self.policy.quirk) and dt == torch.float32 and not self.use_replay
+        # ... and for the fused KS step + 3-layer fused critic without any extra launch: the env step leaves one reward sum
+        # per workgroup, the critic pass adds them
+        self.rpart, self.n_rpart = None, 0
+        if self.pre_rbar:
+            npart = C.c_int()
+            probe = torch.zeros((B + 1) // 2, dtype=torch.float32, device=dev)
+            ok = self.lib.pdec_env_set_reward_partials_out(env.handle, _lib.ptr(probe), C.byref(npart)) == 0
+            hc = self.policy.behavior_critic.model.handle
+            ok = ok and self.lib.pdec_ddpg_set_reward_partials(hc, _lib.ptr(probe), npart.value) == 0    # refused unless fused 3-layer
+            self.lib.pdec_ddpg_set_reward_partials(hc, None, 0)
+            self.lib.pdec_env_set_reward_partials_out(env.handle, None, None)
+            if ok:
+                self.n_rpart = npart.value
+                self.rpart = [torch.zeros(self.n_rpart, dtype=torch.float32, device=dev) for _ in range(3)]
         import os
         Ev = _TorchEvent if os.environ.get("PDEC_TORCH_EVENTS") == "1" else _Event
         self.ev_fork = Ev(self.lib)
         self.ev_act = [Ev(self.lib), Ev(self.lib)]                  # act_k issued (env stream)
         self.ev_upd = [Ev(self.lib), Ev(self.lib)]                  # update_k issued (update stream)
         self.ev_graph = Ev(self.lib)                                # tail of the last graph launch (env stream)
+        self.ev_mid = Ev(self.lib)                                  # critic half of update_k done (update stream)
         self._after_graph = False
         self.tick = 0             # control steps issued so far: every buffer of step k is indexed by k mod 2 / 3 / 6
         self.ep_start = 0         # tick of the first step of the current episode
@@ -126,6 +142,11 @@ class TrainPipeline:
         # update's actor half while act_k still runs: that half then waits for act_k (the fused 3-layer path reads a
         # published copy instead and needs no such edge)
         self.act_in_place = not bool(yes.value)
+        # start env_k behind the critic half of update_k instead of beside the critic pass (see _issue); for the
+        # reference-shaped 2-layer nets the env branch is as long as the whole update, so it is not held back there
+        self.kick_env_after_critic = (not self.act_in_place) if kick_env_after_critic is None else bool(kick_env_after_critic)
+        if os.environ.get("PDEC_KICK") in ("0", "1"):               # diagnostic override
+            self.kick_env_after_critic = os.environ["PDEC_KICK"] == "1"
         self._sp_env, self._sp_upd = C.c_void_p(self.s_env.cuda_stream), C.c_void_p(self.s_upd.cuda_stream)
         self.graphs = {}          # (chunk, pos) -> graph handle
         self._captured = False
@@ -187,37 +208,64 @@ class TrainPipeline:
             L.check(lib.pdec_set_stream(self.actor.handle, self._sp_upd))
             if not self.serial and self.LAG >= 2:
                 self.ev_act[k % 2].record(self.s_env)
-            L.check(lib.pdec_env_set_terminal_out(env.handle, L.ptr(term)))
-            L.check(lib.pdec_env_step(env.handle, L.ptr(y_in), L.ptr(act), L.ptr(act_prev), L.ptr(s_in), L.ptr(y_out),
-                                      L.ptr(self.pbuf), L.ptr(s_out), L.ptr(rew), L.ptr(flags)))
-            if last:
-                term.fill_(1.0)                        # time-out: done = time >= te -> terminal transition
-            if self.pre_rbar:
-                L.check(lib.pdec_reward_mean(env.handle, L.ptr(rew), self.cols, L.ptr(self.rbar[k % 3])))
-            if self.use_replay:
-                self._replay_push(k, s_in, act, rew, term, s_out, first, last)
-            if not self.serial and self.LAG < 2:
-                # LAG = 1: update_{k+1} trains on the transition env_k is producing, so the event it waits on is
-                # recorded behind the whole env branch, not behind the acting kernel
-                self.ev_act[k % 2].record(self.s_env)
-        if self.drain_between:                         # kernel-timing pass: nothing of the env branch overlaps the update
+        if self.drain_between:
             torch.cuda.synchronize()
-        with torch.cuda.stream(self.s_upd):
-            j = k - self.LAG
-            if j >= self._first_tick:
+
+        def env_part():
+            with torch.cuda.stream(self.s_env):
+                L.check(lib.pdec_env_set_terminal_out(env.handle, L.ptr(term)))
+                if self.rpart is not None:
+                    L.check(lib.pdec_env_set_reward_partials_out(env.handle, L.ptr(self.rpart[k % 3]), None))
+                L.check(lib.pdec_env_step(env.handle, L.ptr(y_in), L.ptr(act), L.ptr(act_prev), L.ptr(s_in), L.ptr(y_out),
+                                          L.ptr(self.pbuf), L.ptr(s_out), L.ptr(rew), L.ptr(flags)))
+                if last:
+                    term.fill_(1.0)                    # time-out: done = time >= te -> terminal transition
+                if self.pre_rbar and self.rpart is None:
+                    L.check(lib.pdec_reward_mean(env.handle, L.ptr(rew), self.cols, L.ptr(self.rbar[k % 3])))
                 if self.use_replay:
+                    self._replay_push(k, s_in, act, rew, term, s_out, first, last)
+                if not self.serial and self.LAG < 2:
+                    # LAG = 1: update_{k+1} trains on the transition env_k is producing, so the event it waits on is
+                    # recorded behind the whole env branch, not behind the acting kernel
+                    self.ev_act[k % 2].record(self.s_env)
+            if self.drain_between:                     # kernel-timing pass: nothing of the env branch overlaps the update
+                torch.cuda.synchronize()
+
+        j = k - self.LAG
+        batch = None
+        if j >= self._first_tick:
+            if self.use_replay:
+                with torch.cuda.stream(self.s_upd):
                     batch = self._replay_batch()
+            else:
+                batch = dict(state=self.sring[j % PERIOD].view(self.cols, self.ns), action=self.aring[j % 3].view(self.cols, self.na),
+                             reward=self.rring[j % 3].view(self.cols), terminal=self.tring[j % 3].view(self.cols),
+                             next_state=self.sring[(j + 1) % PERIOD].view(self.cols, self.ns))
+        kick = self.kick_env_after_critic and batch is not None and not self.serial
+        if not kick:
+            env_part()
+
+        def between_halves():
+            # Beside the critic pass the PDE step makes almost no progress and then collides with the whole actor pass;
+            # released when the critic half (pass + reduction) is done it runs beside the actor pass, the second
+            # reduction and the head of the next critic pass instead (r02i, same box: 152 -> 130 us per control step)
+            if kick:
+                self.ev_mid.record(self.s_upd)
+                self.ev_mid.wait(self.s_env)
+                env_part()
+            if self.act_in_place and not self.serial:
+                self.ev_act[k % 2].wait(self.s_upd)
+
+        with torch.cuda.stream(self.s_upd):
+            if batch is not None:
+                if self.rpart is not None:
+                    L.check(lib.pdec_ddpg_set_reward_partials(pol.behavior_critic.model.handle, L.ptr(self.rpart[j % 3]), self.n_rpart))
+                elif self.pre_rbar:
+                    L.check(lib.pdec_ddpg_set_reward_mean(pol.behavior_critic.model.handle, L.ptr(self.rbar[j % 3])))
+                if kick or (self.act_in_place and not self.serial):
+                    pol.update(batch, before_actor_half=between_halves)
                 else:
-                    batch = dict(state=self.sring[j % PERIOD].view(self.cols, self.ns), action=self.aring[j % 3].view(self.cols, self.na),
-                                 reward=self.rring[j % 3].view(self.cols), terminal=self.tring[j % 3].view(self.cols),
-                                 next_state=self.sring[(j + 1) % PERIOD].view(self.cols, self.ns))
-                if batch is not None:
-                    if self.pre_rbar:
-                        L.check(lib.pdec_ddpg_set_reward_mean(pol.behavior_critic.model.handle, L.ptr(self.rbar[j % 3])))
-                    if self.act_in_place and not self.serial:
-                        pol.update(batch, before_actor_half=lambda: self.ev_act[k % 2].wait(self.s_upd))
-                    else:
-                        pol.update(batch)
+                    pol.update(batch)
             if not self.serial:
                 self.ev_upd[k % 2].record(self.s_upd)
         if chunk_last and not self.serial:

@@ -314,6 +314,11 @@ int pdec_ddpg_update_small(pdec_handle A, pdec_handle C, pdec_handle At, pdec_ha
  * r -- the env step -- does it beside the running update) and pdec_ddpg_set_reward_mean hands the device scalar to the
  * NEXT critic pass of `critic`, which then does not read r for the mean (one hand-over per update; fp32 fused paths). */
 int pdec_reward_mean(pdec_handle any_handle, const void* r, int n, void* mean_out);
+/* the same without any extra launch for the fused KS step + 3-layer fused critic: every later pdec_env_step also writes the
+ * sum of the rewards of each of its workgroups (two trajectories each) to partial_sums [*n_partials] (fp32; NULL switches it
+ * off), and pdec_ddpg_set_reward_partials hands them to the next critic pass, which adds them in a fixed order. */
+int pdec_env_set_reward_partials_out(pdec_handle env, void* partial_sums, int* n_partials);
+int pdec_ddpg_set_reward_partials(pdec_handle critic, const void* partial_sums, int n);
 int pdec_ddpg_set_reward_mean(pdec_handle critic, const void* mean_dev);
 
 /* the same with pde_sample (src/PDEagent.jl:317-321) INSIDE the kernel: draw k = loop * Bu + column is word k % 4 of the
