@@ -104,6 +104,30 @@ _RESTYPES = {"pdec_last_error": C.c_char_p}
 _lib = None
 
 
+class _Lib:
+    """The loaded library.  Attribute access returns the C functions; while `record_into(list)` is active every call is
+    also appended to the list as (function, args) -- pipeline.py replays such a list to re-issue a control step whose
+    arguments are those of an earlier one without going through the Python layers again."""
+
+    def __init__(self, cdll):
+        self._c = cdll
+        self._rec = None
+
+    def __getattr__(self, name):
+        f = getattr(self._c, name)
+
+        def call(*a, _f=f):
+            if self._rec is not None:
+                self._rec.append((_f, a))
+            return _f(*a)
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+    def record_into(self, calls):
+        self._rec = calls
+
+
 def load():
     """Load libpdeconv.so (once).  Raises PdecError if it has not been built."""
     global _lib
@@ -120,8 +144,8 @@ def load():
         fn.restype = C.c_int
     lib.pdec_last_error.argtypes = []
     lib.pdec_last_error.restype = C.c_char_p
-    _lib = lib
-    return lib
+    _lib = _Lib(lib)
+    return _lib
 
 
 def check(rc):

@@ -429,6 +429,17 @@ def test_graph_replay_is_bit_identical_to_the_eager_pipeline(pkg, lag, two_layer
         for x, y in zip(getattr(pe.policy, n).model.params(), getattr(pg.policy, n).model.params()):
             assert np.array_equal(x, y), n
     assert bool(torch.isfinite(pg.y).all()) and pe.policy.losses() == pg.policy.losses()
+    # the eager pipeline replays recorded library calls for interior steps (pipeline._eager); issued through the Python
+    # layers every step it must give the same numbers
+    ps = _make_pipeline(pkg, False, lag=lag, two_layer=two_layer)
+    ps.fast_eager = False
+    ps.run(pe.tick)
+    ps.sync()
+    assert len(pe._progs) == 6 and not ps._progs
+    assert torch.equal(ps.y, pe.y) and torch.equal(ps.state, pe.state)
+    for n in ("behavior_actor", "behavior_critic"):
+        for x, y in zip(getattr(ps.policy, n).model.params(), getattr(pe.policy, n).model.params()):
+            assert np.array_equal(x, y), n
     import ctypes as C
     nn_ = C.c_int()
     pkg._lib.check(pg.lib.pdec_graph_num_nodes(pg.graphs[(6, 0)], C.byref(nn_)))
