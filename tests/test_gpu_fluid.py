@@ -277,3 +277,40 @@ def test_config_c5_full_size_shard_properties(pkg):
     m0 = _jul(env.y)[:, 0, 0]
     assert np.abs(m0 - y[:, 0, 0]).max() <= 1e-9 * max(1.0, np.abs(y).max())
     assert not bool(env.done.any())
+
+
+def test_reference_trained_fluid_actor_closed_loop(pkg):
+    """row F3: the actor the reference trained for Fluid_8 (hook.bestNNA 9 -> 18 -> 1; fixture from
+    scripts/Fluid/Fluid_8/saves/hook.jld2 -- the hook holds no trajectory, collect_bestDF = false) driven closed-loop on this
+    path at the reference's own training grid (128 x 128, 8 x 8 sensors, variance 0.08, K = floor(16 nx dt) = 40 RK4
+    sub-steps per control step): three control steps of policy -> prepare_action -> do_step -> reward -> featurize from a
+    random-vortex initial condition follow the oracle's loop (fp64; actions <= 1e-9, spectra <= 1e-10 relative)."""
+    from oracle import fluid, nn
+    from util import load_golden
+    g = load_golden("fluid8_hook.npz")
+    best = [g["best_W1"], g["best_b1"], g["best_W2"], g["best_b2"]]
+    setup, cfg = _pair(pkg, 128, 1, spa=8, variance=0.08)
+    assert setup.oversampling == 40 and setup.state_shape == (9, 64)
+    y0 = fluid.ic(cfg, 3, np.random.default_rng(5))
+    env = pkg.PDEenv(setup, B=1, dtype=F64, y0=y0[None])
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), dtype=torch.float32)
+    assert agent.policy.behavior_actor.model.dims == [9, 18, 1]
+    pkg.checkpoint.load_actor(agent.policy.behavior_actor, best)
+    agent.policy.start_steps = -1
+    P = [b.astype(np.float64) for b in best]
+    y, a_prev = y0.copy(), np.zeros((1, 64))
+    state = fluid.featurize(cfg, y)
+    assert np.abs(env.state[0].cpu().numpy().T - state).max() <= 1e-11 * max(1.0, np.abs(state).max())
+    for k in range(3):
+        a = np.clip(nn.forward(P, [nn.RELU, nn.TANH], state), -1, 1)
+        p = fluid.prepare_action(cfg, a)
+        y = fluid.do_step(cfg, y, p, 40)
+        r = fluid.reward_function(cfg, y, a, a - a_prev)
+        state, a_prev = fluid.featurize(cfg, y), a
+        act = agent.policy(env, learning=False)
+        env(act)
+        assert np.abs(env.action_julia() - a).max() <= 1e-9
+        assert np.abs(env.y_julia() - y).max() <= 1e-10 * np.abs(y).max()
+        assert np.abs(env.reward[0].cpu().numpy() - r).max() <= 1e-9 * max(1.0, np.abs(r).max())
+        assert np.abs(env.state[0].cpu().numpy().T - state).max() <= 1e-9 * max(1.0, np.abs(state).max())
+    assert not bool(env.done.any())
