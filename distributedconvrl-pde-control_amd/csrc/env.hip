@@ -16,6 +16,7 @@
 // a control step run out of LDS (mixed-radix Stockham); per-mode state lives in registers;
 // HBM sees only the compulsory traffic (y, action in; y, state, reward, done out).
 #include "env.hpp"
+#include "mlp.hpp"
 
 namespace pdec {
 
@@ -181,6 +182,7 @@ __device__ __forceinline__ void write_terminal(const EnvDev<T>& e, int b, bool f
 // Generic engine: mixed-radix Stockham through LDS (any N = 2^a 3^b 5^c).
 template <class T>
 struct FftGeneric {
+  static constexpr int kThreads = 1024;     // largest workgroup the host launches this engine with
   C2<T>*X, *Y;
   const C2<T>* tw;
   FftPlan pl;
@@ -235,6 +237,7 @@ struct FftR4 {
   C2<T> w[L - 1][3];
   int tid, par;
   static constexpr int N = 1 << (2 * L), NT = N / 4;
+  static constexpr int kThreads = (NT + 63) / 64 * 64;
   __device__ __forceinline__ void init(unsigned char* smem, const EnvDev<T>& e, int tid_, int) {
     tid = tid_; par = 0;
     buf[0] = reinterpret_cast<C2<T>*>(smem);
@@ -445,6 +448,7 @@ __device__ __forceinline__ void pk_dft4(C2<float> (&a)[4]) {
 
 template <class T>
 struct FftWave256 {
+  static constexpr int kThreads = 64;
   C2<T>* buf;
   C2<T> w[3][3];       // twiddles of the three inner stages, per lane
   int tid;
@@ -532,6 +536,8 @@ struct FftFixed {
   int tid;
   static constexpr int rad(int i) { return i == 0 ? R0 : (i == 1 ? R1 : (i == 2 ? R2 : (i == 3 ? R3 : R4))); }
   static constexpr int M0 = N / R0, ML = N / rad(L - 1);
+  static constexpr int max_m(int i) { return i >= L ? 0 : (N / rad(i) > max_m(i + 1) ? N / rad(i) : max_m(i + 1)); }
+  static constexpr int kThreads = (max_m(0) + 63) / 64 * 64;
   __device__ __forceinline__ void init(unsigned char* smem, const EnvDev<T>& e, int tid_, int nt) {
     tid = tid_;
     buf[0] = reinterpret_cast<C2<T>*>(smem);
@@ -784,6 +790,338 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
         write_terminal<T>(e, b0 + t, m > 0, 0, 1);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------ persistent KS rollout (row F2)
+// T control steps of  action = clamp(actor(state) + randn * act_noise);  (env::PDEenv)(action)  in ONE launch
+// (src/PDEagent.jl:175-209 + src/PDEenv.jl:195-241 + the KS closures of KSSetup.jl:130-245): the two trajectories of a
+// workgroup stay in registers between steps, their sensor dots / state / actions in LDS; nothing returns to HBM between
+// steps but the optional log rows PDEhook records.  The actor (a chain of <= 3 Dense layers, widths <= RO_W, one output)
+// is evaluated one column per lane on the vector unit from a copy of its parameters in LDS; exploration noise from the
+// same Philox element numbering as pdec_policy_act_rng (element = global column, counter offset + t * ceil(cols / 4)).
+#define RO_W 32            // widest layer the in-kernel actor holds in registers
+struct RollActor {
+  const void* params;      // flat [W1 row-major [out][in], b1, W2, b2, ...] in the environment's dtype
+  int L, nparams, rows;    // rows = widest layer: the height of an activation plane
+  int dims[4], acts[3];
+};
+template <class T>
+struct RollArgs {
+  int steps, learning;
+  T act_noise, act_limit;
+  uint64_t seed, offset;
+  T *y, *state, *action;                   // in / out: [B][N], [B][A][ns], [B][A]
+  T* reward_sum;                           // optional [B][A]: += every step's reward
+  T *log_y, *log_p, *log_action, *log_reward;   // optional [steps][B][...]
+  int32_t *done_any, *done_step;           // optional [B]
+};
+
+template <class T>
+__device__ __forceinline__ T ro_act_fn(T z, int act) {
+  if (act == PDEC_ACT_RELU) return z > (T)0 ? z : (T)0;
+  if (act == PDEC_ACT_TANH) return (T)tanh((double)z);
+  return z;
+}
+template <>
+__device__ __forceinline__ float ro_act_fn<float>(float z, int act) {
+  if (act == PDEC_ACT_RELU) return fmaxf(z, 0.f);
+  if (act == PDEC_ACT_TANH) return tanhf(z);
+  return z;
+}
+
+// LDS image of the actor: per layer Wt[din][RO_W] (transposed, outputs zero-padded to RO_W) followed by b[RO_W], so the
+// RO_NB consecutive outputs a thread owns are contiguous (broadcast 128-bit reads).
+#define RO_NB 16
+__host__ __device__ inline int ro_image_elems(const int* dims, int L) {
+  int n = 0;
+  for (int l = 0; l < L; ++l) n += (dims[l] + 1) * RO_W;
+  return n;
+}
+template <class T>
+__device__ __forceinline__ void ro_load_image(const RollActor& A, T* wl, int tid, int nt) {
+  const T* src = static_cast<const T*>(A.params);
+  int so = 0, dof = 0;
+  for (int l = 0; l < A.L; ++l) {
+    const int din = A.dims[l], dout = A.dims[l + 1];
+    for (int i = tid; i < (din + 1) * RO_W; i += nt) {
+      const int r = i / RO_W, o = i - r * RO_W;                    // r < din: weight row, r == din: bias
+      wl[dof + i] = o < dout ? (r < din ? src[so + o * din + r] : src[so + din * dout + o]) : (T)0;
+    }
+    so += din * dout + dout;
+    dof += (din + 1) * RO_W;
+  }
+}
+
+// actor forward for ONE PAIR of adjacent columns per thread (packed v_pk_fma_f32 for fp32): the activations of the pair
+// sit in two LDS planes hb[plane][i][slot] private to the thread (bank = lane: conflict-free, no barrier between layers),
+// the weights are broadcast 128-bit reads of the image; outputs in blocks of RO_NB accumulators, inputs four at a time so
+// the LDS reads of four k-steps are in flight together; k-ordered accumulation like the oracle's W * x + b.
+template <class T> struct RoPair {
+  typedef T type __attribute__((ext_vector_type(2)));
+  typedef T quad __attribute__((ext_vector_type(4), aligned(16)));
+};
+// NB outputs [ob, ob + NB) of one layer for the thread's column pair: acc = b + sum_i W[.][i] * in[i]
+template <class T, int NB>
+__device__ __forceinline__ void ro_block(const T* __restrict__ Wt, int din, int dout, int ob, int act,
+                                         const typename RoPair<T>::type* pin, typename RoPair<T>::type* pout, int nslot) {
+  using T2 = typename RoPair<T>::type;
+  using T4 = typename RoPair<T>::quad;
+  T2 acc[NB];
+  T4 w[4][NB / 4];
+#pragma unroll
+  for (int v = 0; v < NB / 4; ++v) {
+    const T4 b4 = *reinterpret_cast<const T4*>(Wt + din * RO_W + 4 * v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[4 * v + r] = T2{b4[r], b4[r]};
+  }
+  int i = 0;
+  for (; i + 4 <= din; i += 4) {
+    T2 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = pin[(size_t)(i + u) * nslot];
+#pragma unroll
+      for (int v = 0; v < NB / 4; ++v) w[u][v] = *reinterpret_cast<const T4*>(Wt + (i + u) * RO_W + 4 * v);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] += w[u][j >> 2][j & 3] * a[u];
+  }
+  for (; i < din; ++i) {
+    const T2 a0 = pin[(size_t)i * nslot];
+#pragma unroll
+    for (int v = 0; v < NB / 4; ++v) w[0][v] = *reinterpret_cast<const T4*>(Wt + i * RO_W + 4 * v);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] += w[0][j >> 2][j & 3] * a0;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (ob + j < dout) pout[(size_t)(ob + j) * nslot] = T2{ro_act_fn<T>(acc[j].x, act), ro_act_fn<T>(acc[j].y, act)};
+}
+template <class T>
+__device__ __forceinline__ typename RoPair<T>::type ro_actor_pair(const RollActor& A, const T* __restrict__ wl,
+                                                                  typename RoPair<T>::type* hb, int slot, int nslot) {
+  using T2 = typename RoPair<T>::type;
+  T2* pin = hb + slot;
+  T2* pout = hb + (size_t)A.rows * nslot + slot;
+  int off = 0;
+  for (int l = 0; l < A.L; ++l) {
+    const int din = A.dims[l], dout = A.dims[l + 1], act = A.acts[l];
+    int ob = 0;
+    for (; dout - ob > 4; ob += RO_NB) ro_block<T, RO_NB>(wl + off + ob, din, dout, ob, act, pin, pout, nslot);
+    if (ob < dout) ro_block<T, 4>(wl + off + ob, din, dout, ob, act, pin, pout, nslot);
+    T2* tmp = pin; pin = pout; pout = tmp;
+    off += (din + 1) * RO_W;
+  }
+  return pin[0];
+}
+
+template <class T, class ENG>
+__global__ void __launch_bounds__(ENG::kThreads) ks_rollout_kernel(EnvDev<T> e, RollActor actor, RollArgs<T> g) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = e.N, tid = threadIdx.x, nt = blockDim.x, A = e.A, ns = e.ns;
+  set_wave_prio(e.prio);
+  ENG eng;
+  eng.init(smem_raw, e, tid, nt);
+  T* act = reinterpret_cast<T*>(reinterpret_cast<C2<T>*>(smem_raw) + ENG::lds_complex(N));  // [2][A] current
+  T* actp = act + 2 * A;                  // [2][A] previous
+  T* dots = actp + 2 * A;                 // [2][S]
+  T* part = dots + 2 * e.S;               // [8][2][S]
+  T* red = part + 16 * e.S;               // [16]
+  T* stl = red + 16;                      // [2][A * ns]  state of both trajectories
+  T* rsum = stl + 2 * A * ns;             // [2][A]       accumulated reward
+  T* rnow = rsum + 2 * A;                 // [2][A]       this step's reward
+  const size_t wl_off = (size_t)(reinterpret_cast<unsigned char*>(rnow + 2 * A) - smem_raw + 15) & ~(size_t)15;
+  T* wl = reinterpret_cast<T*>(smem_raw + wl_off);   // actor image, 16-byte aligned rows
+  using T2 = typename RoPair<T>::type;
+  T2* hb = reinterpret_cast<T2*>(wl + ((ro_image_elems(actor.dims, actor.L) + 3) & ~3));   // [2][rows][nt] column pairs
+
+  const int b0 = 2 * blockIdx.x, b1 = b0 + 1;
+  const bool has1 = b1 < e.B;
+  const size_t o0 = (size_t)b0 * N, o1 = (size_t)b1 * N;
+  const size_t cols = (size_t)e.B * A;
+
+  ro_load_image<T>(actor, wl, tid, nt);
+  for (int i = tid; i < A * ns; i += nt) {
+    stl[i] = g.state[(size_t)b0 * A * ns + i];
+    stl[A * ns + i] = has1 ? g.state[(size_t)b1 * A * ns + i] : (T)0;
+  }
+  for (int a = tid; a < A; a += nt) {
+    act[a] = g.action[(size_t)b0 * A + a];
+    act[A + a] = has1 ? g.action[(size_t)b1 * A + a] : (T)0;
+    rsum[a] = rsum[A + a] = 0;
+  }
+  C2<T> U[KS_MPT], Nn[KS_MPT], Ck[KS_MPT], v[KS_MPT];
+  T kc1[KS_MPT], kc2[KS_MPT], kc3[KS_MPT], kg[KS_MPT], kc4[KS_MPT];
+  C2<T> kd[KS_MPT];
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {      // per-mode constants (mode layout of the engine) and the initial fields
+    const int k = eng.mode_index(j);
+    const bool ok = k < N;
+    kc1[j] = ok ? e.c1[k] : (T)0; kc2[j] = ok ? e.c2[k] : (T)0; kc3[j] = ok ? e.c3[k] : (T)0;
+    kc4[j] = ok ? e.c4[k] : (T)0; kg[j] = ok ? e.g[k] : (T)0;
+    kd[j] = ok ? e.dhat[k] : mk<T>(0, 0);
+    const int n = eng.phys_index(j);
+    U[j] = n < N ? mk<T>(g.y[o0 + n], has1 ? g.y[o1 + n] : (T)0) : mk<T>(0, 0);
+  }
+  int flag0 = 0, flag1 = 0, first0 = -1, first1 = -1;
+  const T invN = (T)1 / (T)N;
+  __syncthreads();
+
+  for (int t = 0; t < g.steps; ++t) {
+    // ---- policy (src/PDEagent.jl:183-207): one pair of adjacent columns of the [2][A] column space per thread
+    for (int q0 = 0; q0 < A; q0 += nt) {
+      const int q = q0 + tid;
+      if (q < A) {
+        const int idx0 = 2 * q;
+        for (int i = 0; i < ns; ++i) hb[(size_t)i * nt + tid] = T2{stl[(size_t)idx0 * ns + i], stl[(size_t)(idx0 + 1) * ns + i]};
+        const T2 o2 = ro_actor_pair<T>(actor, wl, hb, tid, nt);
+        uint64_t cprev = ~0ull;
+        double rad = 0, ang = 0;
+        uint32_t ph[4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int idx = idx0 + s, r = idx / A, a = idx - r * A;
+          T o = s == 0 ? o2.x : o2.y;
+          if (g.learning && (r == 0 || has1)) {
+            const uint64_t c = (uint64_t)(r == 0 ? b0 : b1) * A + a;          // global column = element of the noise stream
+            if ((c >> 2) != cprev) {
+              const uint64_t ctr = g.offset + (uint64_t)t * ((cols + 3) / 4) + (c >> 2);
+              ph[0] = (uint32_t)ctr; ph[1] = (uint32_t)(ctr >> 32); ph[2] = 0u; ph[3] = 0u;
+              philox4x32(ph, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+              cprev = c >> 2;
+            }
+            if (s == 0 || (c & 1) == 0) {      // the odd element shares the Box-Muller pair of its even neighbour
+              const int hsel = (int)((c >> 1) & 1);
+              const double sc = 1.0 / 4294967296.0;
+              const double u1 = ((double)ph[2 * hsel] + 0.5) * sc, u2 = ((double)ph[2 * hsel + 1] + 0.5) * sc;
+              rad = sqrt(-2.0 * log(u1)); ang = 6.283185307179586 * u2;
+            }
+            o += (T)((c & 1) ? rad * sin(ang) : rad * cos(ang)) * g.act_noise;
+          }
+          o = o < -g.act_limit ? -g.act_limit : (o > g.act_limit ? g.act_limit : o);
+          actp[idx] = act[idx];
+          act[idx] = (r == 0 || has1) ? o : (T)0;
+        }
+      }
+    }
+    __syncthreads();
+    if (g.log_action)
+      for (int a = tid; a < A; a += nt) {
+        g.log_action[((size_t)t * e.B + b0) * A + a] = act[a];
+        if (has1) g.log_action[((size_t)t * e.B + b1) * A + a] = act[A + a];
+      }
+    // ---- prepare_action -> spectrum -> constant term of the CNAB2 update (KSSetup.jl:231-245, :155)
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int n = eng.phys_index(j);
+      T pa = 0, pb = 0;
+      if (n < N) {
+        actuate_cell2<T>(e, act, act + A, n, pa, pb);
+        if (!has1) pb = 0;
+        if (g.log_p) {
+          g.log_p[((size_t)t * e.B + b0) * N + n] = pa;
+          if (has1) g.log_p[((size_t)t * e.B + b1) * N + n] = pb;
+        }
+      }
+      v[j] = mk<T>(pa, pb);
+    }
+    eng.template run<-1>(v);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j)
+      Ck[j] = mk<T>(kc4[j] * v[j].x + (kd[j].x - kd[j].y), kc4[j] * v[j].y + (kd[j].x + kd[j].y));
+    // ---- do_step (KSSetup.jl:130-160): Nn = G fft(u^2), u_hat = fft(u), K CNAB2 sub-steps, y+ = real(ifft(u_hat))
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) v[j] = mk<T>(U[j].x * U[j].x, U[j].y * U[j].y);
+    eng.template run<-1>(v);
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) Nn[j] = cscale(mul_i<+1, T>(v[j]), kg[j]);
+    eng.template run<-1>(U);
+    for (int it = 0; it < e.K; ++it) {
+#pragma unroll
+      for (int j = 0; j < KS_MPT; ++j) v[j] = U[j];
+      eng.template run<+1>(v);
+#pragma unroll
+      for (int j = 0; j < KS_MPT; ++j) {
+        const T wr = v[j].x * invN, wi = v[j].y * invN;
+        v[j] = mk<T>(wr * wr, wi * wi);
+      }
+      eng.template run<-1>(v);
+#pragma unroll
+      for (int j = 0; j < KS_MPT; ++j) {
+        const C2<T> nn1 = Nn[j];
+        Nn[j] = cscale(mul_i<+1, T>(v[j]), kg[j]);
+        U[j] = mk<T>(kc1[j] * U[j].x + kc2[j] * Nn[j].x - kc3[j] * nn1.x + Ck[j].x,
+                     kc1[j] * U[j].y + kc2[j] * Nn[j].y - kc3[j] * nn1.y + Ck[j].y);
+      }
+    }
+    eng.template run<+1>(U);
+    T mx0 = 0, mx1 = 0;
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) {
+      const int n = eng.phys_index(j);
+      U[j] = mk<T>(U[j].x * invN, U[j].y * invN);
+      if (n < N) {
+        if (g.log_y) {
+          g.log_y[((size_t)t * e.B + b0) * N + n] = U[j].x;
+          if (has1) g.log_y[((size_t)t * e.B + b1) * N + n] = U[j].y;
+        }
+        if (!(fabs(U[j].x) <= e.max_value)) mx0 = 1;
+        if (!(fabs(U[j].y) <= e.max_value)) mx1 = 1;
+      }
+    }
+    if (e.check_max == 1) {
+      mx0 = block_max<T>(mx0, red, tid, nt);
+      mx1 = block_max<T>(mx1, red, tid, nt);
+      if (mx0 > 0) { flag0 = 1; if (first0 < 0) first0 = t; }
+      if (mx1 > 0) { flag1 = 1; if (first1 < 0) first1 = t; }
+    }
+    // ---- reward (KSSetup.jl:162-178) and featurize (:190-229) from the sensor dots of the new field
+    const T* Rt = reinterpret_cast<const T*>(eng.publish(U));
+    sense_dots<T>(e, [&](int r, int n) { return Rt[2 * n + r]; }, dots, part, tid, nt);
+    reward_traj<T>(e, dots, act, actp, rnow, tid, nt);
+    featurize_traj<T>(e, dots, nullptr, stl, tid, nt);
+    if (has1) {
+      reward_traj<T>(e, dots + e.S, act + A, actp + A, rnow + A, tid, nt);
+      featurize_traj<T>(e, dots + e.S, nullptr, stl + A * ns, tid, nt);
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += nt) {
+      rsum[a] += rnow[a];
+      rsum[A + a] += rnow[A + a];
+      if (g.log_reward) {
+        g.log_reward[((size_t)t * e.B + b0) * A + a] = rnow[a];
+        if (has1) g.log_reward[((size_t)t * e.B + b1) * A + a] = rnow[A + a];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- results back to HBM
+#pragma unroll
+  for (int j = 0; j < KS_MPT; ++j) {
+    const int n = eng.phys_index(j);
+    if (n < N) {
+      g.y[o0 + n] = U[j].x;
+      if (has1) g.y[o1 + n] = U[j].y;
+    }
+  }
+  for (int i = tid; i < A * ns; i += nt) {
+    g.state[(size_t)b0 * A * ns + i] = stl[i];
+    if (has1) g.state[(size_t)b1 * A * ns + i] = stl[A * ns + i];
+  }
+  for (int a = tid; a < A; a += nt) {
+    g.action[(size_t)b0 * A + a] = act[a];
+    if (has1) g.action[(size_t)b1 * A + a] = act[A + a];
+    if (g.reward_sum) {
+      g.reward_sum[(size_t)b0 * A + a] += rsum[a];
+      if (has1) g.reward_sum[(size_t)b1 * A + a] += rsum[A + a];
+    }
+  }
+  if (tid == 0) {
+    if (g.done_any) { g.done_any[b0] = flag0; if (has1) g.done_any[b1] = flag1; }
+    if (g.done_step) { g.done_step[b0] = first0; if (has1) g.done_step[b1] = first1; }
   }
 }
 
@@ -1160,6 +1498,61 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
   }
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
+}
+
+// ---- persistent rollout: host side
+static size_t ks_rollout_lds(const Env& E, const Mlp& A) {
+  const pdec_env_cfg& c = E.cfg;
+  const size_t ts = dtype_size(c.dtype);
+  return E.lds_bytes + ((size_t)2 * c.A * env_ns(c) + 4 * (size_t)c.A + ((ro_image_elems(A.dims.data(), A.L) + 3) & ~3) + (size_t)4 * *std::max_element(A.dims.begin(), A.dims.begin() + A.L + 1) * E.nthreads) * ts + 16;
+}
+bool ks_rollout_supported(const Env& E, const Mlp& A) {
+  const pdec_env_cfg& c = E.cfg;
+  const char* off = getenv("PDEC_ROLLOUT_PERSISTENT");
+  if (off && off[0] == '0') return false;
+  if (c.pde_kind != PDEC_PDE_KS_CNAB2 || c.mono || c.temporal_steps != 1 || c.check_max_value == 2) return false;
+  if ((E.nthreads & 1) || A.L < 1 || A.L > 3 || A.dims[A.L] != 1 || A.dtype != c.dtype || A.dims[0] != env_ns(c)) return false;
+  for (int l = 0; l <= A.L; ++l)
+    if (A.dims[l] > RO_W) return false;
+  return ks_rollout_lds(E, A) <= 64 * 1024;
+}
+
+template <class T>
+static int ks_rollout_launch(Env& E, const Mlp& A, const RollArgs<T>& g) {
+  EnvDev<T> e = make_dev<T>(E);
+  const pdec_env_cfg& c = E.cfg;
+  RollActor ra{};
+  ra.params = A.params.p; ra.L = A.L; ra.nparams = A.nparams;
+  for (int l = 0; l <= A.L; ++l) { ra.dims[l] = A.dims[l]; ra.rows = std::max(ra.rows, A.dims[l]); }
+  for (int l = 0; l < A.L; ++l) ra.acts[l] = A.acts[l];
+  const size_t lds = ks_rollout_lds(E, A);
+  dim3 grid((c.B + 1) / 2), block(E.nthreads);
+  ProfScope ps(&E, "ks_rollout");
+#define KS_ROLL(ENG) hipLaunchKernelGGL((ks_rollout_kernel<T, ENG>), grid, block, lds, E.stream, e, ra, g)
+  if (E.r4_log == 1) KS_ROLL(FftWave256<T>);
+  else if (E.r4_log == 4) KS_ROLL(FftR4<T COMMA 4>);
+  else if (E.r4_log == 5) KS_ROLL(FftR4<T COMMA 5>);
+  else if (E.r4_log == 7) KS_ROLL(FftFixed192<T>);
+  else if (E.r4_log == 8) KS_ROLL(FftFixed240<T>);
+  else if (E.r4_log == 9) KS_ROLL(FftFixed600<T>);
+  else KS_ROLL(FftGeneric<T>);
+#undef KS_ROLL
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+int ks_rollout_persistent(Env& E, const Mlp& A, int T, void* y, void* state, void* action, double act_noise, double act_limit,
+                          int learning, uint64_t seed, uint64_t offset, void* reward_sum, void* log_y, void* log_p,
+                          void* log_action, void* log_reward, int32_t* done_any, int32_t* done_step) {
+  if (!ks_rollout_supported(E, A)) { set_error("ks_rollout_persistent: configuration not covered"); return PDEC_E_INVALID; }
+  if (E.cfg.dtype == PDEC_F64) {
+    RollArgs<double> g{T, learning, act_noise, act_limit, seed, offset, (double*)y, (double*)state, (double*)action, (double*)reward_sum,
+                       (double*)log_y, (double*)log_p, (double*)log_action, (double*)log_reward, done_any, done_step};
+    return ks_rollout_launch<double>(E, A, g);
+  }
+  RollArgs<float> g{T, learning, (float)act_noise, (float)act_limit, seed, offset, (float*)y, (float*)state, (float*)action,
+                    (float*)reward_sum, (float*)log_y, (float*)log_p, (float*)log_action, (float*)log_reward, done_any, done_step};
+  return ks_rollout_launch<float>(E, A, g);
 }
 
 template <class T>

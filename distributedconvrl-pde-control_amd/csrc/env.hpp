@@ -44,6 +44,14 @@ struct Env : Object {
   Env() : Object(Kind::Env) {}
 };
 
+// env.hip: T acting + env steps of the KS environment in one persistent launch (see ks_rollout_kernel); returns
+// PDEC_E_INVALID without touching anything when the configuration is not covered (the caller then loops per step)
+struct Mlp;
+bool ks_rollout_supported(const Env& E, const Mlp& A);
+int ks_rollout_persistent(Env& E, const Mlp& A, int T, void* y, void* state, void* action, double act_noise, double act_limit,
+                          int learning, uint64_t seed, uint64_t offset, void* reward_sum, void* log_y, void* log_p,
+                          void* log_action, void* log_reward, int32_t* done_any, int32_t* done_step);
+
 // fluid.hip: 2-D pseudo-spectral vorticity environment (src/fluid_rk4.jl + scripts/Fluid/setup/FluidSetup.jl)
 struct FluidEnv;
 int fluid_env_step(Env& E, const void* y_in, const void* action, const void* action_prev, const void* state_prev,

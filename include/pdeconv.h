@@ -238,7 +238,13 @@ int pdec_adam_polyak_step(pdec_handle h, pdec_handle h_target, double eta, doubl
  * skip): reward_sum [B][A] += every step's reward; log_y / log_p / log_action / log_reward: [T][...] rows of the
  * trajectory (what PDEhook logs per step, src/PDEhook.jl:54-62); done_any [B] = OR of the step flags, done_step [B] =
  * first step that raised a flag (-1: none).  The reference stops an episode at `done`; a rollout keeps integrating
- * (blown-up trajectories saturate to inf/NaN) and reports the step, the caller discards what follows it. */
+ * (blown-up trajectories saturate to inf/NaN) and reports the step, the caller discards what follows it.
+ * KS (CNAB2, per-actuator agents, temporal_steps = 1, actor of <= 3 Dense layers no wider than 32 with one output):
+ * ONE persistent launch for all T steps -- a workgroup keeps its two trajectories in registers and their state / actions
+ * in LDS between steps and evaluates the actor itself on the vector unit (k-ordered sums like the oracle; not the
+ * summation order of the MFMA acting kernel, so fp32 actions agree with the per-step loop to ~1e-6, not bit for bit);
+ * PDEC_ROLLOUT_PERSISTENT=0 selects the per-step form, which every other configuration uses (same kernels as the loop
+ * pdec_policy_act_rng -> pdec_env_step, bit-identical to it). */
 int pdec_rollout(pdec_handle env, pdec_handle actor, int T, void* y, void* state, void* action,
                  double act_noise, double act_limit, int learning, uint64_t seed, uint64_t offset,
                  void* reward_sum, void* log_y, void* log_p, void* log_action, void* log_reward,

@@ -156,13 +156,18 @@ def test_agent_checkpoint_roundtrip(pkg, tmp_path):
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("case", ["ks_c2_f32", "kseg_f64", "kseg2d_f32"])
-def test_rollout_equals_step_by_step_loop(pkg, case):
-    """pdec_rollout (T control steps enqueued in one call, row F2) == the per-step loop policy_act_rng -> env(action),
-    bit for bit, including the accumulated reward, the logged rows and the step at which a trajectory blows up"""
+@pytest.mark.parametrize("case", ["ks_c2_f32", "ks_c2_f32_persistent", "kseg_f64", "kseg2d_f32"])
+def test_rollout_equals_step_by_step_loop(pkg, case, monkeypatch):
+    """pdec_rollout (T control steps in one call, row F2) against the per-step loop policy_act_rng -> env(action), including
+    the accumulated reward, the logged rows and the step at which a trajectory blows up.  The host-enqueued form
+    (Keller-Segel, 2-D; KS with PDEC_ROLLOUT_PERSISTENT=0) issues the same kernels and is bit-identical; the persistent
+    KS kernel (one launch for all T steps, actor evaluated on the vector unit inside it) draws the same noise but sums the
+    actor's layers in a different order than the MFMA acting kernel: fp32 actions <= 2e-6, fields <= 2e-5 over 6 steps."""
     import ctypes as C
     L = pkg._lib
-    if case == "ks_c2_f32":
+    persistent = case == "ks_c2_f32_persistent"
+    monkeypatch.setenv("PDEC_ROLLOUT_PERSISTENT", "1" if persistent else "0")
+    if case.startswith("ks_c2_f32"):
         setup, dt, B = pkg.KSSetup.bench_C2(256), torch.float32, 5
         y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
     elif case == "kseg_f64":
@@ -172,7 +177,7 @@ def test_rollout_equals_step_by_step_loop(pkg, case):
         setup, dt, B = pkg.KellerSegel2DSetup(nx=64, ny=32, substeps=4), torch.float32, 2
         y0 = np.moveaxis(setup.generate_random_init(np.random.default_rng(0), B), 1, -1)
     T, noise, lim, seed = 6, 0.3, 1.0, 99
-    envs = [pkg.PDEenv(setup, B=B, dtype=dt, y0=np.ascontiguousarray(y0)) for _ in range(2)]
+    envs = [pkg.PDEenv(setup, B=B, dtype=dt, y0=np.ascontiguousarray(y0), autoreset=False) for _ in range(2)]
     agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=dt, start_steps=-1)
     actor = agent.policy.behavior_actor.model
     ns, A = setup.state_shape
@@ -191,11 +196,20 @@ def test_rollout_equals_step_by_step_loop(pkg, case):
         rows.append((e.y.clone(), e.p.clone(), e.action.clone(), e.reward.clone()))
     out = envs[1].rollout(actor, T, act_noise=noise, act_limit=lim, learning=True, seed=seed, offset=0, log=True)
     torch.cuda.synchronize()
-    assert torch.equal(envs[1].y, e.y) and torch.equal(envs[1].state, e.state) and torch.equal(envs[1].action, e.action)
-    assert torch.equal(out["reward_sum"], rsum)
-    for t in range(T):
-        assert torch.equal(out["y"][t], rows[t][0]) and torch.equal(out["p"][t], rows[t][1])
-        assert torch.equal(out["action"][t], rows[t][2]) and torch.equal(out["reward"][t], rows[t][3])
+    if persistent:
+        close = lambda x, y, tol: float((x - y).abs().max()) <= tol
+        assert close(out["action"][0], rows[0][2], 2e-6)          # same state, same noise element for element
+        assert close(envs[1].y, e.y, 2e-5) and close(envs[1].state, e.state, 2e-5) and close(envs[1].action, e.action, 2e-5)
+        assert close(out["reward_sum"], rsum, 2e-5)
+        for t in range(T):
+            assert close(out["y"][t], rows[t][0], 2e-5) and close(out["p"][t], rows[t][1], 2e-4)
+            assert close(out["action"][t], rows[t][2], 2e-5) and close(out["reward"][t], rows[t][3], 2e-5)
+    else:
+        assert torch.equal(envs[1].y, e.y) and torch.equal(envs[1].state, e.state) and torch.equal(envs[1].action, e.action)
+        assert torch.equal(out["reward_sum"], rsum)
+        for t in range(T):
+            assert torch.equal(out["y"][t], rows[t][0]) and torch.equal(out["p"][t], rows[t][1])
+            assert torch.equal(out["action"][t], rows[t][2]) and torch.equal(out["reward"][t], rows[t][3])
     assert envs[1].steps == T and int(out["done_any"].sum()) == 0 and out["done_step"].tolist() == [-1] * B
     # blow-up bookkeeping: a trajectory started beyond max_value is flagged at step 0
     envs[1].y[B - 1].fill_(1e3)
