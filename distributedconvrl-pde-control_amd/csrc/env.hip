@@ -449,6 +449,7 @@ __device__ __forceinline__ void pk_dft4(C2<float> (&a)[4]) {
 template <class T>
 struct FftWave256 {
   static constexpr int kThreads = 64;
+  static constexpr int kMinWaves = sizeof(T) == 4 ? 8 : 1;
   C2<T>* buf;
   C2<T> w[3][3];       // twiddles of the three inner stages, per lane
   int tid;
@@ -616,8 +617,10 @@ template <class T> using FftFixed192 = FftFixed<T, 192, 4, 4, 4, 3, 4, 1>;
 template <class T> using FftFixed240 = FftFixed<T, 240, 4, 4, 5, 3, 4, 1>;
 template <class T> using FftFixed600 = FftFixed<T, 600, 5, 4, 5, 5, 2, 3>;
 
+template <class ENG, class = void> struct MinWaves { static constexpr int value = 1; };
+template <class ENG> struct MinWaves<ENG, std::void_t<decltype(ENG::kMinWaves)>> { static constexpr int value = ENG::kMinWaves; };
 template <class T, class ENG, bool FUSED>
-__global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
+__global__ void __launch_bounds__(ENG::kThreads, MinWaves<ENG>::value) ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
                                    const T* __restrict__ action, const T* __restrict__ action_prev,
                                    const T* __restrict__ state_prev, T* __restrict__ y_out,
                                    T* __restrict__ p_out, T* __restrict__ state_out,
@@ -625,10 +628,12 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = e.N, tid = threadIdx.x, nt = blockDim.x;
   // This kernel is a long dependent chain (63 FFTs) issued by very few waves.  Beside the f32-MFMA update passes (which
-  // execute on the vector unit) every instruction it issues is taken from them, and their eight waves per workgroup
-  // wait for each other at barriers -- so in the training pipeline, where the UPDATE chain is the critical path and this
-  // step has a whole control step of slack, the passes run at priority 2 and this kernel below them at 1
-  // (r02f, same box: 155 -> 138 us per control step against priority 3 here and 0 there).
+  // execute on the vector unit) each of its instructions waits for an MFMA to drain (~2.7x slower), and a wave of it can
+  // only share a SIMD with two waves of the 222-VGPR critic pass if it needs <= 64 VGPRs (2 x 224 + 64 = 512): with 86
+  // (r02j) the step and the pass excluded each other per CU, so the step's tail delayed every workgroup of the next pass
+  // (75 us in the pipeline against 63 alone).  The fp32 single-wave engine therefore keeps its per-mode constants in LDS
+  // (LDSC below), is bounded to 64 VGPRs and runs at priority 3 -- it is then over well before the next pass and that
+  // pass keeps its alone time (r02l: 135 -> 124 us per control step); the other engines stay below the passes at 1.
   set_wave_prio(e.prio);
   ENG eng;
   eng.init(smem_raw, e, tid, nt);
@@ -652,6 +657,12 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   }
   __syncthreads();
 
+  // LDSC: the per-mode constants, the constant term and the previous nonlinear term live in LDS (lane-private float4
+  // slots) instead of 32 registers -- the kernel then fits in 64 VGPRs and a wave of it can share a SIMD with two waves
+  // of the 222-VGPR critic pass (2 x 224 + 64 = 512), instead of waiting for / holding up a whole workgroup of it
+  constexpr bool LDSC = MinWaves<ENG>::value > 1;
+  typedef T T4v __attribute__((ext_vector_type(4)));
+  T4v* cst = reinterpret_cast<T4v*>(smem_raw + ((size_t)(reinterpret_cast<unsigned char*>(red + 16) - smem_raw + 15) & ~(size_t)15));
   C2<T> U[KS_MPT], Nn[KS_MPT], Ck[KS_MPT], v[KS_MPT];
   T kc1[KS_MPT], kc2[KS_MPT], kc3[KS_MPT], kg[KS_MPT];
   // forcing p (packed pair) -> spectrum -> constant term of the CNAB2 update
@@ -691,6 +702,11 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
       Ck[j] = mk<T>(0, 0);
       kc1[j] = kc2[j] = kc3[j] = kg[j] = 0;
     }
+    if constexpr (LDSC) cst[j * nt + tid] = T4v{kc1[j], kc2[j], kc3[j], kg[j]};
+  }
+  if constexpr (LDSC) {
+    cst[4 * nt + tid] = T4v{Ck[0].x, Ck[0].y, Ck[1].x, Ck[1].y};
+    cst[5 * nt + tid] = T4v{Ck[2].x, Ck[2].y, Ck[3].x, Ck[3].y};
   }
   // Nn = G * fft(u^2);  u_hat = fft(u)
 #pragma unroll
@@ -702,24 +718,57 @@ __global__ void ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, cons
   eng.template run<-1>(v);
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) Nn[j] = cscale(mul_i<+1, T>(v[j]), kg[j]);   // G = i * (-alpha/2)
+  if constexpr (LDSC) {
+    cst[6 * nt + tid] = T4v{Nn[0].x, Nn[0].y, Nn[1].x, Nn[1].y};
+    cst[7 * nt + tid] = T4v{Nn[2].x, Nn[2].y, Nn[3].x, Nn[3].y};
+  }
   eng.template run<-1>(U);
   const T invN = (T)1 / (T)N;
-  for (int it = 0; it < e.K; ++it) {
+  if constexpr (LDSC) {
+    for (int it = 0; it < e.K; ++it) {
 #pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) v[j] = U[j];
-    eng.template run<+1>(v);
+      for (int j = 0; j < KS_MPT; ++j) v[j] = U[j];
+      eng.template run<+1>(v);
 #pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const T wr = v[j].x * invN, wi = v[j].y * invN;
-      v[j] = mk<T>(wr * wr, wi * wi);
+      for (int j = 0; j < KS_MPT; ++j) {
+        const T wr = v[j].x * invN, wi = v[j].y * invN;
+        v[j] = mk<T>(wr * wr, wi * wi);
+      }
+      eng.template run<-1>(v);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {          // modes 2h, 2h + 1
+        const T4v nn = cst[(6 + h) * nt + tid], ck = cst[(4 + h) * nt + tid];
+        T4v nw;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = 2 * h + u;
+          const T4v c = cst[j * nt + tid];   // c1, c2, c3, g
+          const C2<T> n1 = cscale(mul_i<+1, T>(v[j]), c[3]);
+          U[j] = mk<T>(c[0] * U[j].x + c[1] * n1.x - c[2] * nn[2 * u] + ck[2 * u],
+                       c[0] * U[j].y + c[1] * n1.y - c[2] * nn[2 * u + 1] + ck[2 * u + 1]);
+          nw[2 * u] = n1.x; nw[2 * u + 1] = n1.y;
+        }
+        cst[(6 + h) * nt + tid] = nw;
+      }
     }
-    eng.template run<-1>(v);
+  } else {
+    for (int it = 0; it < e.K; ++it) {
 #pragma unroll
-    for (int j = 0; j < KS_MPT; ++j) {
-      const C2<T> nn1 = Nn[j];
-      Nn[j] = cscale(mul_i<+1, T>(v[j]), kg[j]);
-      U[j] = mk<T>(kc1[j] * U[j].x + kc2[j] * Nn[j].x - kc3[j] * nn1.x + Ck[j].x,
-                   kc1[j] * U[j].y + kc2[j] * Nn[j].y - kc3[j] * nn1.y + Ck[j].y);
+      for (int j = 0; j < KS_MPT; ++j) v[j] = U[j];
+      eng.template run<+1>(v);
+#pragma unroll
+      for (int j = 0; j < KS_MPT; ++j) {
+        const T wr = v[j].x * invN, wi = v[j].y * invN;
+        v[j] = mk<T>(wr * wr, wi * wi);
+      }
+      eng.template run<-1>(v);
+#pragma unroll
+      for (int j = 0; j < KS_MPT; ++j) {
+        const C2<T> nn1 = Nn[j];
+        Nn[j] = cscale(mul_i<+1, T>(v[j]), kg[j]);
+        U[j] = mk<T>(kc1[j] * U[j].x + kc2[j] * Nn[j].x - kc3[j] * nn1.x + Ck[j].x,
+                     kc1[j] * U[j].y + kc2[j] * Nn[j].y - kc3[j] * nn1.y + Ck[j].y);
+      }
     }
   }
   // y+ = real(ifft(u_hat))
@@ -1416,7 +1465,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.dx = (T)(c.Lx / c.N);
   e.hstep = (T)(c.dt / c.K);
   e.rk2 = c.integrator == 1;
-  e.prio = env_prio("PDEC_PRIO_KS", 1);
+  e.prio = env_prio("PDEC_PRIO_KS", (E.r4_log == 1 && c.dtype == PDEC_F32) ? 3 : 1);
   e.dist_mu = (T)c.mu;
   e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
   e.Wd = E.Wd; e.Cnt = E.Cnt;
@@ -1431,7 +1480,9 @@ static EnvDev<T> make_dev(const Env& E) {
 
 static size_t ks_lds_bytes(const pdec_env_cfg& c, int r4_log) {
   const size_t ts = dtype_size(c.dtype);
-  return (r4_log == 1 ? 1 : ((r4_log == 4 || r4_log == 5) ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
+  // + the single-wave fp32 engine's lane-private constant slots (8 float4 per lane, 16-byte aligned)
+  return (r4_log == 1 ? 1 : ((r4_log == 4 || r4_log == 5) ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts +
+         ((r4_log == 1 && c.dtype == PDEC_F32) ? 16 + 8 * 16 * 64 : 0);
 }
 static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
