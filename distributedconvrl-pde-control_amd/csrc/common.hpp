@@ -105,7 +105,7 @@ __device__ __forceinline__ void set_wave_prio(int p) {
   else if (p == 2) __builtin_amdgcn_s_setprio(2);
   else if (p == 3) __builtin_amdgcn_s_setprio(3);
 }
-// wave priorities, overridable for experiments: PDEC_PRIO_KS (KS env-step kernel, default 3 for the 64-VGPR fp32 single-wave engine, else 1), PDEC_PRIO_MFMA (fused
+// wave priorities, overridable for experiments: PDEC_PRIO_KS (KS env-step kernel, default 1; 3 in its SIMD-sharing form, pdec_env_set_simd_sharing), PDEC_PRIO_MFMA (fused
 // 3-layer DDPG passes, default 2)
 inline int env_prio(const char* name, int dflt) {
   const char* e = getenv(name);

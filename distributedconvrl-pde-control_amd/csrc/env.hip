@@ -449,7 +449,6 @@ __device__ __forceinline__ void pk_dft4(C2<float> (&a)[4]) {
 template <class T>
 struct FftWave256 {
   static constexpr int kThreads = 64;
-  static constexpr int kMinWaves = sizeof(T) == 4 ? 8 : 1;
   C2<T>* buf;
   C2<T> w[3][3];       // twiddles of the three inner stages, per lane
   int tid;
@@ -617,10 +616,9 @@ template <class T> using FftFixed192 = FftFixed<T, 192, 4, 4, 4, 3, 4, 1>;
 template <class T> using FftFixed240 = FftFixed<T, 240, 4, 4, 5, 3, 4, 1>;
 template <class T> using FftFixed600 = FftFixed<T, 600, 5, 4, 5, 5, 2, 3>;
 
-template <class ENG, class = void> struct MinWaves { static constexpr int value = 1; };
-template <class ENG> struct MinWaves<ENG, std::void_t<decltype(ENG::kMinWaves)>> { static constexpr int value = ENG::kMinWaves; };
-template <class T, class ENG, bool FUSED>
-__global__ void __launch_bounds__(ENG::kThreads, MinWaves<ENG>::value) ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
+// SHARE (pdec_env_set_simd_sharing; fp32 single-wave engine only): the 64-VGPR form of the kernel, see below
+template <class T, class ENG, bool FUSED, bool SHARE = false>
+__global__ void __launch_bounds__(ENG::kThreads, SHARE ? 8 : 1) ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
                                    const T* __restrict__ action, const T* __restrict__ action_prev,
                                    const T* __restrict__ state_prev, T* __restrict__ y_out,
                                    T* __restrict__ p_out, T* __restrict__ state_out,
@@ -628,12 +626,15 @@ __global__ void __launch_bounds__(ENG::kThreads, MinWaves<ENG>::value) ks_env_st
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = e.N, tid = threadIdx.x, nt = blockDim.x;
   // This kernel is a long dependent chain (63 FFTs) issued by very few waves.  Beside the f32-MFMA update passes (which
-  // execute on the vector unit) each of its instructions waits for an MFMA to drain (~2.7x slower), and a wave of it can
-  // only share a SIMD with two waves of the 222-VGPR critic pass if it needs <= 64 VGPRs (2 x 224 + 64 = 512): with 86
-  // (r02j) the step and the pass excluded each other per CU, so the step's tail delayed every workgroup of the next pass
-  // (75 us in the pipeline against 63 alone).  The fp32 single-wave engine therefore keeps its per-mode constants in LDS
-  // (LDSC below), is bounded to 64 VGPRs and runs at priority 3 -- it is then over well before the next pass and that
-  // pass keeps its alone time (r02l: 135 -> 124 us per control step); the other engines stay below the passes at 1.
+  // execute on the vector unit) each of its instructions waits for an MFMA to drain (~2.7x slower), and their eight waves
+  // per workgroup wait for each other at barriers; on its own it runs at priority 1, below the passes at 2 (r02f).
+  // SHARE: in its register form (86 VGPRs) a wave of this kernel cannot share a SIMD with two waves of the 222-VGPR critic
+  // pass (2 x 224 + 86 > 512): step and pass exclude each other per CU, and the step's tail delayed every workgroup of
+  // the next pass (75 us in the pipeline against 63 alone, r02j).  The SHARE form keeps the per-mode constants, the
+  // constant term and the previous nonlinear term in LDS (LDSC below), is bounded to 64 VGPRs (2 x 224 + 64 = 512) and
+  // runs at priority 3: it is over before the next pass needs the registers, and the pass keeps its alone time (r02l:
+  // 135 -> 125 us per control step).  Alone the SHARE form is slower (42 vs 30 us: four exposed LDS round trips per
+  // sub-step), so only the two-stream training pipeline asks for it.
   set_wave_prio(e.prio);
   ENG eng;
   eng.init(smem_raw, e, tid, nt);
@@ -660,7 +661,7 @@ __global__ void __launch_bounds__(ENG::kThreads, MinWaves<ENG>::value) ks_env_st
   // LDSC: the per-mode constants, the constant term and the previous nonlinear term live in LDS (lane-private float4
   // slots) instead of 32 registers -- the kernel then fits in 64 VGPRs and a wave of it can share a SIMD with two waves
   // of the 222-VGPR critic pass (2 x 224 + 64 = 512), instead of waiting for / holding up a whole workgroup of it
-  constexpr bool LDSC = MinWaves<ENG>::value > 1;
+  constexpr bool LDSC = SHARE;
   typedef T T4v __attribute__((ext_vector_type(4)));
   T4v* cst = reinterpret_cast<T4v*>(smem_raw + ((size_t)(reinterpret_cast<unsigned char*>(red + 16) - smem_raw + 15) & ~(size_t)15));
   C2<T> U[KS_MPT], Nn[KS_MPT], Ck[KS_MPT], v[KS_MPT];
@@ -1465,7 +1466,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.dx = (T)(c.Lx / c.N);
   e.hstep = (T)(c.dt / c.K);
   e.rk2 = c.integrator == 1;
-  e.prio = env_prio("PDEC_PRIO_KS", (E.r4_log == 1 && c.dtype == PDEC_F32) ? 3 : 1);
+  e.prio = env_prio("PDEC_PRIO_KS", (E.share_simd && E.r4_log == 1 && c.dtype == PDEC_F32) ? 3 : 1);
   e.dist_mu = (T)c.mu;
   e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
   e.Wd = E.Wd; e.Cnt = E.Cnt;
@@ -1480,9 +1481,7 @@ static EnvDev<T> make_dev(const Env& E) {
 
 static size_t ks_lds_bytes(const pdec_env_cfg& c, int r4_log) {
   const size_t ts = dtype_size(c.dtype);
-  // + the single-wave fp32 engine's lane-private constant slots (8 float4 per lane, 16-byte aligned)
-  return (r4_log == 1 ? 1 : ((r4_log == 4 || r4_log == 5) ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts +
-         ((r4_log == 1 && c.dtype == PDEC_F32) ? 16 + 8 * 16 * 64 : 0);
+  return (r4_log == 1 ? 1 : ((r4_log == 4 || r4_log == 5) ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
 }
 static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
@@ -1513,7 +1512,19 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
   hipLaunchKernelGGL((ks_env_step_kernel<T, ENG, F>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,    \
                      (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,    \
                      (T*)p_out, (T*)state_out, (T*)reward_out, done)
-    if (E.r4_log == 1) { if (fused) KS_LAUNCH(FftWave256<T>, true); else KS_LAUNCH(FftWave256<T>, false); }
+    if (E.r4_log == 1) {
+      if constexpr (sizeof(T) == 4) {
+        if (fused && E.share_simd) {     // 64-VGPR form + its lane-private constant slots (8 float4 per lane, 16-byte aligned)
+          for (int rep__ = 0; rep__ < ps.reps; ++rep__)
+            hipLaunchKernelGGL((ks_env_step_kernel<T, FftWave256<T>, true, true>), grid, block, E.lds_bytes + 16 + 8 * 16 * 64, E.stream, e,
+                               (const T*)y_in, (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,
+                               (T*)p_out, (T*)state_out, (T*)reward_out, done);
+          PDEC_HIP(hipGetLastError());
+          return PDEC_OK;
+        }
+      }
+      if (fused) KS_LAUNCH(FftWave256<T>, true); else KS_LAUNCH(FftWave256<T>, false);
+    }
     else if (E.r4_log == 4) { if (fused) KS_LAUNCH(FftR4<T COMMA 4>, true); else KS_LAUNCH(FftR4<T COMMA 4>, false); }
     else if (E.r4_log == 5) { if (fused) KS_LAUNCH(FftR4<T COMMA 5>, true); else KS_LAUNCH(FftR4<T COMMA 5>, false); }
     else if (E.r4_log == 7) { if (fused) KS_LAUNCH(FftFixed192<T>, true); else KS_LAUNCH(FftFixed192<T>, false); }
@@ -1785,6 +1796,14 @@ int pdec_env_set_terminal_out(pdec_handle h, void* terminal_per_column) {
   PDEC_REQUIRE(E->cfg.pde_kind != PDEC_PDE_FLUID_RK4 || !terminal_per_column,
                "pdec_env_set_terminal_out: not provided for the fluid environment (expand its done[B] flags)");
   E->term_out = terminal_per_column;
+  return PDEC_OK;
+}
+
+int pdec_env_set_simd_sharing(pdec_handle h, int on, int* effective) {
+  Env* E = lookup_as<Env>(h, Kind::Env);
+  if (!E) { set_error("pdec_env_set_simd_sharing: bad handle"); return PDEC_E_HANDLE; }
+  E->share_simd = on != 0;
+  if (effective) *effective = (E->share_simd && E->cfg.pde_kind == PDEC_PDE_KS_CNAB2 && E->r4_log == 1 && E->cfg.dtype == PDEC_F32) ? 1 : 0;
   return PDEC_OK;
 }
 

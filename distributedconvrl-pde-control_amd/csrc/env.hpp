@@ -37,6 +37,7 @@ struct Env : Object {
   DevBuf roll;   // ping-pong buffers of pdec_rollout
   void* term_out = nullptr;
   float* rsum_out = nullptr;
+  bool share_simd = false;   // pdec_env_set_simd_sharing: launch the 64-VGPR form of the fused KS step
   FftPlan fft;
   int nthreads = 64;
   int r4_log = 0;        // 4 / 5: N = 256 / 1024 use the register-resident radix-4 FFT engine

@@ -314,6 +314,15 @@ class PDEenv:
                 _lib.ptr(self._state0), _lib.ptr(self.action) if own_action else None,
                 _lib.ptr(self.action0) if own_action else None, _lib.ptr(self.reward)))
 
+    def set_simd_sharing(self, on=True):
+        """Launch the fused KS step in its 64-VGPR form (constants in LDS), whose waves can share a SIMD with the f32-MFMA
+        critic pass -- for callers that run the step beside the update passes on a second stream (TrainPipeline does).
+        Returns True when this environment has such a form (KS CNAB2, N = 256, fp32)."""
+        import ctypes as C
+        eff = C.c_int()
+        _lib.check(self.lib.pdec_env_set_simd_sharing(self.handle, 1 if on else 0, C.byref(eff)))
+        return bool(eff.value)
+
     # ---- T control steps without returning to the host (SURVEY.md §8f row F2)
     def rollout(self, actor, T, act_noise=0.0, act_limit=1.0, learning=False, seed=0, offset=0, log=False):
         """for t in 1:T; action = policy(env); env(action); end  (src/PDEagent.jl:175-209 + src/PDEenv.jl:195-241)

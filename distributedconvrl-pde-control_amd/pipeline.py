@@ -147,6 +147,13 @@ class TrainPipeline:
         self.kick_env_after_critic = (not self.act_in_place) if kick_env_after_critic is None else bool(kick_env_after_critic)
         if os.environ.get("PDEC_KICK") in ("0", "1"):               # diagnostic override
             self.kick_env_after_critic = os.environ["PDEC_KICK"] == "1"
+        # two streams + the fused 3-layer passes: ask for the PDE step's 64-VGPR form, whose waves can share a SIMD with the
+        # 222-VGPR critic pass instead of excluding it per CU (csrc/env.hip, SHARE); PDEC_SHARE=0: the register form
+        self.simd_sharing = False
+        if not self.serial and self.rpart is not None and os.environ.get("PDEC_SHARE", "1") != "0":
+            eff = C.c_int()
+            _lib.check(self.lib.pdec_env_set_simd_sharing(env.handle, 1, C.byref(eff)))
+            self.simd_sharing = bool(eff.value)
         self._sp_env, self._sp_upd = C.c_void_p(self.s_env.cuda_stream), C.c_void_p(self.s_upd.cuda_stream)
         self.graphs = {}          # (chunk, pos) -> graph handle
         self._progs = {}          # ring phase -> recorded library calls of an interior eager step
@@ -415,6 +422,9 @@ class TrainPipeline:
         self.s_upd.synchronize()
 
     def close(self):
+        if getattr(self, "simd_sharing", False):
+            self.lib.pdec_env_set_simd_sharing(self.env.handle, 0, None)
+            self.simd_sharing = False
         for h in self.graphs.values():
             self.lib.pdec_destroy(h)
         self.graphs = {}

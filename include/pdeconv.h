@@ -320,6 +320,12 @@ int pdec_ddpg_update_small(pdec_handle A, pdec_handle C, pdec_handle At, pdec_ha
  * r -- the env step -- does it beside the running update) and pdec_ddpg_set_reward_mean hands the device scalar to the
  * NEXT critic pass of `critic`, which then does not read r for the mean (one hand-over per update; fp32 fused paths). */
 int pdec_reward_mean(pdec_handle any_handle, const void* r, int n, void* mean_out);
+/* For callers that run the fused KS step beside the f32-MFMA update passes on a second stream (the two-stream training
+ * step): launch the step in the form that needs <= 64 VGPRs -- per-mode constants in LDS instead of registers -- so that a
+ * wave of it can share a SIMD with two waves of the 222-VGPR critic pass instead of excluding a whole workgroup of it
+ * (and being excluded by it) per CU; that form also runs at wave priority 3.  Alone it is slower (42 vs 30 us at C2), so
+ * it is off by default.  *effective = 1 when the environment has such a form (KS CNAB2, N = 256, fp32), else 0. */
+int pdec_env_set_simd_sharing(pdec_handle env, int on, int* effective);
 /* the same without any extra launch for the fused KS step + 3-layer fused critic: every later pdec_env_step also writes the
  * sum of the rewards of each of its workgroups (two trajectories each) to partial_sums [*n_partials] (fp32; NULL switches it
  * off), and pdec_ddpg_set_reward_partials hands them to the next critic pass, which adds them in a fixed order. */

@@ -49,6 +49,40 @@ def test_env_step_fused_matches_golden_and_oracle(pkg, name):
     assert not bool(env.done.any())
 
 
+def test_simd_sharing_form_of_the_fused_step(pkg):
+    """pdec_env_set_simd_sharing: the 64-VGPR form of the fused KS step (per-mode constants, constant term and previous
+    nonlinear term in LDS) against the oracle (KSSetup.jl:130-245, fp32 tolerance of the register form) and against the
+    register form itself over several control steps, odd B; other environments report that they have no such form."""
+    from oracle import ks
+    setup = pkg.KSSetup.bench_C2(256)
+    cfg = ks.KSConfig(256, setup.Lx, setup.sensor_positions, sigma_sensors=1.0, sigma_actuators=1.0, window_size=3)
+    rng = np.random.default_rng(3)
+    B, T = 5, 4
+    y0 = setup.generate_random_init(rng, B) * 0.15
+    acts = rng.uniform(-1, 1, (T + 1, B, 64))
+    envs = [pkg.PDEenv(setup, B=B, dtype=torch.float32, autoreset=False) for _ in range(2)]
+    assert envs[1].set_simd_sharing(True)
+    for e in envs:
+        e.y.copy_(to_dev(y0, torch.float32))
+        e.action.copy_(to_dev(acts[0], torch.float32).reshape(e._ashape))
+    yo = [y0[b].copy() for b in range(B)]
+    for t in range(T):
+        for e in envs:
+            e(to_dev(acts[t + 1], torch.float32).reshape(e._ashape))
+        for b in range(B):
+            o = ks.env_step(cfg, yo[b], acts[t][b][None], acts[t + 1][b][None], 0.0)
+            yo[b] = o["y"]
+            assert np.abs(envs[1].y[b].cpu().numpy() - o["y"]).max() <= 2e-5 * (t + 1)
+            assert np.abs(envs[1].p[b].cpu().numpy() - o["p"]).max() <= 1e-5
+            assert np.abs(envs[1].reward[b].cpu().numpy() - o["reward"]).max() <= 1e-5 * (t + 1)
+        for name in ("y", "p", "state", "reward"):
+            a, b_ = getattr(envs[0], name), getattr(envs[1], name)
+            assert float((a - b_).abs().max()) <= 2e-6 * (t + 1), name
+    assert not bool(envs[1].done.any())
+    assert not envs[1].set_simd_sharing(False)
+    assert not pkg.PDEenv(pkg.KSSetup.KS22(), B=2, dtype=torch.float64).set_simd_sharing(True)     # fp64, N = 192: no such form
+
+
 def test_fp32_env_step_and_odd_batch(pkg):
     """fp32, odd B (the last workgroup integrates a single trajectory), bench geometry C2."""
     from oracle import ks
