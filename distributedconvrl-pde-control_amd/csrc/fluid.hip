@@ -494,10 +494,10 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
 // Used when the padded length p is one of 64/128/192/256/384/512/768 (otherwise the LDS-tile kernels above); 64 and
 // 192 run two lines per wave (half-wave transforms).
 
-// K1w: one wave per carried line s.  LDS: per wave the two spectrum lines j and mirror(j) (2 n complex).
+// K1w: one wave per PAIR of carried lines (a line and its mirror, see below).  LDS: per wave the two spectrum lines j and mirror(j) (2 n complex).
 template <int E, int Q, int LB>
 __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, const C2<double>* __restrict__ omg,
-                                                        C2<double>* __restrict__ W) {
+                                                        C2<double>* __restrict__ W, int pair) {
   typedef WaveFftD<E, Q, LB> F;
   typedef C2<double> Z;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -506,41 +506,68 @@ __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, cons
   const int n = d.n, p = d.p;
   Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)slot * 2 * n;
   Z* Lm = Lj + n;
-  const int s = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
-  if (s >= d.nl) return;                                  // whole line slot; the kernel has no workgroup barrier
-  const int jp = fl_line_jp(s, n, p, d.nl);
-  const int j = fl_unpad(jp, n, p), jm = fl_unpad((p - jp) % p, n, p);
+  // work item t = carried line t (jp = t <= n/2) TOGETHER WITH its mirror line (jp' = p - t): both need exactly the
+  // spectrum lines j and mirror(j) -- with the roles swapped -- so one load of the two lines serves two output lines
+  // (half the reads of omg and half the exposed load latency per transform); line 0 is its own mirror
+  // (pair = 0: one carried line per slot, every line loads its two spectrum lines itself -- more, shorter waves: better
+  // for the small grids, n = 128: 12.8 vs 15.2 us)
+  const int t = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
+  if (t >= (pair ? n / 2 + 1 : d.nl)) return;             // whole line slot; the kernel has no workgroup barrier
+  const int jp = fl_line_jp(t, n, p, d.nl), jpm = (p - jp) % p;
+  const int s_mirror = fl_line_of(jpm, n, p, d.nl);
+  const int j0 = fl_unpad(jp, n, p), j1 = fl_unpad(jpm, n, p);
   const Z zero = mk<double>(0, 0);
   for (int i = l; i < n; i += F::LANES) {
-    Lj[i] = j >= 0 ? omg[((size_t)b * n + j) * n + i] : zero;
-    Lm[i] = jm >= 0 ? omg[((size_t)b * n + jm) * n + i] : zero;
+    Lj[i] = j0 >= 0 ? omg[((size_t)b * n + j0) * n + i] : zero;
+    Lm[i] = j1 >= 0 ? omg[((size_t)b * n + j1) * n + i] : zero;
   }
   __builtin_amdgcn_wave_barrier();
-  const double kj = j >= 0 ? d.k[j] : 0.0, kjm = jm >= 0 ? d.k[jm] : 0.0;
   F f;
   f.init(d.twp, lane);
+  const int nhalf = (pair && s_mirror >= 0 && s_mirror != t) ? 2 : 1;
 #pragma unroll 1
-  for (int fld = 0; fld < 2; ++fld) {
-    Z a[F::R];
+  for (int half = 0; half < nhalf; ++half) {
+    const Z* La = half ? Lm : Lj;     // the line's own spectrum / its mirror's
+    const Z* Lb = half ? Lj : Lm;
+    const int j = half ? j1 : j0, jm = half ? j0 : j1, s = half ? s_mirror : t;
+    const double kj = j >= 0 ? d.k[j] : 0.0, kjm = jm >= 0 ? d.k[jm] : 0.0;
+#pragma unroll 1
+    for (int fld = 0; fld < 2; ++fld) {
+      Z a[F::R];
 #pragma unroll
-    for (int jj = 0; jj < F::R; ++jj) {
-      const int ip = f.mode_index(jj);
-      const int i = fl_unpad(ip, n, p), im = fl_unpad((p - ip) % p, n, p);
-      Z au = zero, av = zero, ax = zero, ay = zero, mu = zero, mv = zero, mx = zero, my = zero;
-      if (j >= 0 && i >= 0) fl_spec<double>(Lj[i], kj, d.k[i], i == 0 && j == 0, au, av, ax, ay);
-      if (jm >= 0 && im >= 0) fl_spec<double>(Lm[im], kjm, d.k[im], im == 0 && jm == 0, mu, mv, mx, my);
-      if (fld == 0) {   // Z1 = Herm(u) + i Herm(v)
-        const Z hu = mk<double>(0.5 * (au.x + mu.x), 0.5 * (au.y - mu.y)), hv = mk<double>(0.5 * (av.x + mv.x), 0.5 * (av.y - mv.y));
-        a[jj] = mk<double>(hu.x - hv.y, hu.y + hv.x);
-      } else {          // Z2 = Herm(wx) + i Herm(wy)
-        const Z hx = mk<double>(0.5 * (ax.x + mx.x), 0.5 * (ax.y - mx.y)), hy = mk<double>(0.5 * (ay.x + my.x), 0.5 * (ay.y - my.y));
-        a[jj] = mk<double>(hx.x - hy.y, hx.y + hy.x);
+      for (int jj = 0; jj < F::R; ++jj) {
+        const int ip = f.mode_index(jj);
+        const int i = fl_unpad(ip, n, p), im = fl_unpad((p - ip) % p, n, p);
+        // fl_spec() of the mode and of its mirror, but only the two spectra this field needs (the velocities need
+        // psihat = omghat ./ k^2, the vorticity gradients do not)
+        const bool va = j >= 0 && i >= 0, vm = jm >= 0 && im >= 0;
+        Z oa = zero, om_ = zero;
+        double ki = 0.0, kim = 0.0;
+        if (va) { oa = La[i]; ki = d.k[i]; }
+        if (vm) { om_ = Lb[im]; kim = d.k[im]; }
+        if (fld == 0) {   // Z1 = Herm(u) + i Herm(v),  u = i ky psi, v = -i kx psi
+          // one reciprocal serves the four quotients of the pair (k^2 of a mode and of its mirror are the same number;
+          // omghat * (1 / k^2) instead of omghat / k^2: <= 1 ulp from the reference's quotient)
+          const double k2 = va ? kj * kj + ki * ki : kjm * kjm + kim * kim;
+          const double r = 1.0 / k2;
+          const Z pa = (va && !(i == 0 && j == 0)) ? mk<double>(oa.x * r, oa.y * r) : zero;
+          const Z pm = (vm && !(im == 0 && jm == 0)) ? mk<double>(om_.x * r, om_.y * r) : zero;
+          const Z au = mk<double>(-ki * pa.y, ki * pa.x), av = mk<double>(kj * pa.y, -kj * pa.x);
+          const Z mu = mk<double>(-kim * pm.y, kim * pm.x), mv = mk<double>(kjm * pm.y, -kjm * pm.x);
+          const Z hu = mk<double>(0.5 * (au.x + mu.x), 0.5 * (au.y - mu.y)), hv = mk<double>(0.5 * (av.x + mv.x), 0.5 * (av.y - mv.y));
+          a[jj] = mk<double>(hu.x - hv.y, hu.y + hv.x);
+        } else {          // Z2 = Herm(wx) + i Herm(wy),  wx = i kx omg, wy = i ky omg
+          const Z ax = mk<double>(-kj * oa.y, kj * oa.x), ay = mk<double>(-ki * oa.y, ki * oa.x);
+          const Z mx = mk<double>(-kjm * om_.y, kjm * om_.x), my = mk<double>(-kim * om_.y, kim * om_.x);
+          const Z hx = mk<double>(0.5 * (ax.x + mx.x), 0.5 * (ax.y - mx.y)), hy = mk<double>(0.5 * (ay.x + my.x), 0.5 * (ay.y - my.y));
+          a[jj] = mk<double>(hx.x - hy.y, hx.y + hy.x);
+        }
       }
-    }
-    f.inverse(a);
-    Z* w = W + (((size_t)b * 2 + fld) * d.nl + s) * p;
+      f.inverse(a);
+      Z* w = W + (((size_t)b * 2 + fld) * d.nl + s) * p;
 #pragma unroll
-    for (int jj = 0; jj < F::R; ++jj) w[l + F::LANES * jj] = a[jj];
+      for (int jj = 0; jj < F::R; ++jj) w[l + F::LANES * jj] = a[jj];
+    }
   }
 }
 
@@ -774,11 +801,12 @@ static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const 
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k3w_kernel<E, Q, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
+  const int pair = n >= 256 ? 1 : 0;      // a line and its mirror per wave (K1w) once there are enough lines to fill the chip
   {
     ProfScope ps(&Ev, "fluid_k1", true);
     for (int r = 0; r < ps.reps; ++r)
-      hipLaunchKernelGGL((fluid_k1w_kernel<E, Q, LB>), dim3((Ev.nl + LPB - 1) / LPB, B), dim3(256), (size_t)LPB * 2 * n * 16, Ev.stream, d,
-                         (const Z*)omg_s, Ev.W.as<Z>());
+      hipLaunchKernelGGL((fluid_k1w_kernel<E, Q, LB>), dim3(((pair ? n / 2 + 1 : Ev.nl) + LPB - 1) / LPB, B), dim3(256),
+                         (size_t)LPB * 2 * n * 16, Ev.stream, d, (const Z*)omg_s, Ev.W.as<Z>(), pair);
   }
   {
     ProfScope ps(&Ev, "fluid_k2", true);
