@@ -124,6 +124,26 @@ function env_step!(h::UInt64, env, action)
     ynew, p, state, reward, done[] != 0
 end
 
+# T acting-only control steps -- action = clamp(actor(state) + randn * act_noise), (env::PDEenv)(action) -- in ONE call
+# (evaluation episodes / data collection: src/PDEagent.jl:175-209 + src/PDEenv.jl:195-241 without the host in the loop;
+# KS: one persistent launch).  y, state, action: device arrays (device_upload) updated in place; reward_sum [B][A]
+# accumulates.  The caller synchronises afterwards (pdec_sync).
+function rollout!(h::UInt64, actor, T::Integer, y::Ptr{Cvoid}, state::Ptr{Cvoid}, action::Ptr{Cvoid};
+                  act_noise = 0.0, act_limit = 1.0, learning = false, seed = 0, offset = 0, reward_sum = C_NULL)
+    check(ccall((:pdec_rollout, LIB), Cint,
+                (UInt64, UInt64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, UInt64, UInt64, Ptr{Cvoid},
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}),
+                h, actor.h, T, y, state, action, act_noise, act_limit, learning ? 1 : 0, seed, offset, reward_sum,
+                C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+end
+
+# for callers that run the fused KS step beside the update passes on a second stream: its 64-VGPR form (see pdeconv.h)
+function set_simd_sharing(h::UInt64, on::Bool)
+    eff = Ref{Cint}(0)
+    check(ccall((:pdec_env_set_simd_sharing, LIB), Cint, (UInt64, Cint, Ref{Cint}), h, on ? 1 : 0, eff))
+    eff[] != 0
+end
+
 # 2-D fluid: gaussians[i] are the `sparse` thresholded bumps of scripts/Fluid/setup/FluidSetup.jl:139-161, passed as
 # the dense BW x BH box around the periodic support of each (boxes [S][BW][BH], origin (j0, i0), 0-based)
 function fluid_env_create(cfg::EnvCfg, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s)
