@@ -1,6 +1,7 @@
 // common.hpp -- handle registry, error plumbing, per-kernel event timing for libpdeconv.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -79,6 +80,21 @@ struct ProfScope {
     }
   }
 };
+
+// One profiled launch timed by the DISPATCH's own begin / end timestamps (hipExtLaunchKernelGGL attaches the two events to
+// the kernel packet): no marker packets in front of and behind the kernel, so the figure is what rocprofv3's kernel trace
+// reports.  Event records around the launch (ProfScope) cost the kernel ~6 us of apparent duration in the two-stream
+// pipeline (72.6 vs 65.7 us for the critic pass).  Used for the single-launch (reps == 1) profile of the two MFMA passes.
+#define PDEC_TIMED_LAUNCH(obj, label, kern, grid, block, lds, ...)                                              \
+  do {                                                                                                           \
+    hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                                   \
+    (void)hipEventCreate(&e0__);                                                                                 \
+    (void)hipEventCreate(&e1__);                                                                                 \
+    hipExtLaunchKernelGGL(kern, grid, block, lds, (obj)->stream, e0__, e1__, 0, __VA_ARGS__);                    \
+    ProfEntry& pe__ = (obj)->profs[label];                                                                       \
+    pe__.ev.emplace_back(e0__, e1__);                                                                            \
+    pe__.reps = 1;                                                                                               \
+  } while (0)
 
 // Host-side slot selectors of double-buffered device state (ADAM beta powers, noise counter, published actor image)
 // flip once per launch that uses them.  A launch recorded into a HIP graph flips them at CAPTURE time only, so a

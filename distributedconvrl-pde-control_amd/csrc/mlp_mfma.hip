@@ -867,7 +867,9 @@ static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
     if (C->stamps.bytes < (size_t)grid * 16 * 8) PDEC_HIP(C->stamps.alloc((size_t)grid * 16 * 8));
     ga.stamps = C->stamps.as<unsigned long long>();
   }
-  {
+  if (C->prof && C->prof_reps == 1) {
+    PDEC_TIMED_LAUNCH(C, "ddpg_critic_fused", kern, dim3(grid), dim3(FTHREADS), lds, ga);
+  } else {
     ProfScope ps(C, "ddpg_critic_fused", true);
     for (int rep = 0; rep < ps.reps; ++rep)
       hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, ga);
@@ -885,9 +887,13 @@ static int launch_actor(Mlp* C, const FusedArgs& g, int grid) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  ProfScope ps(C, "ddpg_actor_fused", true);
-  for (int rep = 0; rep < ps.reps; ++rep)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
+  if (C->prof && C->prof_reps == 1) {
+    PDEC_TIMED_LAUNCH(C, "ddpg_actor_fused", kern, dim3(grid), dim3(FTHREADS), lds, g);
+  } else {
+    ProfScope ps(C, "ddpg_actor_fused", true);
+    for (int rep = 0; rep < ps.reps; ++rep)
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, g);
+  }
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
@@ -923,9 +929,13 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   }
   const int n = M->nparams;
   {
-    ProfScope ps(M, ap ? (nslab > 0 ? "fused_finish" : "fused_apply") : "fused_reduce");
+    const char* label = ap ? (nslab > 0 ? "fused_finish" : "fused_apply") : "fused_reduce";
     const int nblk = nslab > 0 ? 4 * slab_tiles(MT) : (n + 63) / 64;
-    hipLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(1024), 0, M->stream, g);
+    if (M->prof) {
+      PDEC_TIMED_LAUNCH(M, label, fused_finish_kernel, dim3(nblk), dim3(1024), 0, g);
+    } else {
+      hipLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(1024), 0, M->stream, g);
+    }
   }
   PDEC_HIP(hipGetLastError());
   if (ap) {
@@ -951,17 +961,19 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
   const int tanh_out = A->acts[2] == PDEC_ACT_TANH;
   PDEC_REQUIRE(A->acts[2] == PDEC_ACT_TANH || A->acts[2] == PDEC_ACT_IDENTITY, "fused act: unsupported output activation");
   PDEC_REQUIRE(mta <= 2 && lds <= 64 * 1024, "fused act: hidden width %d too large", A->dims[1]);
-  ProfScope ps(A, "policy_act_fused");
   const int prio = env_prio("PDEC_PRIO_ACT", 3);
   const dim3 grid((cols + 63) / 64), block(ACT_THREADS);
-  if (mta == 1)
-    hipLaunchKernelGGL(policy_act_fused_kernel<1>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
-                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out, ctr_cur, ctr_next,
-                       ctr_inc, prio);
-  else
-    hipLaunchKernelGGL(policy_act_fused_kernel<2>, grid, block, lds, A->stream, f, (const float*)state, cols, A->dims[0],
-                       (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, (float*)actions_out, ctr_cur, ctr_next,
-                       ctr_inc, prio);
+#define ACT_ARGS f, (const float*)state, cols, A->dims[0], (float)act_noise, (float)act_limit, learning, tanh_out, seed, offset, \
+                 (float*)actions_out, ctr_cur, ctr_next, ctr_inc, prio
+  if (A->prof) {
+    if (mta == 1) PDEC_TIMED_LAUNCH(A, "policy_act_fused", policy_act_fused_kernel<1>, grid, block, lds, ACT_ARGS);
+    else PDEC_TIMED_LAUNCH(A, "policy_act_fused", policy_act_fused_kernel<2>, grid, block, lds, ACT_ARGS);
+  } else if (mta == 1) {
+    hipLaunchKernelGGL(policy_act_fused_kernel<1>, grid, block, lds, A->stream, ACT_ARGS);
+  } else {
+    hipLaunchKernelGGL(policy_act_fused_kernel<2>, grid, block, lds, A->stream, ACT_ARGS);
+  }
+#undef ACT_ARGS
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
