@@ -420,6 +420,28 @@ def _make_pipeline(pkg, use_graphs, B=64, E=17, lag=2, two_layer=False):
                              chunks=(6, 1), noise_seed=99)
 
 
+def test_pipeline_with_the_simd_sharing_step_tracks_the_register_form(pkg, monkeypatch):
+    """The training pipeline asks for the 64-VGPR form of the fused KS step (pdec_env_set_simd_sharing).  The same 30
+    control steps (acting, PDE step, DDPG update each step, one episode boundary) with the register form instead
+    (PDEC_SHARE=0): same arithmetic in the same order, so fields, actions and the trained networks agree to fp32 round-off
+    amplified over the steps -- a wrong constant slot or sub-step would show up at once at this size."""
+    monkeypatch.setenv("PDEC_SHARE", "1")
+    pa = _make_pipeline(pkg, False)
+    monkeypatch.setenv("PDEC_SHARE", "0")
+    pb = _make_pipeline(pkg, False)
+    assert pa.simd_sharing and not pb.simd_sharing
+    pa.run(30); pb.run(30)
+    pa.sync(); pb.sync()
+    assert bool(torch.isfinite(pa.y).all())
+    assert float((pa.y - pb.y).abs().max()) <= 2e-3 * float(pb.y.abs().max())
+    assert float((pa.aring[(pa.tick - 1) % 3] - pb.aring[(pb.tick - 1) % 3]).abs().max()) <= 2e-3
+    for n in ("behavior_actor", "behavior_critic"):
+        for x, y in zip(getattr(pa.policy, n).model.params(), getattr(pb.policy, n).model.params()):
+            assert np.abs(x - y).max() <= 2e-4 * max(1.0, np.abs(y).max()), n
+    pa.close()
+    assert not pa.simd_sharing and not pa.env.set_simd_sharing(False)       # close() hands the env back in its register form
+
+
 @pytest.mark.parametrize("lag,two_layer", [(2, False), (1, False), (2, True)])
 def test_graph_replay_is_bit_identical_to_the_eager_pipeline(pkg, lag, two_layer):
     """row F2: the two-stream control step replayed from captured HIP graphs (chunks of 6 and 1 steps, first / last step
