@@ -92,7 +92,7 @@ SIGNATURES = {
     "pdec_env_random_init": [Handle, _u64, _u64, _vp],
     "pdec_capture_begin": [Handle], "pdec_capture_end": [Handle, C.POINTER(Handle)],
     "pdec_graph_launch": [Handle, _vp], "pdec_graph_num_nodes": [Handle, C.POINTER(_i)],
-    "pdec_event_create": [C.POINTER(Handle)], "pdec_event_record": [Handle, _vp], "pdec_stream_wait_event": [_vp, Handle],
+    "pdec_event_create": [C.POINTER(Handle)], "pdec_event_record": [Handle, _vp], "pdec_stream_wait_event": [_vp, Handle], "pdec_mlp_set_stop_event": [Handle, Handle], "pdec_mlp_flush_stop_event": [Handle],
     "pdec_env_set_simd_sharing": [Handle, C.c_int, C.POINTER(C.c_int)],
     "pdec_ddpg_critic_grads": [Handle] * 4 + [_vp] * 5 + [_i, _d, _i, _d, _vp],
     "pdec_ddpg_actor_grads": [Handle, Handle, _vp, _i, _d, _vp],

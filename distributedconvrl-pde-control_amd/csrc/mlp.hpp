@@ -19,6 +19,7 @@ struct Mlp : Object {
   DevBuf bpd;                        // double [2][2]
   int bp_sel = 0;
   bool bp_init = false;
+  hipEvent_t stop_event = nullptr;   // one-shot (pdec_mlp_set_stop_event): attached to the next reduction / update launch on this net
   const float* rpart_ext = nullptr;  // per-workgroup reward sums of the producer (pdec_ddpg_set_reward_partials), consumed likewise
   int rpart_n = 0;
   const void* rbar_ext = nullptr;    // batch-mean reward reduced elsewhere (pdec_ddpg_set_reward_mean), consumed by the next critic pass

@@ -933,9 +933,15 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
     const int nblk = nslab > 0 ? 4 * slab_tiles(MT) : (n + 63) / 64;
     if (M->prof) {
       PDEC_TIMED_LAUNCH(M, label, fused_finish_kernel, dim3(nblk), dim3(1024), 0, g);
+      if (M->stop_event && ap) (void)hipEventRecord(M->stop_event, M->stream);
+    } else if (M->stop_event && ap) {
+      // the event rides on this kernel's own dispatch packet (its completion signal): a hipEventRecord behind the
+      // launch is a packet of its own that the next kernel of the stream has to wait for (~4.5 us of the update chain)
+      hipExtLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(1024), 0, M->stream, nullptr, M->stop_event, 0, g);
     } else {
       hipLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(1024), 0, M->stream, g);
     }
+    if (ap) M->stop_event = nullptr;     // consumed by the launch that applies the update (not by a reduce-only one)
   }
   PDEC_HIP(hipGetLastError());
   if (ap) {

@@ -378,6 +378,33 @@ int pdec_event_record(pdec_handle ev, void* hip_stream) {
   PDEC_HIP(hipEventRecord(e->ev, (hipStream_t)hip_stream));
   return PDEC_OK;
 }
+// One-shot: the next slab-reduction / ADAM launch issued on `mlp` (the second kernel of pdec_ddpg_update_critic_async /
+// _actor_async on the fused 3-layer path) carries `event` as the completion event of its own dispatch packet -- equivalent
+// to pdec_event_record(event, stream) right behind that launch, without the separate packet.  Returns PDEC_E_INVALID for
+// networks outside that path (the caller records the event itself).
+int pdec_mlp_set_stop_event(pdec_handle mlp, pdec_handle event) {
+  Mlp* M = lookup_as<Mlp>(mlp, Kind::Mlp);
+  if (!M) { set_error("pdec_mlp_set_stop_event: bad handle"); return PDEC_E_HANDLE; }
+  if (!event) { M->stop_event = nullptr; return PDEC_OK; }
+  Event* e = lookup_as<Event>(event, Kind::Event);
+  if (!e) { set_error("pdec_mlp_set_stop_event: bad event handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(fused_net_supported(M), "pdec_mlp_set_stop_event: fused 3-layer networks only");
+  M->stop_event = e->ev;
+  return PDEC_OK;
+}
+
+// An event set by pdec_mlp_set_stop_event that no launch has consumed (the update took another path) is recorded on the
+// net's stream now, so a waiter never sees a stale event; no-op otherwise.
+int pdec_mlp_flush_stop_event(pdec_handle mlp) {
+  Mlp* M = lookup_as<Mlp>(mlp, Kind::Mlp);
+  if (!M) { set_error("pdec_mlp_flush_stop_event: bad handle"); return PDEC_E_HANDLE; }
+  if (M->stop_event) {
+    PDEC_HIP(hipEventRecord(M->stop_event, M->stream));
+    M->stop_event = nullptr;
+  }
+  return PDEC_OK;
+}
+
 int pdec_stream_wait_event(void* hip_stream, pdec_handle ev) {
   Event* e = lookup_as<Event>(ev, Kind::Event);
   if (!e) { set_error("pdec_stream_wait_event: bad handle"); return PDEC_E_HANDLE; }

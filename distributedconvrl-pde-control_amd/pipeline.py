@@ -147,6 +147,9 @@ class TrainPipeline:
         self.kick_env_after_critic = (not self.act_in_place) if kick_env_after_critic is None else bool(kick_env_after_critic)
         if os.environ.get("PDEC_KICK") in ("0", "1"):               # diagnostic override
             self.kick_env_after_critic = os.environ["PDEC_KICK"] == "1"
+        # events attached to the reduction launches instead of recorded behind them (see _issue); PDEC_STOP_EVENTS=0: records
+        self.stop_events = (self.rpart is not None and Ev is _Event and not self.serial and not self.multi_rank
+                            and os.environ.get("PDEC_STOP_EVENTS", "1") != "0")
         # two streams + the fused 3-layer passes: ask for the PDE step's 64-VGPR form, whose waves can share a SIMD with the
         # 222-VGPR critic pass instead of excluding it per CU (csrc/env.hip, SHARE); PDEC_SHARE=0: the register form
         self.simd_sharing = False
@@ -260,12 +263,22 @@ class TrainPipeline:
             # released when the critic half (pass + reduction) is done it runs beside the actor pass, the second
             # reduction and the head of the next critic pass instead (r02i, same box: 152 -> 130 us per control step)
             if kick:
-                self.ev_mid.record(self.s_upd)
+                if use_stop:
+                    L.check(lib.pdec_mlp_flush_stop_event(pol.behavior_critic.model.handle))     # no-op when consumed
+                else:
+                    self.ev_mid.record(self.s_upd)
                 self.ev_mid.wait(self.s_env)
                 env_part()
             if self.act_in_place and not self.serial:
                 self.ev_act[k % 2].wait(self.s_upd)
 
+        # eager steps on the fused 3-layer path: the two events the env stream waits for ride on the reduction launches' own
+        # dispatch packets (pdec_mlp_set_stop_event) instead of being recorded as packets behind them
+        use_stop = self.stop_events and batch is not None and not capturing and not self.serial
+        if use_stop:
+            if kick:
+                L.check(lib.pdec_mlp_set_stop_event(pol.behavior_critic.model.handle, self.ev_mid.h))
+            L.check(lib.pdec_mlp_set_stop_event(pol.behavior_actor.model.handle, self.ev_upd[k % 2].h))
         with torch.cuda.stream(self.s_upd):
             if batch is not None:
                 if self.rpart is not None:
@@ -276,7 +289,9 @@ class TrainPipeline:
                     pol.update(batch, before_actor_half=between_halves)
                 else:
                     pol.update(batch)
-            if not self.serial:
+            if use_stop:
+                L.check(lib.pdec_mlp_flush_stop_event(pol.behavior_actor.model.handle))          # no-op when consumed
+            elif not self.serial:
                 self.ev_upd[k % 2].record(self.s_upd)
         if chunk_last and not self.serial:
             self.ev_upd[k % 2].wait(self.s_env)    # join: the graph ends on the env stream

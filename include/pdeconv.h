@@ -399,6 +399,13 @@ int pdec_capture_begin(pdec_handle origin);
 int pdec_capture_end(pdec_handle origin, pdec_handle* graph);
 int pdec_graph_launch(pdec_handle graph, void* hip_stream);      /* NULL = the stream it was captured on */
 int pdec_graph_num_nodes(pdec_handle graph, int* n);
+/* One-shot: the next slab-reduction / ADAM launch issued on `mlp` (the second kernel of pdec_ddpg_update_critic_async /
+ * pdec_ddpg_update_actor_async on the fused 3-layer path) carries `event` as the completion event of its own dispatch
+ * packet: what pdec_event_record(event, stream) right behind that call would give, without the record's own packet in the
+ * stream (each costs the update chain ~4.5 us).  PDEC_E_INVALID for networks outside that path. */
+int pdec_mlp_set_stop_event(pdec_handle mlp, pdec_handle event);
+/* records a still pending stop event on the net's stream (the update took a path that does not consume it); else no-op */
+int pdec_mlp_flush_stop_event(pdec_handle mlp);
 /* Device-scope events for the hand-offs between two streams of one device (no system-scope cache fence, unlike a
  * default HIP event): record on one stream, make another stream wait.  Released with pdec_destroy. */
 int pdec_event_create(pdec_handle* ev);
