@@ -37,15 +37,32 @@ __device__ __forceinline__ void sense_dots(const EnvDev<T>& e, YF yf, T* dots, T
     if (j1 > Wd) j1 = Wd;
     int n = e.sn0[s] + j0;
     if (n >= N) n -= N;
-    T a0 = 0, a1 = 0;
-    for (int j = j0; j < j1; ++j) {
+    // eight table rows in flight and four independent partial sums per trajectory: the loop used to be one load-to-use
+    // latency per row (11 k cycles of the 77 k-cycle C2 step for a 90-row band)
+    T p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+    int j = j0;
+    for (; j + 8 <= j1; j += 8) {
+      T gk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gk[u] = e.Gs[(size_t)(j + u) * S + s];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int nn = n + u;
+        nn = nn >= N ? nn - N : nn;
+        p0[u & 3] += gk[u] * yf(0, nn);
+        p1[u & 3] += gk[u] * yf(1, nn);
+      }
+      n += 8;
+      if (n >= N) n -= N;
+    }
+    for (; j < j1; ++j) {
       const T gk = e.Gs[(size_t)j * S + s];
-      a0 += gk * yf(0, n);
-      a1 += gk * yf(1, n);
+      p0[0] += gk * yf(0, n);
+      p1[0] += gk * yf(1, n);
       if (++n == N) n = 0;
     }
-    part[(grp * 2 + 0) * S + s] = a0;
-    part[(grp * 2 + 1) * S + s] = a1;
+    part[(grp * 2 + 0) * S + s] = (p0[0] + p0[1]) + (p0[2] + p0[3]);
+    part[(grp * 2 + 1) * S + s] = (p1[0] + p1[1]) + (p1[2] + p1[3]);
   }
   __syncthreads();
   for (int idx = tid; idx < 2 * S; idx += nt) {
@@ -108,6 +125,11 @@ __device__ __forceinline__ void featurize_traj(const EnvDev<T>& e, const T* dots
     for (int s = tid; s < e.S; s += nt) state[s] = dots[s] * e.sensor_scale;
     return;
   }
+  if (e.fmap) {                         // temporal_steps == 1: every row is fresh -- one gather through the map built at creation (the general
+    const int tot = e.A * e.ns;         // path below spends ~40 instructions per element on divisions by run-time values)
+    for (int idx = tid; idx < tot; idx += nt) state[idx] = dots[e.fmap[idx]] * e.sensor_scale;
+    return;
+  }
   const int w = e.window / 2;
   const int fresh = e.window * e.n_species;
   for (int idx = tid; idx < e.A * e.ns; idx += nt) {
@@ -123,6 +145,42 @@ __device__ __forceinline__ void featurize_traj(const EnvDev<T>& e, const T* dots
       v = prev[a * e.ns + (rr - fresh)];
     }
     state[idx] = v;
+  }
+}
+
+// reward + featurize of the TWO trajectories of a workgroup in one pass each (per-actuator agents, temporal_steps == 1): the
+// table loads (a2s, gsum, fmap) are shared and the two trajectories' load-to-use latencies overlap instead of following
+// each other (3.6 k + 2.2 k cycles of the C2 step as four separate loops).  Same arithmetic per element as reward_traj /
+// featurize_traj.  r1 / st1 null: single trajectory.
+template <class T>
+__device__ __forceinline__ T reward_pair(const EnvDev<T>& e, const T* dots0, const T* dots1, const T* act0, const T* act1,
+                                         const T* actp0, const T* actp1, T* r0, T* r1, int tid, int nt) {
+  T mine = 0;
+  for (int a = tid; a < e.A; a += nt) {
+    const int s = e.a2s[a];
+    const T off = e.r_offset * e.gsum[s];
+    const T d0 = e.r_in_scale * (dots0[s] + off);
+    const T da0 = act0[a] - actp0[a];
+    const T v0 = -pow_abs<T>(d0, e.r_power) / e.r_denom - e.a_pun * act0[a] * act0[a] - e.da_pun * da0 * da0;
+    r0[a] = v0;
+    mine += v0;
+    if (r1) {
+      const T d1 = e.r_in_scale * (dots1[s] + off);
+      const T da1 = act1[a] - actp1[a];
+      const T v1 = -pow_abs<T>(d1, e.r_power) / e.r_denom - e.a_pun * act1[a] * act1[a] - e.da_pun * da1 * da1;
+      r1[a] = v1;
+      mine += v1;
+    }
+  }
+  return mine;
+}
+template <class T>
+__device__ __forceinline__ void featurize_pair(const EnvDev<T>& e, const T* dots0, const T* dots1, T* st0, T* st1, int tid, int nt) {
+  const int tot = e.A * e.ns;
+  for (int idx = tid; idx < tot; idx += nt) {
+    const int m = e.fmap[idx];
+    st0[idx] = dots0[m] * e.sensor_scale;
+    if (st1) st1[idx] = dots1[m] * e.sensor_scale;
   }
 }
 
@@ -150,6 +208,68 @@ __device__ __forceinline__ void actuate_cell2(const EnvDev<T>& e, const T* act0,
   }
   p0 = a0 * e.agent_power;
   p1 = a1 * e.agent_power;
+}
+
+// the KS_MPT cells a lane owns at once: their table rows are independent loads (one per cell and table row in flight
+// together, two rows unrolled) instead of one load-to-use latency per cell and row -- 5.4 k -> the C2 step's actuation;
+// per cell the sum runs over the rows in the same order as actuate_cell2
+template <class T, int M>
+__device__ __forceinline__ void actuate_cells(const EnvDev<T>& e, const T* act0, const T* act1, const int (&n)[M], T (&p0)[M],
+                                              T (&p1)[M]) {
+  int a[M];
+  bool ok[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    ok[j] = n[j] < e.N;
+    a[j] = ok[j] ? e.an0[n[j]] : 0;
+    p0[j] = 0; p1[j] = 0;
+  }
+#pragma unroll 2
+  for (int i = 0; i < e.Cnt; ++i) {
+    T gk[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) gk[j] = ok[j] ? e.GaC[(size_t)i * e.N + n[j]] : (T)0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      p0[j] += act0[a[j]] * gk[j];
+      p1[j] += act1[a[j]] * gk[j];
+      if (++a[j] == e.A) a[j] = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < M; ++j) { p0[j] *= e.agent_power; p1[j] *= e.agent_power; }
+}
+
+// All cells of both trajectories with FOUR CONSECUTIVE cells per lane: one 16/32-byte load per table row and lane (the rows
+// of a lane's cells tid + 64 j are four separate 4-byte loads: 92 loads per lane at C2, 5 k cycles of load-to-use
+// latency), results through an LDS scratch [2][N] from which every lane then takes the cells its transform owns.
+// Per cell the sum runs over the rows in the order of actuate_cell2.  Needs N % 4 == 0.
+template <class T>
+__device__ __forceinline__ void actuate_consecutive(const EnvDev<T>& e, const T* act0, const T* act1, T* scratch, int tid, int nt) {
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  const int N = e.N, A = e.A;
+  for (int c0 = 4 * tid; c0 < N; c0 += 4 * nt) {
+    int a[4];
+    T p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = e.an0[c0 + u];
+#pragma unroll 4
+    for (int i = 0; i < e.Cnt; ++i) {
+      const T4 g = *reinterpret_cast<const T4*>(e.GaC + (size_t)i * N + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p0[u] += act0[a[u]] * g[u];
+        p1[u] += act1[a[u]] * g[u];
+        if (++a[u] == A) a[u] = 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      scratch[c0 + u] = p0[u] * e.agent_power;
+      scratch[N + c0 + u] = p1[u] * e.agent_power;
+    }
+  }
+  __syncthreads();
 }
 
 template <class T>
@@ -667,13 +787,29 @@ __global__ void __launch_bounds__(ENG::kThreads, SHARE ? 8 : 1) ks_env_step_kern
   C2<T> U[KS_MPT], Nn[KS_MPT], Ck[KS_MPT], v[KS_MPT];
   T kc1[KS_MPT], kc2[KS_MPT], kc3[KS_MPT], kg[KS_MPT];
   // forcing p (packed pair) -> spectrum -> constant term of the CNAB2 update
+  T pa4[KS_MPT], pb4[KS_MPT];
+  if (FUSED) {
+    int n4[KS_MPT];
+#pragma unroll
+    for (int j = 0; j < KS_MPT; ++j) n4[j] = eng.phys_index(j);
+    if ((N & 3) == 0 && 2 * N <= 16 * e.S) {     // `part` ([8][2][S], free until the sensor dots) holds the [2][N] scratch
+      actuate_consecutive<T>(e, act, act + e.A, part, tid, nt);
+#pragma unroll
+      for (int j = 0; j < KS_MPT; ++j) {
+        pa4[j] = n4[j] < N ? part[n4[j]] : (T)0;
+        pb4[j] = n4[j] < N ? part[N + n4[j]] : (T)0;
+      }
+    } else {
+      actuate_cells<T, KS_MPT>(e, act, act + e.A, n4, pa4, pb4);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < KS_MPT; ++j) {
     const int n = eng.phys_index(j);
     T pa = 0, pb = 0;
     if (n < N) {
       if (FUSED) {
-        actuate_cell2<T>(e, act, act + e.A, n, pa, pb);
+        pa = pa4[j]; pb = pb4[j];
         if (!has1) pb = 0;
         if (p_out) {
           p_out[o0 + n] = pa;
@@ -806,12 +942,19 @@ __global__ void __launch_bounds__(ENG::kThreads, SHARE ? 8 : 1) ks_env_step_kern
   sense_dots<T>(e, [&](int r, int n) { return Rt[2 * n + r]; }, dots, part, tid, nt);
   const int rw = e.mono ? 1 : e.A;             // reward entries per trajectory
   const int sw = e.mono ? e.S : e.A * e.ns;    // state entries per trajectory
-  T rmine = reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b0 * rw, tid, nt);
-  featurize_traj<T>(e, dots, state_prev ? state_prev + (size_t)b0 * sw : nullptr, state_out + (size_t)b0 * sw, tid, nt);
-  if (has1) {
-    rmine += reward_traj<T>(e, dots + e.S, act + e.A, actp + e.A, reward_out + (size_t)b1 * rw, tid, nt);
-    featurize_traj<T>(e, dots + e.S, state_prev ? state_prev + (size_t)b1 * sw : nullptr,
-                      state_out + (size_t)b1 * sw, tid, nt);
+  T rmine;
+  if (e.fmap && !e.mono) {     // both trajectories in one pass each
+    rmine = reward_pair<T>(e, dots, dots + e.S, act, act + e.A, actp, actp + e.A, reward_out + (size_t)b0 * rw,
+                           has1 ? reward_out + (size_t)b1 * rw : nullptr, tid, nt);
+    featurize_pair<T>(e, dots, dots + e.S, state_out + (size_t)b0 * sw, has1 ? state_out + (size_t)b1 * sw : nullptr, tid, nt);
+  } else {
+    rmine = reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b0 * rw, tid, nt);
+    featurize_traj<T>(e, dots, state_prev ? state_prev + (size_t)b0 * sw : nullptr, state_out + (size_t)b0 * sw, tid, nt);
+    if (has1) {
+      rmine += reward_traj<T>(e, dots + e.S, act + e.A, actp + e.A, reward_out + (size_t)b1 * rw, tid, nt);
+      featurize_traj<T>(e, dots + e.S, state_prev ? state_prev + (size_t)b1 * sw : nullptr,
+                        state_out + (size_t)b1 * sw, tid, nt);
+    }
   }
   if (e.rsum_out) {
     // per-workgroup reward sum (fixed order: lanes by xor-shuffle, then waves in order) for the batch-mean reward of the
@@ -1064,12 +1207,29 @@ __global__ void __launch_bounds__(ENG::kThreads) ks_rollout_kernel(EnvDev<T> e, 
         if (has1) g.log_action[((size_t)t * e.B + b1) * A + a] = act[A + a];
       }
     // ---- prepare_action -> spectrum -> constant term of the CNAB2 update (KSSetup.jl:231-245, :155)
+    T pa4[KS_MPT], pb4[KS_MPT];
+    {
+      int n4[KS_MPT];
+#pragma unroll
+      for (int j = 0; j < KS_MPT; ++j) n4[j] = eng.phys_index(j);
+      if ((N & 3) == 0 && 2 * N <= 16 * e.S) {
+        actuate_consecutive<T>(e, act, act + A, part, tid, nt);
+#pragma unroll
+        for (int j = 0; j < KS_MPT; ++j) {
+          pa4[j] = n4[j] < N ? part[n4[j]] : (T)0;
+          pb4[j] = n4[j] < N ? part[N + n4[j]] : (T)0;
+        }
+        __syncthreads();      // `part` is reused by the sensor dots of this step
+      } else {
+        actuate_cells<T, KS_MPT>(e, act, act + A, n4, pa4, pb4);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < KS_MPT; ++j) {
       const int n = eng.phys_index(j);
       T pa = 0, pb = 0;
       if (n < N) {
-        actuate_cell2<T>(e, act, act + A, n, pa, pb);
+        pa = pa4[j]; pb = pb4[j];
         if (!has1) pb = 0;
         if (g.log_p) {
           g.log_p[((size_t)t * e.B + b0) * N + n] = pa;
@@ -1131,11 +1291,16 @@ __global__ void __launch_bounds__(ENG::kThreads) ks_rollout_kernel(EnvDev<T> e, 
     // ---- reward (KSSetup.jl:162-178) and featurize (:190-229) from the sensor dots of the new field
     const T* Rt = reinterpret_cast<const T*>(eng.publish(U));
     sense_dots<T>(e, [&](int r, int n) { return Rt[2 * n + r]; }, dots, part, tid, nt);
-    reward_traj<T>(e, dots, act, actp, rnow, tid, nt);
-    featurize_traj<T>(e, dots, nullptr, stl, tid, nt);
-    if (has1) {
-      reward_traj<T>(e, dots + e.S, act + A, actp + A, rnow + A, tid, nt);
-      featurize_traj<T>(e, dots + e.S, nullptr, stl + A * ns, tid, nt);
+    if (e.fmap) {
+      reward_pair<T>(e, dots, dots + e.S, act, act + A, actp, actp + A, rnow, has1 ? rnow + A : nullptr, tid, nt);
+      featurize_pair<T>(e, dots, dots + e.S, stl, has1 ? stl + A * ns : nullptr, tid, nt);
+    } else {
+      reward_traj<T>(e, dots, act, actp, rnow, tid, nt);
+      featurize_traj<T>(e, dots, nullptr, stl, tid, nt);
+      if (has1) {
+        reward_traj<T>(e, dots + e.S, act + A, actp + A, rnow + A, tid, nt);
+        featurize_traj<T>(e, dots + e.S, nullptr, stl + A * ns, tid, nt);
+      }
     }
     __syncthreads();
     for (int a = tid; a < A; a += nt) {
@@ -1471,6 +1636,7 @@ static EnvDev<T> make_dev(const Env& E) {
   e.Gs = E.Gs.as<T>(); e.sn0 = E.sn0.as<int>(); e.GaC = E.GaC.as<T>(); e.an0 = E.an0.as<int>();
   e.Wd = E.Wd; e.Cnt = E.Cnt;
   e.gsum = E.gsum.as<T>(); e.a2s = E.a2s.as<int>();
+  e.fmap = E.fmap.p ? E.fmap.as<int>() : nullptr;
   e.term_out = static_cast<T*>(E.term_out);
   e.rsum_out = E.rsum_out;
   e.c1 = E.c1.as<T>(); e.c2 = E.c2.as<T>(); e.c3 = E.c3.as<T>(); e.c4 = E.c4.as<T>(); e.g = E.g.as<T>();
@@ -1795,6 +1961,20 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
   PDEC_HIP(hipMemcpy(E->an0.p, an0.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
   PDEC_HIP(E->a2s.alloc(sizeof(int32_t) * c.A));
   PDEC_HIP(hipMemcpy(E->a2s.p, a2s_h.data(), sizeof(int32_t) * c.A, hipMemcpyHostToDevice));
+  if (!c.mono && c.temporal_steps == 1) {
+    // featurize as one gather (KSSetup.jl:190-229 without temporal stacking): state[a][rr] = dots[sp][(a2s[a] - i) mod S]
+    const int ns1 = c.window * c.n_species, w = c.window / 2;
+    std::vector<int32_t> fm((size_t)c.A * ns1);
+    for (int a = 0; a < c.A; ++a)
+      for (int rr = 0; rr < ns1; ++rr) {
+        const int sp = rr / c.window, i = (rr - sp * c.window) - w;
+        int s = (a2s_h[a] - i) % c.S;
+        if (s < 0) s += c.S;
+        fm[(size_t)a * ns1 + rr] = sp * c.S + s;
+      }
+    PDEC_HIP(E->fmap.alloc(sizeof(int32_t) * fm.size()));
+    PDEC_HIP(hipMemcpy(E->fmap.p, fm.data(), sizeof(int32_t) * fm.size(), hipMemcpyHostToDevice));
+  }
   *h = register_object(std::move(E));
   return PDEC_OK;
 }

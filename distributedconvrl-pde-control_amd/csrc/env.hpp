@@ -22,6 +22,7 @@ struct EnvDev {
   T* term_out;           // optional [B][cols per trajectory]: 1.0 where the trajectory blew up (pdec_env_set_terminal_out)
   const T* gsum;         // [S]     sum of each sensor kernel (reward offset term)
   const int* a2s;        // [A]
+  const int* fmap;       // [A * ns] or null: state[idx] = dots[fmap[idx]] * sensor_scale (featurize without index arithmetic)
   // KS CNAB2 per-mode constants
   const T *c1, *c2, *c3, *c4, *g;
   const C2<T>* dhat;     // h * fft(mu cos(...))
@@ -31,7 +32,7 @@ struct EnvDev {
 
 struct Env : Object {
   pdec_env_cfg cfg;
-  DevBuf Gs, sn0, GaC, an0, gsum, a2s, c1, c2, c3, c4, g, dhat, tw;
+  DevBuf Gs, sn0, GaC, an0, gsum, a2s, fmap, c1, c2, c3, c4, g, dhat, tw;
   int Wd = 0, Cnt = 0;
   DevBuf stage;  // staging for the _host wrappers
   DevBuf roll;   // ping-pong buffers of pdec_rollout
