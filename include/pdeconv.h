@@ -323,7 +323,7 @@ int pdec_reward_mean(pdec_handle any_handle, const void* r, int n, void* mean_ou
 /* For callers that run the fused KS step beside the f32-MFMA update passes on a second stream (the two-stream training
  * step): launch the step in the form that needs <= 64 VGPRs -- per-mode constants in LDS instead of registers -- so that a
  * wave of it can share a SIMD with two waves of the 222-VGPR critic pass instead of excluding a whole workgroup of it
- * (and being excluded by it) per CU; that form also runs at wave priority 3.  Alone it is slower (42 vs 30 us at C2), so
+ * (and being excluded by it) per CU; that form also runs at wave priority 3.  Alone it is slower (37 vs 29 us at C2), so
  * it is off by default.  *effective = 1 when the environment has such a form (KS CNAB2, N = 256, fp32), else 0. */
 int pdec_env_set_simd_sharing(pdec_handle env, int on, int* effective);
 /* the same without any extra launch for the fused KS step + 3-layer fused critic: every later pdec_env_step also writes the
