@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(ENG::kThreads, SHARE ? 8 : 1) ks_env_step_kern
   // the next pass (75 us in the pipeline against 63 alone, r02j).  The SHARE form keeps the per-mode constants, the
   // constant term and the previous nonlinear term in LDS (LDSC below), is bounded to 64 VGPRs (2 x 224 + 64 = 512) and
   // runs at priority 3: it is over before the next pass needs the registers, and the pass keeps its alone time (r02l:
-  // 135 -> 125 us per control step).  Alone the SHARE form is slower (42 vs 30 us: four exposed LDS round trips per
+  // 135 -> 125 us per control step).  Alone the SHARE form is slower (37 vs 29 us: four exposed LDS round trips per
   // sub-step), so only the two-stream training pipeline asks for it.
   set_wave_prio(e.prio);
   ENG eng;
