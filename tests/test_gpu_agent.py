@@ -442,6 +442,38 @@ def test_pipeline_with_the_simd_sharing_step_tracks_the_register_form(pkg, monke
     assert not pa.simd_sharing and not pa.env.set_simd_sharing(False)       # close() hands the env back in its register form
 
 
+def test_events_riding_on_the_reduction_launches_change_nothing(pkg, monkeypatch):
+    """pdec_mlp_set_stop_event: the two events the env stream waits for are attached to the reduction launches' own dispatch
+    packets instead of being recorded behind them (PDEC_STOP_EVENTS=0).  Pure synchronisation: 40 control steps, across an
+    episode boundary, give bit-identical fields, actions, rewards and networks either way; a stop event nobody consumes is
+    recorded by pdec_mlp_flush_stop_event."""
+    monkeypatch.setenv("PDEC_STOP_EVENTS", "1")
+    pa = _make_pipeline(pkg, False)
+    monkeypatch.setenv("PDEC_STOP_EVENTS", "0")
+    pb = _make_pipeline(pkg, False)
+    assert pa.stop_events and not pb.stop_events
+    pa.run(40); pb.run(40)
+    pa.sync(); pb.sync()
+    assert torch.equal(pa.y, pb.y) and torch.equal(pa.state, pb.state) and bool(torch.isfinite(pa.y).all())
+    for k in range(3):
+        assert torch.equal(pa.aring[k], pb.aring[k]) and torch.equal(pa.rring[k], pb.rring[k])
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        for x, y in zip(getattr(pa.policy, n).model.params(), getattr(pb.policy, n).model.params()):
+            assert np.array_equal(x, y), n
+    # an armed event that no launch consumes: flushed as a plain record, after which a waiter is released
+    import ctypes as C
+    L = pkg._lib
+    ev = L.Handle()
+    L.check(pa.lib.pdec_event_create(C.byref(ev)))
+    h = pa.policy.behavior_actor.model.handle
+    L.check(pa.lib.pdec_mlp_set_stop_event(h, ev))
+    L.check(pa.lib.pdec_mlp_flush_stop_event(h))
+    L.check(pa.lib.pdec_mlp_flush_stop_event(h))           # second call: nothing pending, no-op
+    L.check(pa.lib.pdec_stream_wait_event(C.c_void_p(pa.s_env.cuda_stream), ev))
+    pa.sync()
+    pa.lib.pdec_destroy(ev)
+
+
 @pytest.mark.parametrize("lag,two_layer", [(2, False), (1, False), (2, True)])
 def test_graph_replay_is_bit_identical_to_the_eager_pipeline(pkg, lag, two_layer):
     """row F2: the two-stream control step replayed from captured HIP graphs (chunks of 6 and 1 steps, first / last step
