@@ -494,37 +494,16 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
 // Used when the padded length p is one of 64/128/192/256/384/512/768 (otherwise the LDS-tile kernels above); 64 and
 // 192 run two lines per wave (half-wave transforms).
 
-// K1w: one wave per PAIR of carried lines (a line and its mirror, see below).  LDS: per wave the two spectrum lines j and mirror(j) (2 n complex).
+// the spectral part of K1w for one work item: from the two spectrum lines in LDS (Lj: line j0, Lm: its mirror j1) the
+// packed inverse transforms of the carried line t and -- nhalf = 2 -- of its mirror line s_mirror
 template <int E, int Q, int LB>
-__global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, const C2<double>* __restrict__ omg,
-                                                        C2<double>* __restrict__ W, int pair) {
+__device__ __forceinline__ void fluid_k1w_body(const FluidDev<double>& d, const C2<double>* Lj, const C2<double>* Lm, int j0, int j1,
+                                               int t, int s_mirror, int nhalf, C2<double>* __restrict__ W, int b,
+                                               WaveFftD<E, Q, LB>& f, int l) {
   typedef WaveFftD<E, Q, LB> F;
   typedef C2<double> Z;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  // a "line slot" is a wave (LB = 6) or a half wave (LB = 5: two lines per wave); l = position inside the line
-  const int lane = threadIdx.x & 63, l = lane & (F::LANES - 1), slot = (threadIdx.x >> 6) * F::LPW + (lane >> LB);
   const int n = d.n, p = d.p;
-  Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)slot * 2 * n;
-  Z* Lm = Lj + n;
-  // work item t = carried line t (jp = t <= n/2) TOGETHER WITH its mirror line (jp' = p - t): both need exactly the
-  // spectrum lines j and mirror(j) -- with the roles swapped -- so one load of the two lines serves two output lines
-  // (half the reads of omg and half the exposed load latency per transform); line 0 is its own mirror
-  // (pair = 0: one carried line per slot, every line loads its two spectrum lines itself -- more, shorter waves: better
-  // for the small grids, n = 128: 12.8 vs 15.2 us)
-  const int t = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
-  if (t >= (pair ? n / 2 + 1 : d.nl)) return;             // whole line slot; the kernel has no workgroup barrier
-  const int jp = fl_line_jp(t, n, p, d.nl), jpm = (p - jp) % p;
-  const int s_mirror = fl_line_of(jpm, n, p, d.nl);
-  const int j0 = fl_unpad(jp, n, p), j1 = fl_unpad(jpm, n, p);
   const Z zero = mk<double>(0, 0);
-  for (int i = l; i < n; i += F::LANES) {
-    Lj[i] = j0 >= 0 ? omg[((size_t)b * n + j0) * n + i] : zero;
-    Lm[i] = j1 >= 0 ? omg[((size_t)b * n + j1) * n + i] : zero;
-  }
-  __builtin_amdgcn_wave_barrier();
-  F f;
-  f.init(d.twp, lane);
-  const int nhalf = (pair && s_mirror >= 0 && s_mirror != t) ? 2 : 1;
 #pragma unroll 1
   for (int half = 0; half < nhalf; ++half) {
     const Z* La = half ? Lm : Lj;     // the line's own spectrum / its mirror's
@@ -569,6 +548,40 @@ __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, cons
       for (int jj = 0; jj < F::R; ++jj) w[l + F::LANES * jj] = a[jj];
     }
   }
+}
+
+// K1w: one wave per PAIR of carried lines (a line and its mirror, see below).  LDS: per wave the two spectrum lines j and mirror(j) (2 n complex).
+template <int E, int Q, int LB>
+__global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, const C2<double>* __restrict__ omg,
+                                                        C2<double>* __restrict__ W, int pair) {
+  typedef WaveFftD<E, Q, LB> F;
+  typedef C2<double> Z;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  // a "line slot" is a wave (LB = 6) or a half wave (LB = 5: two lines per wave); l = position inside the line
+  const int lane = threadIdx.x & 63, l = lane & (F::LANES - 1), slot = (threadIdx.x >> 6) * F::LPW + (lane >> LB);
+  const int n = d.n, p = d.p;
+  Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)slot * 2 * n;
+  Z* Lm = Lj + n;
+  // work item t = carried line t (jp = t <= n/2) TOGETHER WITH its mirror line (jp' = p - t): both need exactly the
+  // spectrum lines j and mirror(j) -- with the roles swapped -- so one load of the two lines serves two output lines
+  // (half the reads of omg and half the exposed load latency per transform); line 0 is its own mirror
+  // (pair = 0: one carried line per slot, every line loads its two spectrum lines itself -- more, shorter waves: better
+  // for the small grids, n = 128: 12.8 vs 15.2 us)
+  const int t = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
+  if (t >= (pair ? n / 2 + 1 : d.nl)) return;             // whole line slot; the kernel has no workgroup barrier
+  const int jp = fl_line_jp(t, n, p, d.nl), jpm = (p - jp) % p;
+  const int s_mirror = fl_line_of(jpm, n, p, d.nl);
+  const int j0 = fl_unpad(jp, n, p), j1 = fl_unpad(jpm, n, p);
+  const Z zero = mk<double>(0, 0);
+  for (int i = l; i < n; i += F::LANES) {
+    Lj[i] = j0 >= 0 ? omg[((size_t)b * n + j0) * n + i] : zero;
+    Lm[i] = j1 >= 0 ? omg[((size_t)b * n + j1) * n + i] : zero;
+  }
+  __builtin_amdgcn_wave_barrier();
+  F f;
+  f.init(d.twp, lane);
+  const int nhalf = (pair && s_mirror >= 0 && s_mirror != t) ? 2 : 1;
+  fluid_k1w_body<E, Q, LB>(d, Lj, Lm, j0, j1, t, s_mirror, nhalf, W, b, f, l);
 }
 
 // K2w: TC columns per workgroup, one wave per column.  LDS: the [TC][p] column tile (transposition + permuted access).
@@ -678,6 +691,83 @@ __global__ __launch_bounds__(256) void fluid_k3w_kernel(FluidDev<double> d, cons
       }
     }
   }
+}
+
+// K31w = K3w of one RK4 stage fused with K1w of the NEXT right-hand side (src/fluid_rk4.jl:122-190 inside rk4, :192-229):
+// the stage value K3 writes for a kept line j is exactly the spectrum line K1 reads next, and K1 of a line pair (t, mirror)
+// needs only the lines j0, j1 of that pair -- so a wave finishes the stage for its two lines (forward transform along y of
+// W2, chop, linear term + forcing, stage update; `out` / `acc` to HBM as K3w does), keeps the two new spectrum lines in
+// LDS and runs the K1w body from there.  Saves the re-read of the stage value (4 MB per trajectory and RHS at n = 512)
+// and one launch per RHS.  mode 1 / 2 / 4 as in K3w (mode 0, the bare RHS, has no successor).  Pair items only (n >= 256).
+template <int E, int Q, int LB>
+__global__ __launch_bounds__(256) void fluid_k31w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W2,
+                                                         const C2<double>* omg_s, const C2<double>* __restrict__ phat,
+                                                         const C2<double>* f0, C2<double>* acc, C2<double>* out, int mode,
+                                                         double ca, double cb, C2<double>* __restrict__ W) {
+  typedef WaveFftD<E, Q, LB> F;
+  typedef C2<double> Z;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, l = lane & (F::LANES - 1), slot = (threadIdx.x >> 6) * F::LPW + (lane >> LB);
+  const int n = d.n, p = d.p;
+  Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)slot * 2 * n;
+  Z* Lm = Lj + n;
+  const int t = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
+  if (t > n / 2) return;
+  const int jp = fl_line_jp(t, n, p, d.nl), jpm = (p - jp) % p;
+  const int s_mirror = fl_line_of(jpm, n, p, d.nl);
+  const int j0 = fl_unpad(jp, n, p), j1 = fl_unpad(jpm, n, p);
+  const Z zero = mk<double>(0, 0);
+  F f;
+  f.init(d.twp, lane);
+  // ---- K3 for the kept lines j0 and (if it is another line) j1
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const int j = h ? j1 : j0;
+    Z* Ln = h ? Lm : Lj;
+    if (h && (j1 < 0 || j1 == j0)) {
+      if (j1 < 0)                                   // the mirror of the Nyquist line lies in the padding: zero spectrum
+        for (int i = l; i < n; i += F::LANES) Ln[i] = zero;
+      break;
+    }
+    Z a[F::R];
+    const Z* w2 = W2 + ((size_t)b * n + j) * p;
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) a[jj] = w2[l + F::LANES * jj];
+    f.forward(a);
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) {
+      const int i = fl_unpad(f.mode_index(jj), n, p);          // chop() along y
+      if (i >= 0) Ln[i] = a[jj];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double kj = d.k[j];
+    for (int i = l; i < n; i += F::LANES) {
+      const size_t off = ((size_t)b * n + j) * n + i;
+      const double ki = d.k[i], lin = -d.nu * (kj * kj + ki * ki);
+      const Z o = omg_s[off], nlv = Ln[i], ph = phat[off];
+      const Z k = mk<double>(lin * o.x + d.scale_out * nlv.x + ph.x, lin * o.y + d.scale_out * nlv.y + ph.y);
+      Z nv;
+      if (mode == 4) {
+        const Z ac = acc[off];
+        nv = mk<double>(ac.x + cb * k.x, ac.y + cb * k.y);
+      } else {
+        const Z fv = f0[off];
+        nv = mk<double>(fv.x + ca * k.x, fv.y + ca * k.y);
+        if (mode == 1) acc[off] = mk<double>(fv.x + cb * k.x, fv.y + cb * k.y);
+        else {
+          const Z ac = acc[off];
+          acc[off] = mk<double>(ac.x + cb * k.x, ac.y + cb * k.y);
+        }
+      }
+      out[off] = nv;
+      Ln[i] = nv;                                   // the spectrum line of the next right-hand side
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- K1 of the next right-hand side from the two lines
+  const Z* Lmm = (j1 == j0) ? Lj : Lm;              // line 0 is its own mirror
+  const int nhalf = (s_mirror >= 0 && s_mirror != t) ? 2 : 1;
+  fluid_k1w_body<E, Q, LB>(d, Lj, Lmm, j0, j1, t, s_mirror, nhalf, W, b, f, l);
 }
 
 // ------------------------------------------------------------------ wave FFT unit-test entry (pdec_debug_wave_fft)
@@ -859,7 +949,69 @@ static int fluid_rhs_launch(FluidEnv& E, const void* omg_s, const void* phat, co
 }
 
 // do_step (FluidSetup.jl:163-172): K sub-steps of rk4 (src/fluid_rk4.jl:122-132), in place on f
+// RK4 sub-steps with K3 of every stage fused with K1 of the next right-hand side (fluid_k31w_kernel): K1 once, then
+// K2 + K31 per stage, a plain K3 at the very end.  Wave-transform path with line pairs (n >= 256).
+template <int E, int Q, int LB>
+static int fluid_integrate_wave(FluidEnv& Ev, const FluidDev<double>& d, void* f, const void* phat) {
+  typedef C2<double> Z;
+  const int B = Ev.cfg.B, n = Ev.n, p = Ev.p;
+  constexpr int LPW = 64 >> LB, LPB = 4 * LPW;
+  static bool attr = false;
+  if (!attr) {
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k1w_kernel<E, Q, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k2w_kernel<E, Q, FL_K2_TC, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k3w_kernel<E, Q, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k31w_kernel<E, Q, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  const double h = Ev.cfg.dt / Ev.cfg.K;
+  Z *fs = Ev.fs.as<Z>(), *acc = Ev.acc.as<Z>(), *fz = (Z*)f;
+  const dim3 gpair((n / 2 + 1 + LPB - 1) / LPB, B);
+  const size_t lds2 = (size_t)LPB * 2 * n * 16;
+  auto k2 = [&]() {
+    ProfScope ps(&Ev, "fluid_k2");
+    hipLaunchKernelGGL((fluid_k2w_kernel<E, Q, FL_K2_TC, LB>), dim3((p + FL_K2_TC - 1) / FL_K2_TC, B), dim3(64 * FL_K2_TC / LPW),
+                       (size_t)FL_K2_TC * (p + 1) * 16, Ev.stream, d, Ev.W.as<Z>(), Ev.W2.as<Z>());
+  };
+  auto k31 = [&](const Z* omg_s, Z* out, int mode, double ca, double cb) {
+    ProfScope ps(&Ev, "fluid_k31");
+    hipLaunchKernelGGL((fluid_k31w_kernel<E, Q, LB>), gpair, dim3(256), lds2, Ev.stream, d, Ev.W2.as<Z>(), omg_s, (const Z*)phat,
+                       (const Z*)fz, acc, out, mode, ca, cb, Ev.W.as<Z>());
+  };
+  {
+    ProfScope ps(&Ev, "fluid_k1");
+    hipLaunchKernelGGL((fluid_k1w_kernel<E, Q, LB>), gpair, dim3(256), lds2, Ev.stream, d, (const Z*)fz, Ev.W.as<Z>(), 1);
+  }
+  for (int it = 0; it < Ev.cfg.K; ++it) {
+    k2(); k31(fz, fs, 1, 0.5 * h, h / 6.0);
+    k2(); k31(fs, fs, 2, 0.5 * h, h / 3.0);
+    k2(); k31(fs, fs, 2, h, h / 3.0);
+    k2();
+    if (it + 1 < Ev.cfg.K) {
+      k31(fs, fz, 4, 0.0, h / 6.0);
+    } else {
+      ProfScope ps(&Ev, "fluid_k3");
+      hipLaunchKernelGGL((fluid_k3w_kernel<E, Q, LB>), dim3((n + LPB - 1) / LPB, B), dim3(256), (size_t)LPB * n * 16, Ev.stream, d,
+                         Ev.W2.as<Z>(), (const Z*)fs, (const Z*)phat, (const Z*)fz, acc, fz, 4, 0.0, h / 6.0);
+    }
+  }
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
 static int fluid_integrate(FluidEnv& E, void* f, const void* phat) {
+  // measured (B = 16): n = 256: 650 -> 701 env-steps/s fused; n = 512: 76.6 -> 74.5 (the fused waves run six transforms
+  // each and the stage's streaming phase no longer overlaps other waves' transforms) -> fused below 512 only
+  static const char* fuse_env = getenv("PDEC_FLUID_FUSE");     // 1 / 0 force it on / off
+  const bool fuse = fuse_env ? fuse_env[0] == '1' : (E.n >= 256 && E.n < 512);
+  if (fuse && E.n >= 256) {
+    const FluidDev<double> d = fluid_dev(E);
+    if (E.wave_E == 4 && E.wave_Q == 3) return fluid_integrate_wave<4, 3, 6>(E, d, f, phat);
+    if (E.wave_E == 4 && E.wave_Q == 2) return fluid_integrate_wave<4, 2, 6>(E, d, f, phat);
+    if (E.wave_E == 4 && E.wave_Q == 1) return fluid_integrate_wave<4, 1, 6>(E, d, f, phat);
+    if (E.wave_E == 2 && E.wave_Q == 3 && E.wave_LB == 6) return fluid_integrate_wave<2, 3, 6>(E, d, f, phat);
+    if (E.wave_E == 2 && E.wave_Q == 1 && E.wave_LB == 6) return fluid_integrate_wave<2, 1, 6>(E, d, f, phat);
+  }
   const double h = E.cfg.dt / E.cfg.K;
   void *fs = E.fs.p, *acc = E.acc.p;
   int rc;
