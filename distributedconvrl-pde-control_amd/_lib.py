@@ -128,6 +128,13 @@ class _Lib:
     def record_into(self, calls):
         self._rec = calls
 
+    def note(self, fn, *args):
+        """run a NON-library call (e.g. a torch.distributed all-reduce between two library launches) and, while a
+        recording is active, keep it in the list at its place: the replay re-issues it with the same arguments"""
+        if self._rec is not None:
+            self._rec.append((fn, args))
+        return fn(*args)
+
 
 def load():
     """Load libpdeconv.so (once).  Raises PdecError if it has not been built."""

@@ -56,6 +56,21 @@ def _adam_state(model):
     return m, v, np.array([bp[0], bp[1]])
 
 
+def _json_default(o):
+    """bit-generator states hold numpy scalars and, for MT19937-like generators, arrays"""
+    if isinstance(o, np.ndarray):
+        return {"__ndarray__": o.tolist(), "dtype": str(o.dtype)}
+    if isinstance(o, np.generic):
+        return o.item()
+    return int(o)
+
+
+def _json_hook(d):
+    if "__ndarray__" in d:
+        return np.asarray(d["__ndarray__"], dtype=d["dtype"])
+    return d
+
+
 def save_agent(path, agent, with_trajectory=True):
     """what `FileIO.save(".../agent.jld2", "agent", agent)` keeps (scripts/KS/setup/KSSetup.jl:391-402): the four networks,
     their ADAM states, the replay trajectory, plus the positions of the build's counter-based random streams -- a resumed
@@ -74,8 +89,16 @@ def save_agent(path, agent, with_trajectory=True):
     # exploration-noise and minibatch-sampling streams (counter-based: seed + offset is the whole state), the host rng
     kw["noise_seed_off"] = np.array([p._noise_seed, p._noise_off], dtype=np.uint64)
     kw["sample_seed_off"] = np.array([p._sample_seed, p._sample_off], dtype=np.uint64)
+    # ... and the device-resident counter TrainPipeline's acting kernel advances (pdec_policy_act_rng_dev)
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()        # the acting kernel that advances it runs on the environment's stream
+    ctr = C.c_uint64()
+    _lib.check(p.lib.pdec_noise_counter_get(p.behavior_actor.model.handle, C.byref(ctr)))
+    kw["noise_counter_dev"] = np.array([ctr.value], dtype=np.uint64)
     import json
-    kw["rng_state"] = np.array(json.dumps(p.rng.bit_generator.state, default=int))
+    kw["rng_state"] = np.array(json.dumps(p.rng.bit_generator.state, default=_json_default))
     if with_trajectory:                 # the replay traces, as FileIO.save of the whole Agent keeps them
         tr = agent.trajectory
         n_sa, n_rt = min(tr.n_sa, tr.capacity + tr.stride), min(tr.n_rt, tr.capacity)
@@ -107,8 +130,10 @@ def load_agent(path, agent):
     if "noise_seed_off" in z.files:
         p._noise_seed, p._noise_off = (int(x) for x in z["noise_seed_off"])
         p._sample_seed, p._sample_off = (int(x) for x in z["sample_seed_off"])
+        if "noise_counter_dev" in z.files:
+            _lib.check(p.lib.pdec_noise_counter_set(p.behavior_actor.model.handle, int(z["noise_counter_dev"][0])))
         import json
-        st = json.loads(str(z["rng_state"]))
+        st = json.loads(str(z["rng_state"]), object_hook=_json_hook)
         try:
             p.rng.bit_generator.state = st
         except (ValueError, TypeError):

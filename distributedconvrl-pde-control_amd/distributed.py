@@ -42,16 +42,68 @@ class GradReducer:
             self._views[key] = torch.as_tensor(_DevArray(ptr, n, ts), device=model.device)
         return self._views[key]
 
+    native = False        # torch.distributed issues the collective (host path of the process group)
+
     def all_reduce(self, model):
         if self.world_size == 1:
             return
-        g = self._view(model)
-        stream = model.stream
+        # through _Lib.note: a recorded control step (pipeline._eager) keeps the collective at its place between the
+        # gradient launch and the ADAM launch and re-issues it on replay
+        model.lib.note(self._reduce, self._view(model), model.stream)
+
+    def _reduce(self, g, stream):
         if stream is not None:
             with torch.cuda.stream(stream):
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        return 0
+
+
+class NativeGradReducer:
+    """The same exchange through the library's own RCCL communicator (csrc/comm.hip: pdec_comm_create,
+    pdec_allreduce_grads): ONE C call per all-reduce, enqueued on the network's (update) stream between the launch that
+    leaves the flat gradient and the ADAM launch -- no torch.distributed host path (tensor wrappers, work objects, stream
+    guards) on the critical stream, and, being a library call, recorded and replayed with the rest of a control step.
+    The 128-byte ncclUniqueId travels once, at construction: over torch.distributed's object broadcast when a process
+    group exists (any backend), or through `exchange` (a callable rank-0-bytes -> bytes, e.g. over a pipe)."""
+
+    native = True
+
+    def __init__(self, lib, rank=None, world_size=None, reduce_critic=True, exchange=None):
+        import ctypes as C
+        from . import _lib
+        self.lib = lib
+        self.reduce_critic = bool(reduce_critic)
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank, self.world_size = int(rank), int(world_size)
+        buf = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(lib.pdec_comm_unique_id(C.cast(buf, C.c_void_p)))
+        if self.world_size > 1:
+            if exchange is not None:
+                raw = exchange(bytes(buf.raw) if self.rank == 0 else None)
+            else:
+                box = [bytes(buf.raw) if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            C.memmove(buf, raw, 128)
+        self.comm = _lib.Handle()
+        _lib.check(lib.pdec_comm_create(C.byref(self.comm), self.world_size, self.rank, C.cast(buf, C.c_void_p)))
+
+    def all_reduce(self, model):
+        if self.world_size == 1:
+            return
+        from . import _lib
+        _lib.check(self.lib.pdec_allreduce_grads(self.comm, model.handle))
+
+    def close(self):
+        if self.comm is not None:
+            self.lib.pdec_destroy(self.comm)
+            self.comm = None
 
 
 def all_reduce_host_grads(grads, group=None):

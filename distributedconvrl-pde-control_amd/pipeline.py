@@ -86,7 +86,10 @@ class TrainPipeline:
         self.use_replay = bool(use_replay)
         reducer = self.policy.reducer
         self.multi_rank = reducer is not None and reducer.world_size > 1
-        self.use_graphs = bool(use_graphs) and not self.use_replay and not self.multi_rank
+        # a recorded step / a graph holds POINTERS: policy.update must hand the ring tensors through unchanged, which it
+        # does only when no dtype conversion makes a temporary (`.to(dt).contiguous()` is the identity then)
+        self._batch_aliases = env.dtype == self.policy.behavior_critic.model.dtype
+        self.use_graphs = bool(use_graphs) and not self.use_replay and not self.multi_rank and self._batch_aliases
         self.chunks = tuple(sorted({int(c) for c in chunks if c == 1 or c % PERIOD == 0} | {1}, reverse=True))
         setup, B = env.setup, env.B
         ns, A = setup.state_shape
@@ -131,6 +134,9 @@ class TrainPipeline:
         self.ev_upd = [Ev(self.lib), Ev(self.lib)]                  # update_k issued (update stream)
         self.ev_graph = Ev(self.lib)                                # tail of the last graph launch (env stream)
         self.ev_mid = Ev(self.lib)                                  # critic half of update_k done (update stream)
+        self.ev_push = [Ev(self.lib), Ev(self.lib)]                 # replay pushes of step k done (env stream)
+        self.ev_samp = Ev(self.lib)                                 # replay sample of update_k done (update stream)
+        self._samp_pending = False
         self._after_graph = False
         self.tick = 0             # control steps issued so far: every buffer of step k is indexed by k mod 2 / 3 / 6
         self.ep_start = 0         # tick of the first step of the current episode
@@ -148,7 +154,8 @@ class TrainPipeline:
         if os.environ.get("PDEC_KICK") in ("0", "1"):               # diagnostic override
             self.kick_env_after_critic = os.environ["PDEC_KICK"] == "1"
         # events attached to the reduction launches instead of recorded behind them (see _issue); PDEC_STOP_EVENTS=0: records
-        self.stop_events = (self.rpart is not None and Ev is _Event and not self.serial and not self.multi_rank
+        # (N > 1: the launch that applies the update after the all-reduce carries the event, pdec_adam_polyak_step)
+        self.stop_events = (self.rpart is not None and Ev is _Event and not self.serial
                             and os.environ.get("PDEC_STOP_EVENTS", "1") != "0")
         # two streams + the fused 3-layer passes: ask for the PDE step's 64-VGPR form, whose waves can share a SIMD with the
         # 222-VGPR critic pass instead of excluding it per CU (csrc/env.hip, SHARE); PDEC_SHARE=0: the register form
@@ -160,7 +167,13 @@ class TrainPipeline:
         self._sp_env, self._sp_upd = C.c_void_p(self.s_env.cuda_stream), C.c_void_p(self.s_upd.cuda_stream)
         self.graphs = {}          # (chunk, pos) -> graph handle
         self._progs = {}          # ring phase -> recorded library calls of an interior eager step
-        self.fast_eager = os.environ.get("PDEC_FAST_EAGER", "1") == "1" and not self.multi_rank
+        # the recorded-call replay re-issues LIBRARY calls only: with torch events (PDEC_TORCH_EVENTS=1) the cross-stream
+        # records / waits are torch calls it would not see, so it is off for that event type
+        # N > 1: the gradient all-reduce is one more recorded call (a library call with NativeGradReducer, a noted torch call
+        # with GradReducer -- _Lib.note), so the multi-rank pipeline issues its steps the same fast way
+        self.fast_eager = os.environ.get("PDEC_FAST_EAGER", "1") == "1" and Ev is _Event and self._batch_aliases
+        self._key = None          # per-step scalars baked into _progs / the graphs (see _scalar_key)
+        self._recapture = False
         self._captured = False
         self.n_graph_launches = self.n_eager_steps = 0
         self.reset_from(env.y0)
@@ -174,6 +187,12 @@ class TrainPipeline:
                 env.y0.copy_(y0)
             _lib.check(self.lib.pdec_featurize(env.handle, _lib.ptr(env.y0), None, _lib.ptr(self.state0)))
         self.ep_start = self.tick
+        if self.tick > 0:
+            # a restart in the middle of an episode: the transitions of the steps before it must not be trained on -- the
+            # first step of the new episode overwrites sring[tick % 6], which is the next_state of transition tick - 1 and
+            # would be bootstrapped across the reset with terminal = 0 -- and the recorded interior steps are dropped
+            self._first_tick = self.tick
+            self._progs = {}
 
     @property
     def y(self):
@@ -247,8 +266,16 @@ class TrainPipeline:
         batch = None
         if j >= self._first_tick:
             if self.use_replay:
+                if not self.serial and k > 0:
+                    # the host counters the sample is drawn against already include env_{k-1}'s pushes: wait for them
+                    # (the update stream has otherwise only waited for act_{k-1}, which precedes them on the env stream)
+                    self.ev_push[(k - 1) % 2].wait(self.s_upd)
                 with torch.cuda.stream(self.s_upd):
                     batch = self._replay_batch()
+                if batch is not None and not self.serial:
+                    # ... and env_k's pushes overwrite the oldest rows of a full ring: they wait for this sample
+                    self.ev_samp.record(self.s_upd)
+                    self._samp_pending = True
             else:
                 batch = dict(state=self.sring[j % PERIOD].view(self.cols, self.ns), action=self.aring[j % 3].view(self.cols, self.na),
                              reward=self.rring[j % 3].view(self.cols), terminal=self.tring[j % 3].view(self.cols),
@@ -309,18 +336,37 @@ class TrainPipeline:
 
     # ------------------------------------------------------------------ device replay route (row F1)
     def _replay_push(self, k, s_in, act, rew, term, s_out, first, last):
-        tr = self.agent.trajectory
+        """the stage pushes of step k (src/PDEagent.jl:237-314).  They run on the ENV stream (launched through the env's
+        handle), behind the env step / the time-out fill that produce their inputs; `ev_push[k % 2]` marks them done and
+        the update that samples the replay next waits for it (see _issue).  (launched through the critic's
+        handle they ran on the update stream, unordered against env_k, and copied stale rewards / flags.)"""
+        tr, lib, h = self.agent.trajectory, self.lib, self.env.handle
+        cap1 = tr.capacity + tr.stride
+        ns, na = tr.state.shape[1], tr.action.shape[1]
+        dtc = _lib.dtype_code(s_in.dtype)
+
+        def push_sa(s, a):
+            _lib.check(lib.pdec_replay_push_sa(h, _lib.ptr(tr.state), _lib.ptr(tr.action), cap1, ns, na, tr.n_sa % cap1,
+                                               _lib.ptr(s.view(self.cols, self.ns)),
+                                               None if a is None else _lib.ptr(a.view(self.cols, self.na)), self.cols, dtc))
+            tr.n_sa += self.cols
+
+        if self._samp_pending:
+            self.ev_samp.wait(self.s_env)
+            self._samp_pending = False
         if first and len(tr) > 0 and tr.n_sa > tr.n_rt:
             tr.pop_sa(tr.stride)                                    # PRE_EPISODE: the dummy (s, a) of the last episode
-        tr.push_sa(s_in.view(self.cols, self.ns), act.view(self.cols, self.na))          # PRE_ACT
+        push_sa(s_in, act)                                          # PRE_ACT
         # POST_ACT: reward and the per-column terminal flags the env step (and the time-out) produced -- two
         # one-column traces of equal capacity, pushed by the same two-trace kernel as (s, a)
-        _lib.check(self.lib.pdec_replay_push_sa(tr._h, _lib.ptr(tr.reward), _lib.ptr(tr.terminal), tr.capacity, 1, 1,
-                                                tr.n_rt % tr.capacity, _lib.ptr(rew.view(self.cols)),
-                                                _lib.ptr(term.view(self.cols)), self.cols, _lib.dtype_code(rew.dtype)))
+        _lib.check(lib.pdec_replay_push_sa(h, _lib.ptr(tr.reward), _lib.ptr(tr.terminal), tr.capacity, 1, 1,
+                                           tr.n_rt % tr.capacity, _lib.ptr(rew.view(self.cols)),
+                                           _lib.ptr(term.view(self.cols)), self.cols, _lib.dtype_code(rew.dtype)))
         tr.n_rt += self.cols
         if last:
-            tr.push_sa(s_out.view(self.cols, self.ns), None)        # POST_EPISODE dummy
+            push_sa(s_out, None)                                    # POST_EPISODE dummy
+        if not self.serial:
+            self.ev_push[k % 2].record(self.s_env)
 
     def _replay_batch(self):
         tr, pol = self.agent.trajectory, self.policy
@@ -334,6 +380,7 @@ class TrainPipeline:
     def capture(self):
         """record the chunk graphs (needs >= 3 warm-up steps behind it so that every lazily created buffer exists and
         the update has transitions to train on); advances the run by len(chunks) periods of eager-equivalent steps"""
+        self._check_key()
         if not self.use_graphs or self._captured:
             return
         if self.E > 0:
@@ -341,8 +388,13 @@ class TrainPipeline:
             self.chunks = tuple(c for c in self.chunks if c <= self.E - 2)
         while self.tick - self.LAG < self._first_tick + 2:      # lazily created buffers / first-use uploads happen eagerly
             self._eager()
+        self._key = self._scalar_key()
         for c in self.chunks:
             for pos in range(PERIOD):
+                if not self._reachable(c, pos):
+                    # e.g. chunk 24 with 26-step episodes: the interior offsets 1 .. E-1-c never meet this ring phase
+                    # (the search below would issue eager steps for ever); run() falls back to a smaller chunk
+                    continue
                 while not (self.tick % PERIOD == pos and self._interior(self.tick, c)):
                     self._eager()
                 self._sync_streams_for_graph()
@@ -360,6 +412,34 @@ class TrainPipeline:
                 self._launch(h)
                 self.tick += c
         self._captured = True
+
+    def _reachable(self, c, pos):
+        """is there a future tick at ring phase `pos` from which c consecutive steps are interior to an episode?  The
+        pattern of (tick mod 6, episode offset) repeats after lcm(E, 6) <= 6 E ticks."""
+        if self.E <= 0:
+            return True
+        t0 = max(self.tick, self._first_tick + self.LAG)
+        return any(t % PERIOD == pos and self._interior(t, c) for t in range(t0, t0 + PERIOD * self.E + PERIOD))
+
+    def _scalar_key(self):
+        """the per-step scalars that a recorded step / a captured graph holds as frozen launch arguments"""
+        pol = self.policy
+        return (float(pol.act_noise), float(pol.act_limit), float(pol.behavior_actor.optimizer.eta),
+                float(pol.behavior_critic.optimizer.eta), float(pol.y), float(pol.p), int(bool(pol.quirk)),
+                bool(self.kick_env_after_critic), int(self.noise_seed))
+
+    def _check_key(self):
+        """a noise / learning-rate schedule (or load_agent restoring act_noise) changed a frozen scalar: drop the recorded
+        steps and the graphs -- the run continues eagerly with the new values until capture() is called again"""
+        key = self._scalar_key()
+        if key != self._key:
+            self._progs = {}
+            if self.graphs:
+                for h in self.graphs.values():
+                    self.lib.pdec_destroy(h)
+                self.graphs = {}
+            self._captured = False
+            self._key = key
 
     def _interior(self, k, n):
         """steps k .. k+n-1 are neither the first nor the last of an episode (those run eagerly)"""
@@ -412,12 +492,13 @@ class TrainPipeline:
     def run(self, n):
         """issue n control steps (asynchronous: returns when they are enqueued)"""
         n = int(n)
+        self._check_key()
         while n > 0:
             k = self.tick
             done = False
             if self._captured:
                 for c in self.chunks:
-                    if c <= n and self._interior(k, c):
+                    if c <= n and (c, k % PERIOD) in self.graphs and self._interior(k, c):
                         self._sync_streams_for_graph()
                         self._launch(self.graphs[(c, k % PERIOD)])
                         self.tick += c

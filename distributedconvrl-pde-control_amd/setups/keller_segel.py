@@ -20,7 +20,7 @@ class KellerSegelSetup:
                  nna_scale=2.0, nna_scale_critic=17.0, drop_middle_layer=True, gamma=0.99, rho=0.995,
                  batch_size=3, start_steps=-1, update_after=1, update_freq=1, update_loops=20,
                  learning_rate=0.0005, learning_rate_critic=0.001, act_limit=1.0, act_noise=1.2,
-                 trajectory_length=100_000, integrator="rk4"):
+                 trajectory_length=100_000, integrator="rk4", memory_size=0):
         self.integrator = integrator          # "rk4" (do_step, :234-239) or "midpoint" (PDEenv's built-in, src/PDEenv.jl:208-214)
         self.nx, self.Lx = int(nx), float(Lx)
         self.dx = self.Lx / self.nx
@@ -36,7 +36,9 @@ class KellerSegelSetup:
         self.max_value, self.check_max_value, self.agent_power = max_value, check_max_value, agent_power
         self.action_punish, self.delta_action_punish = action_punish, delta_action_punish
         self.window_size, self.temporal_steps, self.memory_size, self.mono, self.n_species = \
-            window_size, temporal_steps, 0, False, 2
+            window_size, int(temporal_steps), int(memory_size), False, 2
+        from .ks import _refuse_unbuilt_branches
+        _refuse_unbuilt_branches(self, "scripts/Keller-Segel/setup/KellerSegelSetup.jl:295-314")
         self.nna_scale, self.nna_scale_critic, self.drop_middle_layer = nna_scale, nna_scale_critic, drop_middle_layer
         self.gamma, self.rho, self.batch_size = gamma, rho, batch_size
         self.start_steps, self.update_after, self.update_freq, self.update_loops = \

@@ -26,6 +26,16 @@ def prepare_gaussians(nx, Lx, positions, sigma, norm_mode):
     return out
 
 
+def _refuse_unbuilt_branches(setup, where):
+    """memory_size > 0 (action memory: src/PDEagent.jl:201 + the featurize branch cited in `where`) and a temporal stack for
+    the mono / global agent are optional branches no shipped script sets; a caller who sets them gets an error, not silence"""
+    if setup.memory_size != 0:
+        raise _lib.PdecError(f"memory_size = {setup.memory_size}: the action-memory branch of featurize / the acting path "
+                             f"({where}, src/PDEagent.jl:201) is not built; only memory_size = 0 is supported")
+    if setup.temporal_steps < 1 or (getattr(setup, "mono", False) and setup.temporal_steps != 1):
+        raise _lib.PdecError(f"temporal_steps = {setup.temporal_steps} is not supported for this setup ({where})")
+
+
 class KSSetup:
     def __init__(self, nx, Lx, sensor_positions, actuator_positions=None, actuators_to_sensors=None,
                  sigma_sensors=1.0, sigma_actuators=1.0, mu=0.0, te=5.0, t0=0.0, dt=0.1, oversampling=30,
@@ -34,7 +44,7 @@ class KSSetup:
                  nna_scale=0.6, nna_scale_critic=7.0, drop_middle_layer=True,
                  gamma=0.99, rho=0.995, batch_size=3, start_steps=6, update_after=10, update_freq=1,
                  update_loops=20, learning_rate=0.0005, learning_rate_critic=0.001, act_limit=1.0,
-                 act_noise=1.2, trajectory_length=150_000, integrator="cnab2"):
+                 act_noise=1.2, trajectory_length=150_000, integrator="cnab2", temporal_steps=1, memory_size=0):
         self.nx, self.Lx = int(nx), float(Lx)
         self.dx = self.Lx / self.nx
         # "cnab2": the reference's spectral CNAB2 step (KSSetup.jl:130-160); "rk4_fd": RK4 + periodic 5-point FD variant
@@ -57,7 +67,11 @@ class KSSetup:
             start_steps, update_after, update_freq, update_loops
         self.learning_rate, self.learning_rate_critic = learning_rate, learning_rate_critic
         self.act_limit, self.act_noise, self.trajectory_length = act_limit, act_noise, trajectory_length
-        self.temporal_steps, self.memory_size, self.n_species = 1, 0, 1
+        # featurize's optional branches (KSSetup.jl:209-226): temporal stacking runs in the step kernels' general
+        # featurize path; the action-memory rows (memory_size > 0: extra actor outputs fed back as state rows,
+        # src/PDEagent.jl:201) are not built -- refused here rather than silently ignored
+        self.temporal_steps, self.memory_size, self.n_species = int(temporal_steps), int(memory_size), 1
+        _refuse_unbuilt_branches(self, "scripts/KS/setup/KSSetup.jl:209-226")
         self.gaussians = prepare_gaussians(self.nx, self.Lx, self.sensor_positions, sigma_sensors, 1)
         if mono:   # KSglobalSetup.jl:99-102,125
             self.gaussians_actuators = prepare_gaussians(self.nx, self.Lx, self.actuator_positions, sigma_actuators, 2)
@@ -112,7 +126,7 @@ class KSSetup:
         kind = _lib.PDE_KS_RK4_FD if self.integrator in ("rk4_fd", "midpoint_fd") else _lib.PDE_KS_CNAB2
         c.integrator = 1 if self.integrator == "midpoint_fd" else 0
         c.pde_kind, c.dtype, c.B, c.N, c.n_species = kind, dtype_code, B, self.nx, 1
-        c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, 1, int(self.mono)
+        c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, self.temporal_steps, int(self.mono)
         c.K = self.oversampling
         c.check_max_value = {"y": 1, "reward": 2}.get(self.check_max_value, 0)
         c.Lx, c.dt, c.mu, c.max_value = self.Lx, self.dt, (0.0 if self.mono else self.mu), self.max_value

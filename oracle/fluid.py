@@ -162,8 +162,10 @@ def reward_function(cfg, yhat, action, delta_action):
     return -np.abs(sensors) - cfg.action_punish * a ** 2 - cfg.delta_action_punish * da ** 2
 
 
-def featurize(cfg, yhat):
-    """scripts/Fluid/setup/FluidSetup.jl:204-245 (temporal_steps=1, memory_size=0)."""
+def featurize(cfg, yhat, prev_state=None):
+    """scripts/Fluid/setup/FluidSetup.jl:204-245 (memory_size=0).  temporal_steps > 1 (:229-237; 1 in the shipped scripts):
+    prev_state=None is the `isnothing(env)` branch (fresh rows repeated), otherwise the fresh rows are stacked on the newest
+    rows of the previous state."""
     y = np.real(np.fft.ifft2(yhat))
     spa = cfg.sensors_per_axis
     dots = np.tensordot(cfg.gaussians, y, axes=([1, 2], [0, 1])) / 70         # :216
@@ -175,7 +177,15 @@ def featurize(cfg, yhat):
             sh = np.roll(np.roll(sensors, i, axis=0), j, axis=1)              # circshift(sensors,[i,j])
             # reshape(sh', (1, S)) in column-major Julia == row-major flatten of sh
             rows.append(sh.reshape(-1))                                       # :220-222
-    return np.stack(rows)
+    result = np.stack(rows)
+    T = getattr(cfg, "temporal_steps", 1)
+    if T > 1:                                                                 # :229
+        if prev_state is None:
+            result = np.concatenate([result] * T)                             # :231-234
+        else:
+            prev = np.asarray(prev_state, dtype=np.float64)
+            result = np.concatenate([result, prev[:prev.shape[0] - result.shape[0], :]])   # :236
+    return result
 
 
 def prepare_action(cfg, action):

@@ -12,7 +12,7 @@ class KSConfig:
     def __init__(self, nx, Lx, sensor_positions, actuator_positions=None, actuators_to_sensors=None,
                  sigma_sensors=1.0, sigma_actuators=1.0, mu=0.0, dt=0.1, oversampling=30,
                  max_value=30.0, agent_power=7.5, action_punish=0.002, delta_action_punish=0.002,
-                 window_size=1, te=5.0, mono=False, disturbance_in_step=True):
+                 window_size=1, te=5.0, mono=False, disturbance_in_step=True, temporal_steps=1):
         self.nx, self.Lx = int(nx), float(Lx)
         self.dx = self.Lx / self.nx                                   # KSSetup.jl:34
         self.sensor_positions = np.asarray(sensor_positions, dtype=np.int64)      # 1-based cells
@@ -26,6 +26,7 @@ class KSConfig:
         self.max_value, self.agent_power = max_value, agent_power
         self.action_punish, self.delta_action_punish = action_punish, delta_action_punish
         self.window_size, self.te, self.mono = window_size, te, mono
+        self.temporal_steps = int(temporal_steps)                     # KSSetup.jl:30 (1 in every shipped script)
         self.disturbance_in_step = disturbance_in_step                # absent in KSglobalSetup.jl:167
         self.xx = self.dx * np.arange(1, self.nx + 1)                 # collect(dx:dx:Lx), KSSetup.jl:36
         self.gaussians = prepare_gaussians(self, sigma_sensors, 1, self.sensor_positions)
@@ -160,16 +161,26 @@ def reward_function(cfg, y, action, delta_action):
     return r
 
 
-def featurize(cfg, y):
-    """scripts/KS/setup/KSSetup.jl:190-229 with temporal_steps=1, memory_size=0 (all shipped
-    KS experiments); mono variant KSglobalSetup.jl:211-249 returns the [S,1] column."""
+def featurize(cfg, y, prev_state=None):
+    """scripts/KS/setup/KSSetup.jl:190-229 with memory_size=0; mono variant KSglobalSetup.jl:211-249 returns the
+    [S,1] column.  temporal_steps > 1 (:209-218; 1 in every shipped KS script): prev_state=None is the reference's
+    `isnothing(env)` branch (the fresh rows repeated), otherwise the fresh rows stacked on the newest rows of the
+    previous state (`env.state[1:end-size(result)[1], :]`)."""
     sensors = sensor_dots(cfg, y) / cfg.max_value                             # :201
     if cfg.mono:
         return sensors.reshape(-1, 1)                                         # KSglobalSetup.jl:225-227
     w = int(np.floor(cfg.window_size / 2))                                    # :204
     rows = [circshift(sensors, i) for i in range(-w, w + 1)]                  # :205
     result = np.stack(rows)
-    return result[:, cfg.actuators_to_sensors - 1]                            # :207
+    result = result[:, cfg.actuators_to_sensors - 1]                          # :207
+    T = getattr(cfg, "temporal_steps", 1)
+    if T > 1:                                                                 # :209
+        if prev_state is None:
+            result = np.concatenate([result] * T)                             # :211-214
+        else:
+            prev = np.asarray(prev_state, dtype=np.float64)
+            result = np.concatenate([result, prev[:prev.shape[0] - result.shape[0], :]])   # :216
+    return result
 
 
 def prepare_action(cfg, action):
@@ -194,14 +205,15 @@ def generate_random_init(cfg, rng):
     return y0 * 30 / np.linalg.norm(y0)
 
 
-def env_step(cfg, y, action_prev, action, time):
-    """(env::PDEenv)(action), src/PDEenv.jl:195-241, with the KS closures."""
+def env_step(cfg, y, action_prev, action, time, prev_state=None):
+    """(env::PDEenv)(action), src/PDEenv.jl:195-241, with the KS closures (prev_state: env.state before the step, read
+    by featurize when temporal_steps > 1)."""
     action = np.asarray(action, dtype=np.float64)
     delta_action = action - np.asarray(action_prev, dtype=np.float64)         # :196
     p = prepare_action(cfg, action)                                           # :199
     y_new = do_step(cfg, y, p)                                                # :217
     reward = reward_function(cfg, y_new, action, delta_action)                # :220
-    state = featurize(cfg, y_new)                                             # :222
+    state = featurize(cfg, y_new, prev_state)                                 # :222
     time = time + cfg.dt                                                      # :225
     done = bool(time >= cfg.te or np.max(np.abs(y_new)) > cfg.max_value)      # :227
     return dict(y=y_new, p=p, reward=reward, state=state, done=done, time=time,

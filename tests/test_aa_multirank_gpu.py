@@ -38,6 +38,39 @@ def make(reducer, B):
     return pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), device="cuda:0", reducer=reducer,
                             quirk_target_broadcast=False, max_update_cols=cols_g)
 
+flat = lambda nna: torch.as_tensor(np.concatenate([p.ravel() for p in nna.params()]))
+if mode == "native":
+    # the library's own RCCL communicator (NativeGradReducer -> pdec_comm_create / pdec_allreduce_grads), the 128-byte id
+    # travelling over the gloo group.  RCCL refuses a communicator whose ranks share one device ("Duplicate GPU"), so on
+    # a single-GPU box this reports the refusal (the error path of pdec_comm_create); with >= 2 devices it runs the three
+    # updates and compares with the torch.distributed reducer bit for bit.
+    ndev = torch.cuda.device_count()
+    if ndev >= world:
+        torch.cuda.set_device(rank)
+    out = {"rank": rank, "mode": mode, "devices": ndev}
+    try:
+        nred = pkg.distributed.NativeGradReducer(pkg._lib.init(torch.cuda.current_device()), reduce_critic=True)
+        out["created"] = True
+    except pkg.PdecError as e:
+        out["created"], out["error"] = False, str(e)
+    flags = [None] * world
+    dist.all_gather_object(flags, out["created"])
+    if all(flags):
+        dev = f"cuda:{torch.cuda.current_device()}"
+        mk = lambda red: pkg.create_agent(setup=setup, B=hi - lo, rng=np.random.default_rng(1), device=dev, reducer=red,
+                                          quirk_target_broadcast=False, max_update_cols=cols_g)
+        sh = {k: v.to(dev) for k, v in shard.items()}
+        a_nat, a_tor = mk(nred), mk(pkg.distributed.GradReducer(reduce_critic=True))
+        for _ in range(3):
+            a_nat.policy.update(sh); a_tor.policy.update(sh)
+        torch.cuda.synchronize()
+        out["native_equals_torch"] = all(torch.equal(flat(getattr(a_nat.policy, n)), flat(getattr(a_tor.policy, n)))
+                                         for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"))
+    dist.barrier()
+    if rank == 0:
+        print("RESULT " + json.dumps(out))
+    dist.destroy_process_group()
+    sys.exit(0)
 red = pkg.distributed.GradReducer(reduce_critic=(mode == "all"))
 assert red.world_size == world
 agent = make(red, hi - lo)
@@ -45,7 +78,6 @@ for _ in range(3):
     agent.policy.update(shard)
 torch.cuda.synchronize()
 pol = agent.policy
-flat = lambda nna: torch.as_tensor(np.concatenate([p.ravel() for p in nna.params()]))
 mine = {"actor": flat(pol.behavior_actor), "target_actor": flat(pol.target_actor), "critic": flat(pol.behavior_critic)}
 out = {"rank": rank, "mode": mode}
 for k, v in mine.items():
@@ -87,7 +119,12 @@ def _run_ranks(tmp_path, mode, world=2):
                    MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+    try:
+        outs = [p.communicate(timeout=300 if mode == "native" else 600) for p in procs]
+    except subprocess.TimeoutExpired:
+        for p in procs:                      # the exact processes started above, nothing else
+            p.kill()
+        raise
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")]
@@ -112,6 +149,19 @@ def test_two_ranks_all_gradients(tmp_path):
     assert r["critic_vs_unreduced"] > 1e-6, r
 
 
+def test_native_rccl_reducer_with_two_ranks(tmp_path):
+    """the gradient exchange through the library's own RCCL communicator with nranks = 2.  On a box with
+    >= 2 GPUs the two ranks run three data-parallel updates through NativeGradReducer and through the torch.distributed
+    reducer: every network bit-identical.  On the single-GPU boxes of this pool RCCL itself refuses the communicator
+    (two ranks on one device -- `ncclCommInitRank`: invalid usage / duplicate GPU); then the test pins exactly that: the
+    refusal surfaces as a PdecError naming the RCCL call, on every rank, without a hang."""
+    r = _run_ranks(tmp_path, "native")
+    if r["created"]:
+        assert r["devices"] >= 2 and r["native_equals_torch"], r
+    else:
+        assert r["devices"] < 2 and "ncclCommInitRank" in r["error"], r
+
+
 def test_bench_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` (no launcher): the parent starts two fresh ranks before touching the GPU; with
     PDEC_BENCH_BACKEND=gloo they share the single device.  One JSON line, n_gpus = 2, both ranks observed."""
@@ -125,3 +175,19 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_observed"] == 2 and d["collective_backend"] == "gloo"
     assert d["config"]["global_batch"] == 128 and d["checks"]["finite"] and d["value"] > 0
+    # N > 1 issues its interior steps from recorded call lists too (the all-reduce is one more recorded call) and the
+    # completion events ride on the launches that apply the updates, exactly as with one rank
+    assert d["issue"]["recorded_step_replay"] and d["issue"]["stop_events"] and d["collective_issued_by"] == "torch.distributed"
+
+
+def test_bench_c4_two_ranks_on_one_gpu():
+    """`bench.py --config C4 --gpus 2` (reduced grid 64 x 64, B = 8 per rank): the data-parallel RL step of the 2-D
+    Keller-Segel config through the same self-launcher -- env + act + update per step, gradients all-reduced"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PDEC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C4", "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--batch", "8", "--nx", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["n_ranks_observed"] == 2 and d["config"]["global_batch"] == 16
+    assert d["checks"]["finite"] and d["value"] > 0 and d["roofline"]["kernel"] and d["unit"] == "env-steps/s"

@@ -314,3 +314,33 @@ def test_reference_trained_fluid_actor_closed_loop(pkg):
         assert np.abs(env.reward[0].cpu().numpy() - r).max() <= 1e-9 * max(1.0, np.abs(r).max())
         assert np.abs(env.state[0].cpu().numpy().T - state).max() <= 1e-9 * max(1.0, np.abs(state).max())
     assert not bool(env.done.any())
+
+
+def test_temporal_stack_of_the_fluid_featurize(pkg):
+    """featurize with temporal_steps = 2 (scripts/Fluid/setup/FluidSetup.jl:229-237; optional branch): 18 state rows per
+    actuator, reset repeats the 3 x 3 window, a step stacks the fresh window on the previous one -- two steps vs the oracle"""
+    from oracle import fluid
+    n, spa, K = 32, 4, 2
+    setup, cfg0 = _pair(pkg, n, 1, spa=spa, K=K, temporal_steps=2)
+    import copy
+    cfg = copy.copy(cfg0)
+    cfg.temporal_steps = 2
+    assert setup.state_shape == (18, spa * spa)
+    B = 2
+    rng = np.random.default_rng(8)
+    y, _ = _fields(cfg, B, seed=13)
+    env = pkg.PDEenv(setup, B=B, dtype=F64, y0=y)
+    st = [fluid.featurize(cfg, y[b]) for b in range(B)]
+    for b in range(B):
+        assert st[b].shape == (18, spa * spa)
+        assert np.abs(env.state[b].cpu().numpy().T - st[b]).max() <= 1e-12 * max(1.0, np.abs(st[b]).max())
+    for step in range(2):
+        a = rng.uniform(-1, 1, (B, 1, spa * spa))
+        yj = _jul(env.y)
+        env(to_dev(a.reshape(B, -1, 1), F64))
+        for b in range(B):
+            yn = fluid.do_step(cfg, yj[b], fluid.prepare_action(cfg, a[b]), K)
+            ref = fluid.featurize(cfg, yn, st[b])
+            assert np.abs(env.state[b].cpu().numpy().T - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+            assert np.array_equal(ref[9:], st[b][:9])
+            st[b] = ref

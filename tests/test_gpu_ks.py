@@ -269,3 +269,35 @@ def test_config_c3_per_gpu_shard_full_size(pkg):
     s0, s1 = yd.double().sum(1), out.double().sum(1)
     assert float((s1 - s0).abs().max()) <= 2e-3 * float(yd.abs().sum(1).max()) / nx * 30      # fp32 sums of 1024 cells
     assert int(flags.sum()) == 0
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_temporal_stack_of_the_ks_featurize(pkg, prec):
+    """featurize with temporal_steps > 1 (scripts/KS/setup/KSSetup.jl:209-218; optional branch, 1 in the shipped scripts):
+    reset repeats the fresh window rows, every step stacks the fresh rows on the newest rows of the previous state.
+    Three control steps, temporal_steps = 3, window 3, odd B, against the oracle (teacher-forced on y)."""
+    from oracle import ks
+    dt = torch.float64 if prec == "f64" else torch.float32
+    tol = 1e-12 if prec == "f64" else 2e-5
+    setup = pkg.KSSetup.KS22(window_size=3, temporal_steps=3)
+    cfg = ks.KSConfig(192, 22.0, np.arange(1, 193, 24), sigma_sensors=0.7, sigma_actuators=0.7, window_size=3, temporal_steps=3)
+    assert setup.state_shape == (9, 8)
+    rng = np.random.default_rng(5)
+    B = 3
+    y0 = setup.generate_random_init(rng, B) * 0.2
+    env = pkg.PDEenv(setup, B=B, dtype=dt, y0=y0, autoreset=False)
+    st = [ks.featurize(cfg, y0[b]) for b in range(B)]                       # reset: isnothing(env) branch
+    for b in range(B):
+        assert st[b].shape == (9, 8) and np.abs(env.state[b].cpu().numpy().T - st[b]).max() <= tol
+    a_prev = np.zeros((B, 1, 8))
+    for step in range(3):
+        a = rng.uniform(-1, 1, (B, 1, 8))
+        y = env.y.cpu().numpy().astype(np.float64)
+        env(to_dev(a.reshape(B, 8, 1), dt).reshape(env._ashape))
+        for b in range(B):
+            o = ks.env_step(cfg, y[b], a_prev[b], a[b], 0.0, prev_state=st[b])
+            assert np.abs(env.y[b].cpu().numpy() - o["y"]).max() <= tol
+            assert np.abs(env.state[b].cpu().numpy().T - o["state"]).max() <= tol
+            assert np.array_equal(o["state"][3:], st[b][:6])                  # the stack really shifts
+            st[b] = o["state"]
+        a_prev = a

@@ -1,0 +1,215 @@
+"""GPU tests of pipeline.TrainPipeline beyond the eager / graph identity of test_gpu_agent.py: the device-replay route
+(ordering of the stage pushes against the env step, src/PDEagent.jl:237-340), graph capture with episode lengths whose
+ring phases are not all reachable, frozen per-step scalars, mid-episode restarts, the full-size C2 instance of the
+headline."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(pkg, use_graphs=False, B=64, E=17, lag=2, chunks=(6, 1), use_replay=False, replay_steps=8, nx=256):
+    setup = pkg.KSSetup.bench_C2(nx)
+    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+    y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
+    cols = B * setup.n_actuators
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
+                             noise_seed=7, trajectory_length=(replay_steps * cols // B if use_replay else 1))
+    agent.policy.act_noise = 0.3
+    torch.cuda.synchronize()
+    return pkg.TrainPipeline(env, agent, lag=lag, episode_steps=E, stream_env=s_env, stream_upd=s_upd, use_graphs=use_graphs,
+                             chunks=chunks, noise_seed=99, use_replay=use_replay)
+
+
+def _same_networks(pa, pb, names=("behavior_actor", "behavior_critic", "target_actor", "target_critic")):
+    for n in names:
+        for x, y in zip(getattr(pa.policy, n).model.params(), getattr(pb.policy, n).model.params()):
+            assert np.array_equal(x, y), n
+
+
+def test_replay_pushes_are_ordered_behind_the_env_step(pkg):
+    """the stage pushes of step k copy the reward / terminal flags / next state that env_k writes.
+    Pipeline A runs 30 steps (two episode boundaries, a replay of 8 steps that wraps three times) WITHOUT any host
+    synchronisation; pipeline B -- same seeds -- drains the device after every step, which hides any missing
+    stream order.  Both must leave the same four traces, counters and networks, bit for bit; and the newest rows
+    of the reward / terminal / state traces must be the ring contents of the last step."""
+    pa = _make(pkg, use_replay=True)
+    pb = _make(pkg, use_replay=True)
+    n = 30
+    pa.run(n)
+    for _ in range(n):
+        pb.run(1)
+        torch.cuda.synchronize()
+    pa.sync(); pb.sync()
+    ta, tb = pa.agent.trajectory, pb.agent.trajectory
+    assert (ta.n_sa, ta.n_rt) == (tb.n_sa, tb.n_rt) and ta.n_rt == n * pa.cols
+    for name in ("state", "action", "reward", "terminal"):
+        assert torch.equal(getattr(ta, name), getattr(tb, name)), name
+    _same_networks(pa, pb)
+    assert torch.equal(pa.y, pb.y) and bool(torch.isfinite(pa.y).all())
+    # newest rows = what the last env step produced (step n-1 is not the last of an episode: 30 = 17 + 13)
+    k = n - 1
+    lo = (ta.n_rt - pa.cols) % ta.capacity
+    assert torch.equal(ta.reward[lo:lo + pa.cols], pa.rring[k % 3].view(-1))
+    assert torch.equal(ta.terminal[lo:lo + pa.cols], pa.tring[k % 3].view(-1))
+    # ... and the terminal row block of a time-out step is all ones: step 16 (last of episode 0) lies 13 steps back,
+    # outside the 8-step replay, so check step 33 after four more steps
+    pa.run(4); pa.sync()
+    lo = (ta.n_rt - pa.cols) % ta.capacity
+    assert float(ta.terminal[lo:lo + pa.cols].min()) == 1.0          # step 33 = 2 * 17 - 1
+    pa.close(); pb.close()
+
+
+def test_capture_skips_unreachable_ring_phases(pkg):
+    """chunk 24 with 26-step episodes -- the interior offsets 1 .. E-1-c combined with E mod 6 never meet
+    some ring phases, and the capture loop used to issue eager steps for ever looking for them.  Now those (chunk, phase)
+    pairs are skipped, run() falls back to smaller chunks, and the run stays bit-identical to the eager pipeline."""
+    pg = _make(pkg, True, E=26, chunks=(24, 6, 1))
+    pe = _make(pkg, False, E=26)
+    pg.run(5)
+    pg.capture()                                       # returns
+    assert pg._captured and 0 < len([1 for (c, _p) in pg.graphs if c == 24]) < 6
+    assert len([1 for (c, _p) in pg.graphs if c == 6]) == 6
+    pe.run(pg.tick)
+    for n in (3, 26, 31):
+        pg.run(n); pe.run(n)
+    pg.sync(); pe.sync()
+    assert pg.tick == pe.tick and pg.n_graph_launches > 0
+    assert torch.equal(pg.y, pe.y)
+    _same_networks(pg, pe)
+    pg.close()
+
+
+def test_changed_scalars_invalidate_recorded_steps_and_graphs(pkg):
+    """act_noise, act_limit, the learning rates, gamma and rho are frozen into the recorded interior
+    steps and the graphs.  A noise schedule (the reference decays act_noise between training loops,
+    scripts/KS/setup/KSSetup.jl:304-319) must reach the kernels: after the change the pipeline with recorded steps /
+    graphs equals the one issued through the Python layers every step."""
+    pa = _make(pkg, True)
+    pb = _make(pkg, False)
+    pb.fast_eager = False
+    pa.run(5); pa.capture()
+    pb.run(pa.tick)
+    pa.run(14); pb.run(14)
+    for p in (pa, pb):
+        p.policy.act_noise = 0.05
+        p.policy.behavior_actor.optimizer.eta = 1e-4
+    pa.run(20); pb.run(20)
+    pa.sync(); pb.sync()
+    assert not pa._captured and not pa.graphs and pa._progs       # dropped, interior steps re-recorded with the new values
+    assert torch.equal(pa.y, pb.y)
+    for k in range(3):
+        assert torch.equal(pa.aring[k], pb.aring[k])
+    _same_networks(pa, pb)
+    pa.capture()
+    pa.run(13); pb.run(pa.tick - pb.tick)
+    pa.sync(); pb.sync()
+    assert pa._captured and torch.equal(pa.y, pb.y)
+    _same_networks(pa, pb)
+    pa.close()
+
+
+def test_torch_events_disable_the_recorded_step_replay(pkg, monkeypatch):
+    """PDEC_TORCH_EVENTS=1 (diagnostic): the cross-stream records / waits are torch calls the recorded-call replay would
+    not re-issue, so fast_eager is off for that event type and the run equals the default one"""
+    monkeypatch.setenv("PDEC_TORCH_EVENTS", "1")
+    pt = _make(pkg, False)
+    monkeypatch.delenv("PDEC_TORCH_EVENTS")
+    pe = _make(pkg, False)
+    assert not pt.fast_eager and pe.fast_eager
+    pt.run(25); pe.run(25)
+    pt.sync(); pe.sync()
+    assert not pt._progs and torch.equal(pt.y, pe.y)
+    _same_networks(pt, pe)
+
+
+def test_restart_in_the_middle_of_an_episode(pkg):
+    """reset_from() at tick > 0 that does not follow a time-out step.  The transitions produced before
+    the restart must not be trained on (the first step of the new episode overwrites the next-state slot of the last old
+    transition): no update is issued until LAG steps of the new episode exist, recorded steps are dropped, and the
+    recorded-step pipeline equals the one issued through the Python layers."""
+    pa = _make(pkg, False)
+    pb = _make(pkg, False)
+    pb.fast_eager = False
+    for p in (pa, pb):
+        p.run(9)
+        p.sync()
+        before = [x.copy() for x in p.policy.behavior_critic.model.params()]
+        p.reset_from(p.env.y0)
+        assert p._first_tick == 9 and p.ep_start == 9 and not p._progs
+        p.run(2)                                   # steps 9, 10: their updates (transitions 7, 8) are skipped
+        p.sync()
+        after = p.policy.behavior_critic.model.params()
+        assert all(np.array_equal(x, y) for x, y in zip(before, after))
+        p.run(12)
+        p.sync()
+        assert not all(np.array_equal(x, y) for x, y in zip(before, p.policy.behavior_critic.model.params()))
+    assert torch.equal(pa.y, pb.y) and bool(torch.isfinite(pa.y).all())
+    _same_networks(pa, pb)
+
+
+def test_checkpoint_keeps_the_device_noise_counter(pkg, tmp_path):
+    """TrainPipeline's acting kernel advances a DEVICE-resident Philox counter
+    (pdec_policy_act_rng_dev); save_agent stores it and load_agent restores it, so a resumed pipeline continues the
+    exploration-noise stream instead of replaying it from 0.  Also: bit-generator states with arrays (MT19937) serialise."""
+    pa = _make(pkg, False, B=8)
+    pa.run(7); pa.sync()
+    ctr = C.c_uint64()
+    pkg._lib.check(pa.lib.pdec_noise_counter_get(pa.actor.handle, C.byref(ctr)))
+    assert ctr.value == 7 * ((pa.cols * pa.na + 3) // 4) > 0
+    pa.policy.rng = np.random.Generator(np.random.MT19937(3))
+    path = str(tmp_path / "agent.npz")
+    pkg.checkpoint.save_agent(path, pa.agent)
+    pb = _make(pkg, False, B=8)
+    pb.policy.rng = np.random.Generator(np.random.MT19937(4))
+    pkg.checkpoint.load_agent(path, pb.agent)
+    c2 = C.c_uint64()
+    pkg._lib.check(pb.lib.pdec_noise_counter_get(pb.actor.handle, C.byref(c2)))
+    assert c2.value == ctr.value
+    assert pb.policy.rng.integers(0, 1 << 30) == np.random.Generator(np.random.MT19937(3)).integers(0, 1 << 30)
+    _same_networks(pa, pb)
+
+
+def test_full_size_c2_pipeline_properties(pkg, monkeypatch):
+    """the exact instance the headline times -- config C2 at FULL size (KS N = 256, B = 512, fp32,
+    3-layer nets, 32 768 update columns, two streams, LAG 2, SIMD-sharing form of the fused step beside the critic pass) --
+    through TrainPipeline for 64 control steps including one episode reset (E = 51): every field / network finite, the
+    HIP-graph replay bit-identical to the eager issue, and the SIMD-sharing form tracking the register form (same
+    arithmetic and order: <= 2e-6 per step on y, checked teacher-forced on the step kernel itself at B = 512)."""
+    pe = _make(pkg, False, B=512, E=51, chunks=(24, 6, 1))
+    pg = _make(pkg, True, B=512, E=51, chunks=(24, 6, 1))
+    assert pe.simd_sharing and pe.rpart is not None and pe.stop_events and pe.kick_env_after_critic
+    pg.run(5); pg.capture()
+    pe.run(pg.tick)
+    n = 64 - pg.tick % 64 + 64
+    pg.run(n); pe.run(n)
+    pg.sync(); pe.sync()
+    assert pg.n_graph_launches > 0 and pe.tick == pg.tick >= 64 + 51
+    assert torch.equal(pe.y, pg.y) and torch.equal(pe.state, pg.state)
+    for k in range(3):
+        assert torch.equal(pe.aring[k], pg.aring[k]) and torch.equal(pe.rring[k], pg.rring[k])
+    _same_networks(pe, pg)
+    assert bool(torch.isfinite(pe.y).all()) and float(pe.y.abs().max()) < 50.0
+    for n_ in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        assert all(np.isfinite(x).all() for x in getattr(pe.policy, n_).model.params())
+    la, lc = pe.policy.losses()
+    assert np.isfinite(la) and np.isfinite(lc)
+    # SHARE vs register form of the very kernel instance, one step from the same state at B = 512
+    env = pe.env
+    pe.sync()
+    y_in, act = pe.y.clone(), pe.aring[(pe.tick - 1) % 3].clone()
+    outs = []
+    for share in (True, False):
+        env.set_simd_sharing(share)
+        with torch.cuda.stream(pe.s_env):
+            env.y.copy_(y_in)
+            env(act.clone())
+        pe.sync()
+        outs.append(env.y.clone())
+    env.set_simd_sharing(True)
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * max(1.0, float(outs[1].abs().max()))
+    pg.close(); pe.close()

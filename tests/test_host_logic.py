@@ -282,3 +282,37 @@ def test_jld2_writer_roundtrip_and_checksums(pkg, tmp_path):
         mine = next(o for o in w.objs.values() if o.dims == (1, 6))
         for (ta, pa, sa), (tb, pb, sb_) in zip(o.msgs[:3], mine.msgs[:3]):
             assert ta == tb and fr.buf[pa:pa + sa] == w.buf[pb:pb + sb_]
+
+
+def test_optional_featurize_branches_are_refused_or_restated(pkg):
+    """memory_size > 0 (KSSetup.jl:220-226, PDEagent.jl:201) is refused at setup by every setup class --
+    an error, not silence; temporal_steps > 1 is accepted (the step kernels' general featurize path) and the oracle restates
+    both branches of KSSetup.jl:209-218"""
+    from oracle import ks
+    for mk in (lambda **k: pkg.KSSetup.KS22(**k), lambda **k: pkg.FluidSetup(nx=32, sensors_per_axis=4, **k),
+               lambda **k: pkg.KellerSegelSetup(**k), lambda **k: pkg.KellerSegel2DSetup(**k)):
+        with pytest.raises(pkg.PdecError, match="memory_size"):
+            mk(memory_size=2)
+    with pytest.raises(pkg.PdecError, match="temporal_steps"):
+        pkg.KSSetup.KS22_global(temporal_steps=2)
+    s = pkg.KSSetup.KS22(window_size=3, temporal_steps=2)
+    assert s.state_shape == (6, 8) and s.env_cfg(1, 0).temporal_steps == 2
+    cfg = ks.KSConfig(192, 22.0, np.arange(1, 193, 24), sigma_sensors=0.7, sigma_actuators=0.7, window_size=3, temporal_steps=2)
+    y = np.sin(np.arange(192) / 7.0)
+    f0 = ks.featurize(cfg, y)
+    assert f0.shape == (6, 8) and np.array_equal(f0[:3], f0[3:])
+    f1 = ks.featurize(cfg, 2 * y, prev_state=f0)
+    assert np.array_equal(f1[3:], f0[:3]) and np.allclose(f1[:3], 2 * f0[:3])
+
+
+def test_graph_capture_phase_reachability(pkg):
+    """which (chunk, ring phase) pairs the graph capture can ever meet -- host logic of
+    pipeline.TrainPipeline._reachable, no GPU: E = 26 / 27 / 30 with chunk 24 miss phases, E = 51 (the bench) meets all"""
+    TP = pkg.TrainPipeline
+    def phases(E, c):
+        p = object.__new__(TP)
+        p.E, p.tick, p._first_tick, p.LAG, p.ep_start = E, 8, 0, 2, 0
+        return [pos for pos in range(6) if p._reachable(c, pos)]
+    assert phases(51, 24) == list(range(6)) and phases(17, 6) == list(range(6))
+    assert phases(26, 24) == [1, 3, 5] and phases(27, 24) == [1, 2, 4, 5] and phases(30, 24) == [1, 2, 3, 4, 5]
+    assert phases(26, 6) == list(range(6)) and phases(0, 24) == list(range(6))

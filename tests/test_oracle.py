@@ -254,3 +254,17 @@ def test_philox_stream_known_answer_and_derived_draws():
     assert len(np.unique(lg)) > 700
     z = rng.randn(1, 0, 200000)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+
+
+def test_c_oracle_is_clean_under_asan_and_ubsan():
+    """SURVEY.md §5 (sanitizers; CPU build only -- GPU ASAN is unavailable on the pool): the oracle's C restatement rebuilt
+    with -fsanitize=address,undefined behind oracle/c/sanitize_main.c, which drives every exported entry point at ragged
+    sizes with exactly-sized buffers; any out-of-bounds access / UB aborts the run"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle", "c"), "sanitize"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="3")
+    r = subprocess.run([os.path.join(root, "oracle", "_build", "oracle_sanitize")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "sanitize: OK" in r.stdout, r.stdout + r.stderr

@@ -36,5 +36,5 @@ for k, c in acc.items():
     if e.get("SQ_VALU_MFMA_BUSY_CYCLES") and e.get("SQ_BUSY_CYCLES"):
         e["mfma_busy_over_sq_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CYCLES"]
     out[k] = e
-json.dump({"csrc_sha16": bench.csrc_sha16(), "kernels": out}, sys.stdout, indent=1)
+json.dump({"csrc_sha16": bench.csrc_sha16(os.environ.get("PDEC_PMC_CONFIG", "C2")), "kernels": out}, sys.stdout, indent=1)
 print()

@@ -14,6 +14,8 @@ Units and gfx950 corrections applied (same guide): the counters are in KiB; FETC
 is the corrected figure for 16-B-per-lane streaming reads and `fetch_bytes_raw` the uncorrected one
 (narrower accesses are uncalibrated: the truth lies between the two); WRITE_SIZE is exact for
 16-B-per-lane stores.  bench.py reads the newest profiles/r*_pmc_traffic.json for `roofline.traffic`.
+For `bench.py --config C4 | C5` collect with that flag, set PDEC_PMC_CONFIG=C4 | C5 for this script (the kernel-source hash it
+stamps is the one of that config) and name the file profiles/rNN_c4_pmc_traffic.json / rNN_c5_pmc_traffic.json.
 """
 import csv
 import glob
@@ -66,7 +68,7 @@ def main():
             e["hbm_bytes_per_launch_uncorrected"] = f * 1024 + w * 1024
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench                                      # csrc_sha16(): which kernel sources these counters belong to
-    json.dump({"source_files": [os.path.relpath(s) for s in srcs], "csrc_sha16": bench.csrc_sha16(), "kernels": out},
+    json.dump({"source_files": [os.path.relpath(s) for s in srcs], "csrc_sha16": bench.csrc_sha16(os.environ.get("PDEC_PMC_CONFIG", "C2")), "kernels": out},
               sys.stdout, indent=1)
     print()
 
