@@ -609,11 +609,12 @@ __device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float g
   }
 }
 
+// ROUND-2 FORM, kept as the bit-identity reference of fused_finish_kernel below (PDEC_FINISH_REF=1 selects it; tests only).
 // grid: nslab > 0 -> one block per chunk (4 * slab_tiles(MT)); nslab == 0 -> ceil(n / 64) blocks (apply from grads).
 // block = 64 chunk elements x 16 slab groups (1024 threads): each thread sums every 16th slab (16 loads in flight,
 // a contiguous 256-B row each), then a fixed-order combine over the groups -> deterministic, so data-parallel
 // replicas stay bit-identical.
-__global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g_in) {
+__global__ __launch_bounds__(1024) void fused_finish_ref_kernel(FinishArgs g_in) {
   FinishArgs g = g_in;
   set_wave_prio(g.prio);
   if (g.apply) {      // the beta powers come from device memory; one thread of the grid writes the advanced pair
@@ -689,6 +690,110 @@ __global__ __launch_bounds__(1024) void fused_finish_kernel(FinishArgs g_in) {
     }
     __syncthreads();
     for (int sft = 128; sft > 0; sft >>= 1) {
+      if (tid < sft)
+        for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + sft];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double inv = 1.0 / g.Bu;
+      if (g.mode == 0)   // critic: quirk -> mean(c^2) + 2 mean(c) mean(r) + mean(r^2); else mean((r+c)^2)
+        *g.loss_out = (float)(g.quirk ? red[1][0] * inv + 2.0 * (red[0][0] * inv) * (red[2][0] * inv) + red[3][0] * inv
+                                      : red[4][0] * inv);
+      else               // actor: -mean(q)
+        *g.loss_out = (float)(-red[0][0] * inv);
+    }
+  }
+}
+
+// Slab reduction + parameter update, round-3 decomposition.  The summation tree of every gradient element is the one of
+// the round-2 kernel above -- 16 partial sums over the slabs z = k, k + 16, k + 32, ... in that order, combined in the
+// order k = 0 .. 15 -- so parameters stay bit-identical; what changed is who adds what:
+//   * one block per HALF chunk (32 elements x nslab slabs = 128 contiguous bytes per slab row) instead of per chunk:
+//     the critic's 369 live chunks (64 KB each) over 256 CUs put two whole chunks on 140 CUs and one on the rest, and a
+//     CU streams at a fixed ~10 B/clk, so the launch lasted as long as 128 KB on one CU; 738 halves leave at most 96 KB;
+//   * 128 threads per block = 16 slab groups x 8 lanes, every lane loads 16 B (four elements of a slab row) and keeps
+//     16 such loads in flight: a quarter of the load instructions for the same bytes;
+//   * all blocks are co-resident (792 blocks x 2 waves = 6 waves per CU), so no second round of blocks waits for the first.
+// grid: nslab > 0 -> 8 * slab_tiles(MT) blocks; nslab == 0 -> ceil(n / 128) blocks (apply from the gradient buffer).
+#define FIN_THREADS 128
+__global__ __launch_bounds__(FIN_THREADS) void fused_finish_kernel(FinishArgs g_in) {
+  FinishArgs g = g_in;
+  set_wave_prio(g.prio);
+  if (g.apply) {      // the beta powers come from device memory; one thread of the grid writes the advanced pair
+    g.omb1p = 1.0 - g.bp.cur[0];
+    g.omb2p = 1.0 - g.bp.cur[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) bp_advance(g.bp, g.b1, g.b2);
+  }
+  __shared__ float part[16][36];
+  const int tid = threadIdx.x;
+  const int K0 = g.K0, H = g.H, MT = g.MT;
+  const int n = H * K0 + H + H * H + H + H + 1;
+  const int offb1 = H * K0, offW2 = offb1 + H, offb2 = offW2 + H * H, offW3 = offb2 + H, offb3 = offW3 + H;
+  if (g.nslab > 0) {
+    const int c = blockIdx.x >> 1, half = blockIdx.x & 1, T = c >> 2, r = c & 3;
+    int i = -1;   // flat parameter index of the chunk element this thread finishes (threads 0..31; -1: padding)
+    if (tid < 32) {
+      const int l = 32 * half + tid, q = l >> 4, lr = l & 15;
+      if (T < MT) {                                  // dW3 / db3: only row 0 of the [16][HP] product is real
+        const int row = 4 * q + r, col = 16 * T + lr;
+        if (row == 0) i = col < H ? offW3 + col : (col == H ? offb3 : -1);
+      } else if (T < MT + MT * MT) {                 // dW2 / db2
+        const int u = T - MT, ti = u / MT, tk = u - ti * MT;
+        const int row = 16 * ti + 4 * q + r, col = 16 * tk + lr;
+        if (row < H) i = col < H ? offW2 + row * H + col : (col == H ? offb2 + row : -1);
+      } else {                                       // dW1 / db1
+        const int ti = T - MT - MT * MT;
+        const int row = 16 * ti + 4 * q + r, col = lr;
+        if (row < H) i = col < K0 ? row * K0 + col : (col == K0 ? offb1 + row : -1);
+      }
+    }
+    if (__syncthreads_or(i >= 0)) {
+      float p0 = 0.f, m0 = 0.f, v0 = 0.f, pt0 = 0.f;
+      if (g.apply && i >= 0) {                       // issue the parameter loads before the slab stream
+        p0 = g.p[i]; m0 = g.m[i]; v0 = g.v[i];
+        if (g.pt) pt0 = g.pt[i];
+      }
+      const int tx4 = tid & 7, ty = tid >> 3;        // 16-byte lane inside the 128-byte half row, slab group
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(g.slabs + (size_t)c * g.nslab * 64 + 32 * half) + tx4;   // row stride: 16 float4
+        int z = ty;
+        for (; z + 240 < g.nslab; z += 256) {
+          f32x4 v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(&sp[(size_t)(z + 16 * u) * 16]);
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; z < g.nslab; z += 16) acc += sp[(size_t)z * 16];
+      }
+      *reinterpret_cast<f32x4*>(&part[ty][4 * tx4]) = acc;
+      __syncthreads();
+      if (i >= 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += part[k][tid];
+        a *= g.scale;
+        g.grads[i] = a;
+        if (g.apply) finish_param(g, i, a, p0, m0, v0, pt0);
+      }
+    }
+  } else {
+    const int i = blockIdx.x * FIN_THREADS + tid;
+    if (i < n && g.apply) finish_param(g, i, g.grads[i], g.p[i], g.m[i], g.v[i], g.pt ? g.pt[i] : 0.f);
+  }
+  if (blockIdx.x == 0 && g.loss_out && g.nslab > 0) {   // block 0 also finalises the loss (fixed-order tree -> deterministic)
+    // the round-2 tree: 256 strided partial sums, pairwise tree 128, 64, ..., 1 -- thread t owns partials t and t + 128
+    // and starts with their sum (= the tree's first level)
+    __shared__ double red[5][FIN_THREADS];
+    const float* stc = g.slabs + (size_t)(4 * (2 * MT + MT * MT)) * g.nslab * 64;   // stats chunk
+    double st[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+    for (int hh = 0; hh < 2; ++hh)
+      for (int z = tid + 128 * hh; z < g.nslab; z += 256)
+        for (int k = 0; k < 5; ++k) st[hh][k] += (double)stc[(size_t)z * 64 + k];
+    for (int k = 0; k < 5; ++k) red[k][tid] = st[0][k] + st[1][k];
+    __syncthreads();
+    for (int sft = 64; sft > 0; sft >>= 1) {
       if (tid < sft)
         for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + sft];
       __syncthreads();
@@ -930,16 +1035,23 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   const int n = M->nparams;
   {
     const char* label = ap ? (nslab > 0 ? "fused_finish" : "fused_apply") : "fused_reduce";
-    const int nblk = nslab > 0 ? 4 * slab_tiles(MT) : (n + 63) / 64;
-    if (M->prof) {
-      PDEC_TIMED_LAUNCH(M, label, fused_finish_kernel, dim3(nblk), dim3(1024), 0, g);
+    const bool use_ref = getenv("PDEC_FINISH_REF") != nullptr;            // tests only: the round-2 kernel (bit-identity reference)
+    if (use_ref) {
+      const int nblk = nslab > 0 ? 4 * slab_tiles(MT) : (n + 63) / 64;
+      hipLaunchKernelGGL(fused_finish_ref_kernel, dim3(nblk), dim3(1024), 0, M->stream, g);
       if (M->stop_event && ap) (void)hipEventRecord(M->stop_event, M->stream);
-    } else if (M->stop_event && ap) {
-      // the event rides on this kernel's own dispatch packet (its completion signal): a hipEventRecord behind the
-      // launch is a packet of its own that the next kernel of the stream has to wait for (~4.5 us of the update chain)
-      hipExtLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(1024), 0, M->stream, nullptr, M->stop_event, 0, g);
     } else {
-      hipLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(1024), 0, M->stream, g);
+      const int nblk = nslab > 0 ? 8 * slab_tiles(MT) : (n + FIN_THREADS - 1) / FIN_THREADS;
+      if (M->prof) {
+        PDEC_TIMED_LAUNCH(M, label, fused_finish_kernel, dim3(nblk), dim3(FIN_THREADS), 0, g);
+        if (M->stop_event && ap) (void)hipEventRecord(M->stop_event, M->stream);
+      } else if (M->stop_event && ap) {
+        // the event rides on this kernel's own dispatch packet (its completion signal): a hipEventRecord behind the
+        // launch is a packet of its own that the next kernel of the stream has to wait for (~4.5 us of the update chain)
+        hipExtLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(FIN_THREADS), 0, M->stream, nullptr, M->stop_event, 0, g);
+      } else {
+        hipLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(FIN_THREADS), 0, M->stream, g);
+      }
     }
     if (ap) M->stop_event = nullptr;     // consumed by the launch that applies the update (not by a reduce-only one)
   }

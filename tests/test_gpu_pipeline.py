@@ -213,3 +213,43 @@ def test_full_size_c2_pipeline_properties(pkg, monkeypatch):
     env.set_simd_sharing(True)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * max(1.0, float(outs[1].abs().max()))
     pg.close(); pe.close()
+
+
+@pytest.mark.parametrize("B", [64, 512])
+def test_round3_finish_kernel_is_bit_identical_to_the_round2_one(pkg, monkeypatch, B):
+    """fused_finish_kernel was re-cut (one block per half chunk, 16-byte loads, 128 threads) for HBM
+    throughput with the summation tree of every gradient element unchanged (src/custom_nna.jl:23-24, src/PDEagent.jl:415-417:
+    ADAM in Float64, Polyak).  40 control steps of the training pipeline (one episode boundary; 32 and 256 gradient slabs)
+    with the round-2 kernel (PDEC_FINISH_REF=1) and with the new one: all four networks, their ADAM moments, the losses and
+    the fields bit-identical."""
+    import ctypes as C
+    monkeypatch.setenv("PDEC_FINISH_REF", "1")
+    pa = _make(pkg, False, B=B, E=23)
+    pa.run(40); pa.sync()
+    la = pa.policy.losses()
+    monkeypatch.delenv("PDEC_FINISH_REF")
+    pb = _make(pkg, False, B=B, E=23)
+    pb.run(40); pb.sync()
+    _same_networks(pa, pb)
+    assert torch.equal(pa.y, pb.y) and la == pb.policy.losses() and all(np.isfinite(la))
+    for n in ("behavior_actor", "behavior_critic"):
+        sa, sb = pkg.checkpoint._adam_state(getattr(pa.policy, n).model), pkg.checkpoint._adam_state(getattr(pb.policy, n).model)
+        assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), n
+
+
+@pytest.mark.parametrize("B", [64, 512])
+def test_prefetching_passes_are_bit_identical_to_the_round2_form(pkg, monkeypatch, B):
+    """the critic / actor passes now keep a second LDS region and copy the next weight image (W2 of the
+    behaviour critic, W2^T for the backward pass) while the current one is still being read, in two row parts
+    (csrc/mlp_mfma.hip, PF).  Only WHERE an operand row is read from changes -- the MFMA chains, their order and every sum
+    are the same -- so 30 pipeline steps with PDEC_PREFETCH=0 (round-2 form: one region, image switches exposed) and with
+    the default give bit-identical networks, losses and fields (src/PDEagent.jl:385-409)."""
+    monkeypatch.setenv("PDEC_PREFETCH", "0")
+    pa = _make(pkg, False, B=B, E=19)
+    pa.run(30); pa.sync()
+    la = pa.policy.losses()
+    monkeypatch.delenv("PDEC_PREFETCH")
+    pb = _make(pkg, False, B=B, E=19)
+    pb.run(30); pb.sync()
+    _same_networks(pa, pb)
+    assert torch.equal(pa.y, pb.y) and la == pb.policy.losses() and all(np.isfinite(la))
