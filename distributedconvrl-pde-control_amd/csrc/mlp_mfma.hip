@@ -31,26 +31,33 @@ namespace pdec {
 #define LDW1 20            // LDS leading dim of W1 images
 
 // padded weight image of one 3-layer net [K0, H, H, 1] (device, floats)
+// Round 3: the image is laid out exactly as the passes keep it in LDS -- first the "small" block [W1 [HP][LDW1] | b1 [HP] |
+// b2 [HP] | w3 [HP] | b3 [4]], then W2 [HP][LDW] and W2^T [HP][LDW], each block padded to a multiple of 256 floats -- so that
+// every block reaches LDS by asynchronous LDS-DMA in whole 1-KiB pieces (dma_even): no register round trip, no remainder.
 struct FNet {
   const float* w;   // base
   int K0, H, HP, LDW;
-  int oW1, ob1, oW2, oW2T, ob2, ow3, ob3, total;
+  int oW1, ob1, ob2, ow3, ob3, oW2, oW2T, total;
+  int nsmall, nbig;   // padded block sizes (floats, multiples of 256)
 };
+__host__ __device__ constexpr int pad256(int n) { return (n + 255) / 256 * 256; }
+__host__ __device__ constexpr int small_floats(int HP) { return pad256(HP * LDW1 + 3 * HP + 4); }
+__host__ __device__ constexpr int big_floats(int HP) { return pad256(HP * (HP + LDWPAD)); }
 
 static FNet make_fnet_layout(int K0, int H) {
   FNet f{};
   f.K0 = K0; f.H = H;
   f.HP = (H + 1 + 15) / 16 * 16;
   f.LDW = f.HP + LDWPAD;
-  int o = 0;
-  f.oW1 = o; o += f.HP * KXP;
-  f.ob1 = o; o += f.HP;
-  f.oW2 = o; o += f.HP * f.LDW;
-  f.oW2T = o; o += f.HP * f.LDW;
-  f.ob2 = o; o += f.HP;
-  f.ow3 = o; o += f.HP;
-  f.ob3 = o; o += 4;
-  f.total = o;
+  f.nsmall = small_floats(f.HP); f.nbig = big_floats(f.HP);
+  f.oW1 = 0;
+  f.ob1 = f.HP * LDW1;
+  f.ob2 = f.ob1 + f.HP;
+  f.ow3 = f.ob2 + f.HP;
+  f.ob3 = f.ow3 + f.HP;
+  f.oW2 = f.nsmall;
+  f.oW2T = f.oW2 + f.nbig;
+  f.total = f.oW2T + f.nbig;
   return f;
 }
 
@@ -61,13 +68,13 @@ __global__ void prep_fused_kernel(const float* __restrict__ p, float* __restrict
   const int K0 = f.K0, H = f.H;
   const int pW1 = 0, pb1 = H * K0, pW2 = pb1 + H, pb2 = pW2 + H * H, pW3 = pb2 + H, pb3 = pW3 + H;
   float v = 0.f;
-  if (i < f.ob1) { const int r = (i - f.oW1) / KXP, c = (i - f.oW1) % KXP; if (r < H && c < K0) v = p[pW1 + r * K0 + c]; }
-  else if (i < f.oW2) { const int r = i - f.ob1; if (r < H) v = p[pb1 + r]; }
-  else if (i < f.oW2T) { const int r = (i - f.oW2) / f.LDW, c = (i - f.oW2) % f.LDW; if (r < H && c < H) v = p[pW2 + r * H + c]; }
-  else if (i < f.ob2) { const int r = (i - f.oW2T) / f.LDW, c = (i - f.oW2T) % f.LDW; if (r < H && c < H) v = p[pW2 + c * H + r]; }
+  if (i < f.ob1) { const int r = i / LDW1, c = i % LDW1; if (r < H && c < K0) v = p[pW1 + r * K0 + c]; }
+  else if (i < f.ob2) { const int r = i - f.ob1; if (r < H) v = p[pb1 + r]; }
   else if (i < f.ow3) { const int r = i - f.ob2; if (r < H) v = p[pb2 + r]; }
   else if (i < f.ob3) { const int r = i - f.ow3; if (r < H) v = p[pW3 + r]; }
-  else { if (i == f.ob3) v = p[pb3]; }
+  else if (i < f.oW2) { if (i == f.ob3) v = p[pb3]; }
+  else if (i < f.oW2T) { const int r = (i - f.oW2) / f.LDW, c = (i - f.oW2) % f.LDW; if (r < H && c < H) v = p[pW2 + r * H + c]; }
+  else { const int r = (i - f.oW2T) / f.LDW, c = (i - f.oW2T) % f.LDW; if (r < H && c < H) v = p[pW2 + c * H + r]; }
   out[i] = v;
 }
 
@@ -81,36 +88,36 @@ __device__ __forceinline__ SmallLds carve_small(float* base, int HP) {
   s.W1 = base; s.b1 = s.W1 + HP * LDW1; s.b2 = s.b1 + HP; s.w3 = s.b2 + HP; s.b3 = s.w3 + HP;
   return s;
 }
-static inline int small_floats(int HP) { return HP * LDW1 + 3 * HP + 4; }
-// floats of the big region: the padded W2 image, or the staging images that later overlay it
+// floats of the big region: the padded W2 image (in whole DMA pieces), or the staging images that later overlay it
 __host__ __device__ constexpr int wreg_floats(int MT, int MTA) {
   const int HP = 16 * MT, HPa = 16 * MTA;
-  int a = HP * (HP + LDWPAD), b = 2 * HP * LDP, c = (32 + 4 * HPa) * LDP;
+  int a = big_floats(HP), b = 2 * HP * LDP, c = (32 + 4 * HPa) * LDP;
   int m = a > b ? a : b;
   return m > c ? m : c;
 }
 
-__device__ __forceinline__ void load_small(const SmallLds& s, const FNet& f, int tid) {
-  for (int i = tid; i < f.HP * KXP; i += FTHREADS) s.W1[(i / KXP) * LDW1 + (i % KXP)] = f.w[f.oW1 + i];
-  for (int i = tid; i < f.HP; i += FTHREADS) { s.b1[i] = f.w[f.ob1 + i]; s.b2[i] = f.w[f.ob2 + i]; s.w3[i] = f.w[f.ow3 + i]; }
-  if (tid < 4) s.b3[tid] = f.w[f.ob3 + tid];
-}
-// global -> LDS copy of a padded weight image: loads are issued in batches of 6 x 16 B per lane before the
-// first LDS store so that the L2 latency is paid once per batch, not once per element
-__device__ __forceinline__ void load_big(float* dst, const float* src, int n, int tid) {
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-  const int n4 = n / 4;
-  int i = tid;
-  for (; i + 5 * FTHREADS < n4; i += 6 * FTHREADS) {
-    f32x4 v[6];
+// Asynchronous global -> LDS copy of NFL floats (a multiple of 256) by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+// instruction, no VGPR round trip).  EVERY one of the NW waves issues the same number of instructions, dma_count<NFL, NW>()
+// -- a wave whose turn falls beyond the last piece copies the last piece again (same bytes, harmless) -- so that a wave can
+// wait for an older copy while younger ones are still in flight with a literal s_waitcnt vmcnt(N) (dma_wait_but<N>).
+// The data may be read after that wait + a workgroup barrier.
+template <int NFL, int NW>
+__host__ __device__ constexpr int dma_count() { return (NFL / 256 + NW - 1) / NW; }
+template <int NFL, int NW>
+__device__ __forceinline__ void dma_even(float* dst_lds, const float* src, int w, int l) {
+  static_assert(NFL % 256 == 0 && NFL > 0, "dma_even copies whole 1-KiB pieces");
+  constexpr int NCH = NFL / 256;
 #pragma unroll
-    for (int u = 0; u < 6; ++u) v[u] = s4[i + u * FTHREADS];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) d4[i + u * FTHREADS] = v[u];
+  for (int j = 0; j < dma_count<NFL, NW>(); ++j) {
+    int c = w + NW * j;
+    c = c < NCH ? c : NCH - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 256 + l * 4),
+                                     (__attribute__((address_space(3))) void*)(dst_lds + (size_t)c * 256), 16, 0, 0);
   }
-  for (; i < n4; i += FTHREADS) d4[i] = s4[i];
 }
+template <int N>
+__device__ __forceinline__ void dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // h = relu(W1 x + b1): x given as KT register rows (lane holds x[4t+q][col])
 template <int MT, int KT>
@@ -130,14 +137,16 @@ __device__ __forceinline__ void layer_in(f32x4 (&h)[MT], const float (&x)[KT], c
 // out = W in (+ bias): W image row-major [..][ldw] in LDS, 4 consecutive k per ds_read_b128.
 // Two output tiles are accumulated at a time with their MFMAs interleaved, so consecutive MFMAs of a wave are
 // independent (issue interval 32 cycles instead of the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32).
-template <int MTO, int MTI, bool BIAS>
-__device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MTI], const float* W, int ldw,
-                                         const float* bias, int lr, int q) {
+// Tiles MO0 .. MO1-1 of the output only: a weight image may live in two LDS regions (rows below / above a split), each
+// handed in with a base pointer W such that row r of the image is at W + r * ldw.
+template <int MTO, int MTI, bool BIAS, int MO0, int MO1>
+__device__ __forceinline__ void layer_hh_part(f32x4 (&out)[MTO], const f32x4 (&in)[MTI], const float* W, int ldw,
+                                              const float* bias, int lr, int q) {
 #ifndef PDEC_LAYER_PAIR
 #define PDEC_LAYER_PAIR 1
 #endif
 #pragma unroll
-  for (int mo = 0; PDEC_LAYER_PAIR && mo + 1 < MTO; mo += 2) {
+  for (int mo = MO0; PDEC_LAYER_PAIR && mo + 1 < MO1; mo += 2) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (BIAS) {
       const float* b = bias + 16 * mo + 4 * q;
@@ -174,7 +183,7 @@ __device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MT
     out[mo + 1] = acc1;
   }
 #pragma unroll
-  for (int mo = PDEC_LAYER_PAIR ? (MTO & ~1) : 0; mo < MTO; ++mo) {
+  for (int mo = PDEC_LAYER_PAIR ? MO0 + ((MO1 - MO0) & ~1) : MO0; mo < MO1; ++mo) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (BIAS) {
       const float* b = bias + 16 * mo + 4 * q;
@@ -192,19 +201,11 @@ __device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MT
     out[mo] = acc;
   }
 }
-
-// Asynchronous global -> LDS copy (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR round trip).
-// nfl floats, src and dst 16-byte aligned.  The data may be read after dma_wait() + a workgroup barrier.
-__device__ __forceinline__ void dma_copy(float* dst_lds, const float* src, int nfl, int tid) {
-  const int w = tid >> 6, l = tid & 63;
-  const int nchunk = nfl >> 8;
-  for (int c = w; c < nchunk; c += FTHREADS / 64)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * 256 + l * 4),
-                                     (__attribute__((address_space(3))) void*)(dst_lds + (size_t)c * 256), 16, 0, 0);
-  const int done = nchunk << 8;
-  if (tid < nfl - done) dst_lds[done + tid] = src[done + tid];
+template <int MTO, int MTI, bool BIAS>
+__device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MTI], const float* W, int ldw,
+                                         const float* bias, int lr, int q) {
+  layer_hh_part<MTO, MTI, BIAS, 0, MTO>(out, in, W, ldw, bias, lr, q);
 }
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct FusedArgs {
   FNet A, C, At, Ct;          // A/At unused fields are ignored by the actor pass
@@ -230,18 +231,42 @@ struct FusedArgs {
 static inline int slab_tiles(int MT) { return MT + MT * MT + MT; }
 static inline size_t slab_floats_total(int MT, int nslab) { return ((size_t)4 * slab_tiles(MT) + 1) * nslab * 64; }
 
+// Workgroup barrier for LDS data only: every LDS operation of this wave is complete, then s_barrier.  Unlike __syncthreads()
+// -- whose workgroup fence makes hipcc wait vmcnt(0), i.e. drain every LDS-DMA in flight -- it leaves vector-memory
+// operations (the weight-image copies, slab stores) outstanding across the barrier.  The "memory" clobber keeps the
+// compiler from moving LDS accesses across it.  Data a DMA wrote is visible after dma_wait*() + lds_barrier().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// block-wide deterministic sum (the fixed tree of block_sum) on raw barriers
+__device__ __forceinline__ float block_sum_lds(float v, float* red, int tid) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  lds_barrier();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  lds_barrier();
+  float r = 0.f;
+  for (int i = 0; i < FTHREADS / 64; ++i) r += red[i];
+  lds_barrier();
+  return r;
+}
+
 // ------------------------------------------------------------------ critic pass
+// LDS map (floats): Wreg [wreg_floats] | sc [small(HP)] target critic's small block | sc2 [small(HP)] behaviour critic's |
+// sa [small(HPa)] | saW2 [big(HPa)] | red [8 + 8 HP + 64].  Round 3: every weight block arrives by LDS-DMA in whole pieces
+// (dma_even) -- round 2 loaded the small blocks through registers, 3.5 k cycles per load_small with nothing to overlap --
+// and the behaviour critic's small block is copied during the target phase into its own region, so the phase switch is one
+// barrier + the issue of the next big copy.  Copies are waited for in issue order with literal vmcnt counts.
 template <int MT, int MTA>
 __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
-  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD;
+  constexpr int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD, NW = FTHREADS / 64;
+  constexpr int NS = small_floats(HP), NSa = small_floats(HPa), NB = big_floats(HP), NBa = big_floats(HPa);
   float* Wreg = smem;                                   // [HP][LDW] big weight image / staging images
-  float* sc = Wreg + wreg_floats(MT, MTA);              // critic small image
-  float* sa = sc + (HP * LDW1 + 3 * HP + 4);            // actor small image
-  float* saW2 = sa + (HPa * LDW1 + 3 * HPa + 4);        // actor W2 [HPa][LDWa]
-  float* red = saW2 + HPa * LDWa;                       // [8]
-  const SmallLds SC = carve_small(sc, HP), SA = carve_small(sa, HPa);
+  float* sc = Wreg + wreg_floats(MT, MTA);              // target critic's small block
+  float* sc2 = sc + NS;                                 // behaviour critic's small block
+  float* sa = sc2 + NS;                                 // target actor's small block
+  float* saW2 = sa + NSa;                               // target actor's W2 [HPa][LDWa]
+  float* red = saW2 + NBa;                              // [8] block sums | [8][HP] pass A | [8][8] loss statistics
+  const SmallLds SCt = carve_small(sc, HP), SC = carve_small(sc2, HP), SA = carve_small(sa, HPa);
   const int ns = g.ns, na = g.na, K0 = ns + na;
   const int col = blockIdx.x * FCOLS + w * 16 + lr;
   const bool valid = col < g.Bu;
@@ -249,8 +274,14 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
 
   // ---- phase T: target actor + target critic
   STAMP(0);
-  // per-column inputs of all phases first (they are the OLDEST vector-memory operations, so waiting for them does not
-  // wait for the weight-image DMAs issued behind them)
+  // Copy schedule.  hipcc drains every LDS-DMA in flight (vmcnt(0)) at the first use of an ordinary global load and at every
+  // __syncthreads(), so: the small blocks of the target nets are copied first, the per-column inputs are loaded and CONSUMED
+  // (that wait covers the small copies, which are needed now anyway), and only then the long copies start -- the target
+  // critic's W2 and the behaviour critic's small block -- which stay in flight across the raw barriers (lds_barrier) of the
+  // target actor and layer 1.  No ordinary global load is used again before the last copy of the pass has been waited for.
+  dma_even<NS, NW>(sc, g.Ct.w, w, l);
+  dma_even<NSa, NW>(sa, g.At.w, w, l);
+  dma_even<NBa, NW>(saW2, g.At.w + g.At.oW2, w, l);
   float xn[4], xq[4];                       // input rows 4t+q of s' and of [s; a]
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -261,11 +292,8 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     else if (valid && row < K0) v = g.a[(size_t)col * na + (row - ns)];
     xq[t] = v;
   }
-  const float rv = valid ? g.r[col] : 0.f;
-  const float tv = valid ? g.t[col] : 0.f;
-  load_small(SC, g.Ct, tid);
-  load_small(SA, g.At, tid);
-  load_big(saW2, g.At.w + g.At.oW2, HPa * LDWa, tid);
+  float rv = valid ? g.r[col] : 0.f;
+  float tv = valid ? g.t[col] : 0.f;
   // mean reward for the reference's (1xBu).+(Bu) broadcast: every workgroup reduces all of r in the
   // same fixed order, so the value is identical everywhere
   float rsum = 0.f;
@@ -285,10 +313,16 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     for (; i < n4; i += FTHREADS) { const f32x4 v = r4[i]; rsum += (v[0] + v[1]) + (v[2] + v[3]); }
     for (int k = 4 * n4 + tid; k < g.Bu; k += FTHREADS) rsum += g.r[k];
   }
-  // the target critic's weight image lands in LDS while the target actor and the first critic layer run
-  dma_copy(Wreg, g.Ct.w + g.Ct.oW2, HP * LDW, tid);
-  float rbar = block_sum(rsum, red, tid) / (float)g.Bu;   // contains __syncthreads (small images visible)
-  if (g.rbar_dev) rbar = g.rbar_dev[0];
+  float rbar_in = g.rbar_dev ? g.rbar_dev[0] : 0.f;
+  // every loaded value is consumed HERE (the compiler's wait for them lands in front of this statement)
+  asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]),
+               "+v"(rv), "+v"(tv), "+v"(rsum), "+v"(rbar_in));
+  dma_wait();                                             // (the small copies; nothing else is outstanding)
+  dma_even<NB, NW>(Wreg, g.Ct.w + g.Ct.oW2, w, l);
+  dma_even<NS, NW>(sc2, g.C.w, w, l);
+  constexpr int N_SC = dma_count<NS, NW>();
+  float rbar = block_sum_lds(rsum, red, tid) / (float)g.Bu;   // raw barriers inside (small blocks visible afterwards)
+  if (g.rbar_dev) rbar = rbar_in;
   STAMP(1);
 
   float x[4];
@@ -305,27 +339,26 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     for (int t = 0; t < 4; ++t)
       if (4 * t + q == ns) x[t] = valid ? an : 0.f;
     f32x4 h1[MT], h2[MT];
-    layer_in<MT, 4>(h1, x, SC, lr, q);
-    dma_wait();
-    __syncthreads();
-    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
+    layer_in<MT, 4>(h1, x, SCt, lr, q);
+    dma_wait_but<N_SC>();                                 // the target critic's W2 has landed
+    lds_barrier();
+    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SCt.b2, lr, q);
     relu_<MT>(h2);
-    const float qt = head<MT>(h2, SC.w3, SC.b3[0], q);
+    const float qt = head<MT>(h2, SCt.w3, SCt.b3[0], q);
     tgt = g.gamma * (1.f - tv) * qt;
   }
-  __syncthreads();
+  dma_wait();                                             // the behaviour critic's small block (issued a phase ago)
+  lds_barrier();                                        // every wave is done with Wreg; sc2 visible
   STAMP(2);
-  // ---- phase Q: behaviour critic forward (small image first, then the big image lands behind layer 1)
-  load_small(SC, g.C, tid);
-  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);
-  __syncthreads();
+  // ---- phase Q: behaviour critic forward; its W2 lands behind layer 1
+  dma_even<NB, NW>(Wreg, g.C.w + g.C.oW2, w, l);
   STAMP(3);
 #pragma unroll
   for (int t = 0; t < 4; ++t) x[t] = xq[t];
   f32x4 h1[MT], h2[MT];
   layer_in<MT, 4>(h1, x, SC, lr, q);
   dma_wait();
-  __syncthreads();
+  lds_barrier();
   layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
   relu_<MT>(h2);
   const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
@@ -333,45 +366,62 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   const float dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
   // loss statistics (one lane per column contributes)
   const bool rep = valid && q == 0;
-  float st0 = rep ? c : 0.f, st1 = rep ? c * c : 0.f, st2 = rep ? rv : 0.f, st3 = rep ? rv * rv : 0.f,
-        st4 = rep ? (rv + c) * (rv + c) : 0.f;
+  float sv[5] = {rep ? c : 0.f, rep ? c * c : 0.f, rep ? rv : 0.f, rep ? rv * rv : 0.f, rep ? (rv + c) * (rv + c) : 0.f};
   const int nslab = gridDim.x;
   float* Lm = Wreg;                 // staging images overlay the big weight region
   float* Rm = Wreg + HP * LDP;
   const int cw = (w & 3) * 16 + lr;
 
-  // ---- pass A: dW3/db3 = dq x [h2; 1]^T.  A single output row: reduce dq*h2 over the 16 columns of each wave
-  // with lane shuffles, then over the 8 waves through LDS (fixed order -> deterministic); no MFMA/staging round.
-  __syncthreads();
+  // ---- pass A: dW3/db3 = dq x [h2; 1]^T.  A single output row: reduce dq*h2 over the 16 columns of each wave with DPP
+  // row sums, then over the 8 waves through LDS (fixed order -> deterministic); no MFMA/staging round.  Round 3: dz2 is taken
+  // from h2 first and the 36 row sums then overwrite h2 in place with no branch between them (round 2 interleaved each
+  // sum with its lane-0 store under an exec mask: 36 serial dependent chains, ~8 k cycles); the five loss statistics ride on
+  // the same barrier instead of a block reduction of their own at the end of the kernel.
+  lds_barrier();
   STAMP(4);
-  dma_copy(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);     // W2^T for the backward pass lands behind pass A
+  dma_even<NB, NW>(Wreg, g.C.w + g.C.oW2T, w, l);     // W2^T for the backward pass lands behind pass A
+  f32x4 dz2[MT];
+  head_bwd<MT>(dz2, h2, SC.w3, dq, q);
+  float a_keep = 0.f;                 // this thread's element of dW3 / of the statistics (stored behind the next barrier)
   {
-    float* redA = red + 8;            // [8][HP], its own LDS area
+    float* redA = red + 8;            // [8][HP]
+    float* red5 = redA + 8 * HP;      // [8][8]
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * m + 4 * q + r;
-        const float v = row_sum16((row == g.C.H ? 1.f : h2[m][r]) * dq);
-        if (lr == 0) redA[w * HP + row] = v;
+        h2[m][r] = row_sum16((row == g.C.H ? 1.f : h2[m][r]) * dq);
       }
-    __syncthreads();
-    if (tid < HP) {
-      float a = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < FTHREADS / 64; ++ww) a += redA[ww * HP + tid];
-      // slab position of element (row 0, column tid) of the [16][HP] product: tile tid/16, register 0, lane tid%16
-      g.slab[((size_t)(4 * (tid >> 4)) * nslab + blockIdx.x) * 64 + (tid & 15)] = a;
+    for (int k = 0; k < 5; ++k)
+      for (int off = 32; off > 0; off >>= 1) sv[k] += __shfl_xor(sv[k], off);
+    if (lr == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redA[w * HP + 16 * m + 4 * q + r] = h2[m][r];
+    }
+    if (l == 0)
+      for (int k = 0; k < 5; ++k) red5[w * 8 + k] = sv[k];
+    lds_barrier();
+    if (tid < HP) {
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) a_keep += redA[ww * HP + tid];
+    } else if (tid >= FTHREADS - 8) {          // the last eight lanes of the last wave: the statistics chunk
+      if (tid - (FTHREADS - 8) < 5)
+        for (int ww = 0; ww < NW; ++ww) a_keep += red5[ww * 8 + tid - (FTHREADS - 8)];
     }
   }
-  // ---- dz2, dh1 = W2^T dz2, dz1
-  f32x4 dz2[MT];
-  head_bwd<MT>(dz2, h2, SC.w3, dq, q);
-  __syncthreads();
+  // ---- dh1 = W2^T dz2, dz1
   STAMP(5);
-  dma_wait();
-  __syncthreads();
+  dma_wait();                         // W2^T (no store is outstanding yet: the slab stores of pass A follow the barrier)
+  lds_barrier();
   STAMP(6);
+  if (tid < HP)                       // slab position of element (row 0, column tid) of the [16][HP] product: tile tid/16, register 0, lane tid%16
+    g.slab[((size_t)(4 * (tid >> 4)) * nslab + blockIdx.x) * 64 + (tid & 15)] = a_keep;
+  else if (tid >= FTHREADS - 8)
+    g.slab[((size_t)(4 * (2 * MT + MT * MT)) * nslab + blockIdx.x) * 64 + (tid - (FTHREADS - 8))] = a_keep;
   f32x4 dz1[MT];
   layer_hh<MT, MT, false>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
 #pragma unroll
@@ -390,14 +440,14 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     const int cw128 = w * 16 + lr;
     f32x4 accC[((MT + 7) / 8 + 1) & ~1];
     zero_(accC);
-    __syncthreads();
+    lds_barrier();
     stage_rows_ld<MT>(Lc, LDP128, dz1, cw128, q, -1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int row = 4 * t + q;
       Rc[row * LDP128 + cw128] = row == K0 ? 1.f : x[t];
     }
-    __syncthreads();
+    lds_barrier();
     gemm_pass_paired<((MT + 7) / 8 + 1) & ~1, 8>(accC, Lc, Rc, LDP128, MT, 1, w, lr, q);
     store_pass(accC, g.slab, nslab, MT + MT * MT, MT, 1, w, l);
   }
@@ -407,68 +457,61 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
     f32x4 accB[(MT * MT + 7) / 8];
     zero_(accB);
     for (int half = 0; half < 2; ++half) {
-      __syncthreads();
+      lds_barrier();
       if ((w >> 2) == half) {
         stage_rows<MT>(Lm, dz2, cw, q, -1);
         stage_rows<MT>(Rm, h1, cw, q, g.C.H);
       }
-      __syncthreads();
+      lds_barrier();
       gemm_pass_paired<(MT * MT + 7) / 8, 4>(accB, Lm, Rm, LDP, MT, MT, w, lr, q);
     }
     store_pass(accB, g.slab, nslab, MT, MT, MT, w, l);
   }
   STAMP(9);
-  {   // the five loss statistics in one fixed-order block reduction
-    float sv[5] = {st0, st1, st2, st3, st4};
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-      for (int off = 32; off > 0; off >>= 1) sv[k] += __shfl_xor(sv[k], off);
-    __syncthreads();
-    float* red5 = Wreg;   // staging region is free again
-    if (l == 0)
-      for (int k = 0; k < 5; ++k) red5[w * 8 + k] = sv[k];
-    __syncthreads();
-    if (tid < 8) {
-      float* st = g.slab + ((size_t)(4 * (2 * MT + MT * MT)) * nslab + blockIdx.x) * 64;
-      float a = 0.f;
-      if (tid < 5)
-        for (int ww = 0; ww < FTHREADS / 64; ++ww) a += red5[ww * 8 + tid];
-      st[tid] = a;
-    }
-  }
   STAMP(10);
 }
 
 // ------------------------------------------------------------------ actor pass
+// LDS map: Wreg | sc (critic's small block) | sa | saW2 | saW2T | red [8] | X [32][LDW] (MT = 9).  The backward pass needs
+// W2^T where the forward had W2: its first 32 rows (two output tiles) are copied into X during the forward, the rest into
+// the big region at the switch, behind those two tiles -- round 2 waited for the whole 87.5 KB copy with nothing to do.
+#define AX_ROWS 32
 template <int MT, int MTA>
 __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
-  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD;
+  constexpr int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD, NW = FTHREADS / 64;
+  constexpr int NS = small_floats(HP), NSa = small_floats(HPa), NB = big_floats(HP), NBa = big_floats(HPa);
+  constexpr bool SPLIT = HP > AX_ROWS && (AX_ROWS * LDW) % 256 == 0;     // W2^T in two parts (X + big region)
+  constexpr int NX = SPLIT ? AX_ROWS * LDW : 256;
   float* Wreg = smem;
   float* sc = Wreg + wreg_floats(MT, MTA);
-  float* sa = sc + (HP * LDW1 + 3 * HP + 4);
-  float* saW2 = sa + (HPa * LDW1 + 3 * HPa + 4);
-  float* saW2T = saW2 + HPa * LDWa;
-  float* red = saW2T + HPa * LDWa;
+  float* sa = sc + NS;
+  float* saW2 = sa + NSa;
+  float* saW2T = saW2 + NBa;
+  float* red = saW2T + NBa;
+  float* X = red + 8;
   const SmallLds SC = carve_small(sc, HP), SA = carve_small(sa, HPa);
   const int ns = g.ns;
   const int col = blockIdx.x * FCOLS + w * 16 + lr;
   const bool valid = col < g.Bu;
   set_wave_prio(g.prio);
 
+  // copy schedule as in the critic pass: small blocks, then the per-column input loaded AND consumed, then the long copy
+  dma_even<NSa, NW>(sa, g.A.w, w, l);
+  dma_even<NBa, NW>(saW2, g.A.w + g.A.oW2, w, l);
+  dma_even<NBa, NW>(saW2T, g.A.w + g.A.oW2T, w, l);
+  dma_even<NS, NW>(sc, g.C.w, w, l);
   float xs[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int row = 4 * t + q;
     xs[t] = (valid && row < ns) ? g.s[(size_t)col * ns + row] : 0.f;
   }
-  load_small(SA, g.A, tid);
-  load_big(saW2, g.A.w + g.A.oW2, HPa * LDWa, tid);
-  load_small(SC, g.C, tid);
-  load_big(saW2T, g.A.w + g.A.oW2T, HPa * LDWa, tid);
-  dma_copy(Wreg, g.C.w + g.C.oW2, HP * LDW, tid);   // lands behind the actor forward and the critic's first layer
-  __syncthreads();
+  asm volatile("" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]));
+  dma_wait();
+  dma_even<NB, NW>(Wreg, g.C.w + g.C.oW2, w, l);      // lands behind the actor forward and the critic's first layer
+  lds_barrier();
   f32x4 ha1[MTA], ha2[MTA];
   layer_in<MTA, 4>(ha1, xs, SA, lr, q);
   layer_hh<MTA, MTA, true>(ha2, ha1, saW2, LDWa, SA.b2, lr, q);
@@ -480,7 +523,8 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   f32x4 h1[MT], h2[MT];
   layer_in<MT, 4>(h1, x, SC, lr, q);
   dma_wait();
-  __syncthreads();
+  lds_barrier();
+  if constexpr (SPLIT) dma_even<NX, NW>(X, g.C.w + g.C.oW2T, w, l);      // rows 0 .. 31 of W2^T, behind the forward
   layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
   relu_<MT>(h2);
   const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
@@ -488,12 +532,22 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   const float dq = valid ? -1.f / (float)g.Bu : 0.f;
   f32x4 dz2[MT];
   head_bwd<MT>(dz2, h2, SC.w3, dq, q);
-  __syncthreads();
-  dma_copy(Wreg, g.C.w + g.C.oW2T, HP * LDW, tid);
-  dma_wait();
-  __syncthreads();
   f32x4 dz1[MT];
-  layer_hh<MT, MT, false>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
+  if constexpr (SPLIT) {
+    dma_wait();
+    lds_barrier();                                       // X visible; every wave is done with the big region
+    dma_even<NB - NX, NW>(Wreg + NX, g.C.w + g.C.oW2T + NX, w, l);       // rows 32 .. of W2^T behind the first two tiles
+    layer_hh_part<MT, MT, false, 0, AX_ROWS / 16>(dz1, dz2, X, LDW, nullptr, lr, q);
+    dma_wait();
+    lds_barrier();
+    layer_hh_part<MT, MT, false, AX_ROWS / 16, MT>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
+  } else {
+    lds_barrier();
+    dma_even<NB, NW>(Wreg, g.C.w + g.C.oW2T, w, l);
+    dma_wait();
+    lds_barrier();
+    layer_hh<MT, MT, false>(dz1, dz2, Wreg, LDW, nullptr, lr, q);
+  }
   // da = sum_i W1[i][ns] * dz1[i]  (gradient w.r.t. the action input row of the critic)
   float da = 0.f;
 #pragma unroll
@@ -523,12 +577,12 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   float* I4 = I3 + HPa * LDP;             // DZA1 [HPa][LDP]
   float* I5 = I4 + HPa * LDP;             // Xaug [16][LDP]
   const int cw = (w & 3) * 16 + lr;
-  __syncthreads();
+  lds_barrier();
   for (int i = tid; i < 16 * LDP; i += FTHREADS) { I0[i] = 0.f; I5[i] = 0.f; }
   f32x4 acc3[1], acc2[(MTA * MTA + 7) / 8], acc1[1];
   zero_(acc3); zero_(acc2); zero_(acc1);
   for (int half = 0; half < 2; ++half) {
-    __syncthreads();
+    lds_barrier();
     if ((w >> 2) == half) {
       if (q == 0) I0[cw] = dza3;
       stage_rows<MTA>(I1, ha2, cw, q, g.A.H);
@@ -541,7 +595,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
         I5[row * LDP + cw] = row == ns ? 1.f : xs[t];
       }
     }
-    __syncthreads();
+    lds_barrier();
     gemm_pass(acc3, I0, I1, 1, MTA, w, lr, q);
     gemm_pass(acc2, I2, I3, MTA, MTA, w, lr, q);
     gemm_pass(acc1, I4, I5, MTA, 1, w, lr, q);
@@ -549,7 +603,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_actor_fused_kernel(FusedArgs g)
   store_pass(acc3, g.slab, nslab, 0, 1, MTA, w, l);
   store_pass(acc2, g.slab, nslab, MTA, MTA, MTA, w, l);
   store_pass(acc1, g.slab, nslab, MTA + MTA * MTA, MTA, 1, w, l);
-  st0 = block_sum(st0, red, tid);
+  st0 = block_sum_lds(st0, red, tid);
   if (tid == 0) {
     float* st = g.slab + ((size_t)(4 * (2 * MTA + MTA * MTA)) * nslab + blockIdx.x) * 64;
     st[0] = st0;
@@ -594,7 +648,7 @@ __device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float g
   g.p[i] = pn;
   const int K0 = g.K0, H = g.H;
   int o1, o2 = -1, j = i;
-  if (j < H * K0) o1 = g.lay.oW1 + (j / K0) * KXP + (j % K0);
+  if (j < H * K0) o1 = g.lay.oW1 + (j / K0) * LDW1 + (j % K0);
   else if ((j -= H * K0) < H) o1 = g.lay.ob1 + j;
   else if ((j -= H) < H * H) { o1 = g.lay.oW2 + (j / H) * g.lay.LDW + (j % H); o2 = g.lay.oW2T + (j % H) * g.lay.LDW + (j / H); }
   else if ((j -= H * H) < H) o1 = g.lay.ob2 + j;
@@ -829,15 +883,10 @@ __global__ __launch_bounds__(ACT_THREADS) void policy_act_fused_kernel(FNet f, c
   // wave priority: PDEC_PRIO_ACT (default 3: short and latency-critical when nothing else holds the PDE step back)
   set_wave_prio(prio);
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
-  const int HPa = 16 * MTA, LDWa = HPa + LDWPAD;
-  float* sa = smem;                                  // small image
-  float* saW2 = sa + (HPa * LDW1 + 3 * HPa + 4);     // W2 [HPa][LDWa]
+  constexpr int HPa = 16 * MTA, LDWa = HPa + LDWPAD, NSa = small_floats(HPa), NBa = big_floats(HPa);
+  float* sa = smem;                                  // small block
+  float* saW2 = sa + NSa;                            // W2 [HPa][LDWa]
   const SmallLds SA = carve_small(sa, HPa);
-  for (int i = tid; i < HPa * KXP; i += ACT_THREADS) SA.W1[(i / KXP) * LDW1 + (i % KXP)] = f.w[f.oW1 + i];
-  for (int i = tid; i < HPa; i += ACT_THREADS) { SA.b1[i] = f.w[f.ob1 + i]; SA.b2[i] = f.w[f.ob2 + i]; SA.w3[i] = f.w[f.ow3 + i]; }
-  if (tid < 4) SA.b3[tid] = f.w[f.ob3 + tid];
-  for (int i = tid; i < HPa * LDWa; i += ACT_THREADS) saW2[i] = f.w[f.oW2 + i];
-  __syncthreads();
   const int c = blockIdx.x * (ACT_THREADS / 4) + w * 16 + lr;
   const bool valid = c < cols;
   float x[4];
@@ -846,6 +895,10 @@ __global__ __launch_bounds__(ACT_THREADS) void policy_act_fused_kernel(FNet f, c
     const int row = 4 * t + q;
     x[t] = (valid && row < ns) ? state[(size_t)c * ns + row] : 0.f;
   }
+  dma_even<NSa, ACT_THREADS / 64>(sa, f.w, w, l);                 // the image is laid out as it sits in LDS: two copies
+  dma_even<NBa, ACT_THREADS / 64>(saW2, f.w + f.oW2, w, l);
+  dma_wait();
+  __syncthreads();
   f32x4 h1[MTA], h2[MTA];
   layer_in<MTA, 4>(h1, x, SA, lr, q);
   layer_hh<MTA, MTA, true>(h2, h1, saW2, LDWa, SA.b2, lr, q);
@@ -931,10 +984,14 @@ static FNet fnet_of(const Mlp* M) {
 
 template <int MT, int MTA>
 static size_t lds_bytes(bool actor_pass) {
-  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD;
-  (void)LDW;
-  size_t f = (size_t)wreg_floats(MT, MTA) + small_floats(HP) + small_floats(HPa) + (size_t)HPa * LDWa * (actor_pass ? 2 : 1) + 8 +
-             (actor_pass ? 0 : 8 * HP);   // critic pass: [8][HP] cross-wave reduction of pass A
+  const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD;
+  size_t f = (size_t)wreg_floats(MT, MTA) + small_floats(HPa) + 8;
+  if (actor_pass) {   // sc | sa | saW2 | saW2T | red [8] | X (the first rows of W2^T, see the kernel)
+    f += small_floats(HP) + 2 * (size_t)big_floats(HPa);
+    if (HP > AX_ROWS && (AX_ROWS * LDW) % 256 == 0) f += (size_t)AX_ROWS * LDW;
+  } else {            // sc | sc2 | sa | saW2 | red [8] + [8][HP] pass A + [8][8] loss statistics
+    f += 2 * (size_t)small_floats(HP) + big_floats(HPa) + 8 * HP + 64;
+  }
   return f * 4;
 }
 
@@ -1075,7 +1132,7 @@ int fused_policy_act(Mlp* A, const void* state, int cols, double act_noise, doub
   f.w = A->fw_pub[A->pub].as<float>();
   const int mta = mt_of(A->dims[1]);
   const int HPa = 16 * mta;
-  const size_t lds = ((size_t)small_floats(HPa) + (size_t)HPa * (HPa + LDWPAD)) * 4;
+  const size_t lds = ((size_t)small_floats(HPa) + (size_t)big_floats(HPa)) * 4;
   const int tanh_out = A->acts[2] == PDEC_ACT_TANH;
   PDEC_REQUIRE(A->acts[2] == PDEC_ACT_TANH || A->acts[2] == PDEC_ACT_IDENTITY, "fused act: unsupported output activation");
   PDEC_REQUIRE(mta <= 2 && lds <= 64 * 1024, "fused act: hidden width %d too large", A->dims[1]);

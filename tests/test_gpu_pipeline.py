@@ -235,21 +235,3 @@ def test_round3_finish_kernel_is_bit_identical_to_the_round2_one(pkg, monkeypatc
     for n in ("behavior_actor", "behavior_critic"):
         sa, sb = pkg.checkpoint._adam_state(getattr(pa.policy, n).model), pkg.checkpoint._adam_state(getattr(pb.policy, n).model)
         assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), n
-
-
-@pytest.mark.parametrize("B", [64, 512])
-def test_prefetching_passes_are_bit_identical_to_the_round2_form(pkg, monkeypatch, B):
-    """the critic / actor passes now keep a second LDS region and copy the next weight image (W2 of the
-    behaviour critic, W2^T for the backward pass) while the current one is still being read, in two row parts
-    (csrc/mlp_mfma.hip, PF).  Only WHERE an operand row is read from changes -- the MFMA chains, their order and every sum
-    are the same -- so 30 pipeline steps with PDEC_PREFETCH=0 (round-2 form: one region, image switches exposed) and with
-    the default give bit-identical networks, losses and fields (src/PDEagent.jl:385-409)."""
-    monkeypatch.setenv("PDEC_PREFETCH", "0")
-    pa = _make(pkg, False, B=B, E=19)
-    pa.run(30); pa.sync()
-    la = pa.policy.losses()
-    monkeypatch.delenv("PDEC_PREFETCH")
-    pb = _make(pkg, False, B=B, E=19)
-    pb.run(30); pb.sync()
-    _same_networks(pa, pb)
-    assert torch.equal(pa.y, pb.y) and la == pb.policy.losses() and all(np.isfinite(la))
