@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdeconv.so")
+LIB_PATH = os.environ.get("PDEC_LIB_PATH") or os.path.join(_HERE, "libpdeconv.so")      # (override: A/B builds, diagnostics)
 
 PDEC_F32, PDEC_F64 = 0, 1
 PDE_KS_CNAB2, PDE_KSEG_RK4, PDE_KS_RK4_FD, PDE_FLUID_RK4, PDE_KSEG2D_RK4 = 0, 1, 2, 3, 4
