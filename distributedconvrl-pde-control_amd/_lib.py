@@ -51,6 +51,7 @@ SIGNATURES = {
     "pdec_kseg2d_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _i, _pi32, _pi32, _i, _pi32],
     "pdec_fluid_ic": [Handle, _pd, _i, _vp],
     "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
+    "pdec_debug_critic_stamps": [Handle, _i, _pd],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
     "pdec_featurize": [Handle, _vp, _vp, _vp],

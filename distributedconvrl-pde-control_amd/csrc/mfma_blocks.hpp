@@ -147,6 +147,60 @@ __device__ __forceinline__ void gemm_pass_paired(f32x4 (&acc)[NACC], const float
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// gemm_pass_paired for the LAST round of a pass: every tile pair goes to its slab chunks right behind its own MFMAs instead of
+// all tiles at the end of the pass -- the 21 MB of dW2 partials then leave the chip spread over the round's ~10 k cycles of
+// MFMA work instead of as one burst that the end of the kernel waits for (~4 us of HBM write time at 256 workgroups).
+template <int NACC, int NT>
+__device__ __forceinline__ void gemm_pass_paired_store(f32x4 (&acc)[NACC], const float* L, const float* R, int ldp, int nL, int nR,
+                                                       int w, int lr, int q, float* slab, int nslab, int T0, int l) {
+#pragma unroll
+  for (int pp = 0; pp < NACC; pp += 2) {
+    const int p0 = w + 8 * pp, p1 = p0 + 8;
+    if (p0 < nL * nR) {
+      const int ti0 = p0 / nR, tk0 = p0 - ti0 * nR;
+      const float* l0 = L + (16 * ti0 + lr) * ldp + 4 * q;
+      const float* r0 = R + (16 * tk0 + lr) * ldp + 4 * q;
+      const bool two = pp + 1 < NACC && p1 < nL * nR;
+      const int ti1 = two ? p1 / nR : ti0, tk1 = two ? p1 - ti1 * nR : tk0;
+      const float* l1 = L + (16 * ti1 + lr) * ldp + 4 * q;
+      const float* r1 = R + (16 * tk1 + lr) * ldp + 4 * q;
+      f32x4 a0 = acc[pp], a1 = acc[pp + 1 < NACC ? pp + 1 : pp];
+      if (two) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 av0 = *reinterpret_cast<const f32x4*>(l0 + 16 * t);
+          const f32x4 bv0 = *reinterpret_cast<const f32x4*>(r0 + 16 * t);
+          const f32x4 av1 = *reinterpret_cast<const f32x4*>(l1 + 16 * t);
+          const f32x4 bv1 = *reinterpret_cast<const f32x4*>(r1 + 16 * t);
+          a0 = mfma4(av0[0], bv0[0], a0);
+          a1 = mfma4(av1[0], bv1[0], a1);
+          a0 = mfma4(av0[1], bv0[1], a0);
+          a1 = mfma4(av1[1], bv1[1], a1);
+          a0 = mfma4(av0[2], bv0[2], a0);
+          a1 = mfma4(av1[2], bv1[2], a1);
+          a0 = mfma4(av0[3], bv0[3], a0);
+          a1 = mfma4(av1[3], bv1[3], a1);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(l0 + 16 * t);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(r0 + 16 * t);
+          a0 = mfma4(av[0], bv[0], a0);
+          a0 = mfma4(av[1], bv[1], a0);
+          a0 = mfma4(av[2], bv[2], a0);
+          a0 = mfma4(av[3], bv[3], a0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        __builtin_nontemporal_store(a0[r], &slab[((size_t)(4 * (T0 + p0) + r) * nslab + blockIdx.x) * 64 + l]);
+        if (two) __builtin_nontemporal_store(a1[r], &slab[((size_t)(4 * (T0 + p1) + r) * nslab + blockIdx.x) * 64 + l]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 // write a D-layout activation (MT tiles) into a [feature][ldp] LDS image at column cw (any leading dimension)
 template <int MT>
 __device__ __forceinline__ void stage_rows_ld(float* img, int ldp, const f32x4 (&v)[MT], int cw, int q, int ones_row) {

@@ -1024,6 +1024,16 @@ int pdec_noise_counter_set(pdec_handle actor, uint64_t value) {
   return PDEC_OK;
 }
 
+int pdec_debug_critic_stamps(pdec_handle critic, int arm, double* out13) {
+  GET_MLP(M, critic);
+  if (arm) { M->stamps_armed = true; return PDEC_OK; }
+  PDEC_REQUIRE(out13, "pdec_debug_critic_stamps: null");
+  PDEC_REQUIRE(!M->stamps_armed && M->stamps_last[12] > 0, "pdec_debug_critic_stamps: no fused critic pass has run on this network since it was armed");
+  PDEC_HIP(hipStreamSynchronize(M->stream));
+  for (int i = 0; i < 13; ++i) out13[i] = M->stamps_last[i];
+  return PDEC_OK;
+}
+
 int pdec_noise_counter_get(pdec_handle actor, uint64_t* value) {
   GET_MLP(M, actor);
   PDEC_REQUIRE(value, "pdec_noise_counter_get: null");

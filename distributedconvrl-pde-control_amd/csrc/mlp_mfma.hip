@@ -391,6 +391,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
 
 
   // ---- phase T: target actor + target critic
+  if (g.stamps && threadIdx.x == 0) g.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memrealtime();
   STAMP(0);
   // Copy schedule.  hipcc drains every LDS-DMA in flight (vmcnt(0)) at the first use of an ordinary global load and at every
   // __syncthreads(), so: the small blocks of the target nets are copied first, the per-column inputs are loaded and CONSUMED
@@ -574,19 +575,25 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   {
     f32x4 accB[(MT * MT + 7) / 8];
     zero_(accB);
-    for (int half = 0; half < 2; ++half) {
-      lds_barrier();
-      if ((w >> 2) == half) {
-        stage_rows<MT>(Lm, dz2, cw, q, -1);
-        stage_rows<MT>(Rm, h1, cw, q, g.C.H);
-      }
-      lds_barrier();
-      gemm_pass_paired<(MT * MT + 7) / 8, 4>(accB, Lm, Rm, LDP, MT, MT, w, lr, q);
+    lds_barrier();
+    if ((w >> 2) == 0) {
+      stage_rows<MT>(Lm, dz2, cw, q, -1);
+      stage_rows<MT>(Rm, h1, cw, q, g.C.H);
     }
-    store_pass(accB, g.slab, nslab, MT, MT, MT, w, l);
+    lds_barrier();
+    gemm_pass_paired<(MT * MT + 7) / 8, 4>(accB, Lm, Rm, LDP, MT, MT, w, lr, q);
+    lds_barrier();
+    if ((w >> 2) == 1) {
+      stage_rows<MT>(Lm, dz2, cw, q, -1);
+      stage_rows<MT>(Rm, h1, cw, q, g.C.H);
+    }
+    lds_barrier();
+    gemm_pass_paired_store<(MT * MT + 7) / 8, 4>(accB, Lm, Rm, LDP, MT, MT, w, lr, q, g.slab, nslab, MT, l);     // stores behind each tile pair
   }
   STAMP(9);
   STAMP(10);
+  // slots 11 / 12: the constant 100 MHz counter at the start / end of the workgroup (shader clock = d s_memtime / d s_memrealtime x 100 MHz)
+  if (g.stamps && threadIdx.x == 0) g.stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------ actor pass
@@ -1153,22 +1160,33 @@ static size_t lds_bytes(bool actor_pass, bool split = false) {
   return f * 4;
 }
 
-// PDEC_STAMPS=1 (diagnostic): per-phase s_memtime deltas of the critic pass, averaged over workgroups, to stderr
-static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
+// Phase stamps of the critic pass (diagnostic; PDEC_STAMPS=1 prints them, pdec_debug_critic_stamps arms one launch and returns
+// them): per-phase s_memtime deltas averaged over the workgroups, and the shader clock the pass ran at
+static int read_stamps(Mlp* C, unsigned long long* dev, int grid, double* out13) {
   PDEC_HIP(hipStreamSynchronize(C->stream));
   std::vector<unsigned long long> h((size_t)grid * 16);
   PDEC_HIP(hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
-  double d[10] = {0};
-  unsigned long long tmin = ~0ull, tmax = 0;
+  double d[10] = {0}, clk = 0;
   for (int b = 0; b < grid; ++b) {
     for (int k = 0; k < 10; ++k) d[k] += (double)(h[b * 16 + k + 1] - h[b * 16 + k]);
-    tmin = std::min(tmin, h[b * 16]);
-    tmax = std::max(tmax, h[b * 16 + 10]);
+    const double rt = (double)(h[b * 16 + 12] - h[b * 16 + 11]);          // 100 MHz ticks
+    if (rt > 0) clk += (double)(h[b * 16 + 10] - h[b * 16]) / rt * 0.1;     // GHz
   }
-  fprintf(stderr, "[pdec stamps] critic pass, mean s_memtime ticks (100 MHz) per phase over %d WGs:", grid);
+  double tot = 0;
+  for (int k = 0; k < 10; ++k) { out13[k] = d[k] / grid; tot += out13[k]; }
+  out13[10] = tot;              // shader cycles per workgroup, first to last stamp
+  out13[11] = clk / grid;       // shader clock in GHz during the pass (mean over workgroups)
+  out13[12] = grid;
+  return PDEC_OK;
+}
+static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
+  double o[13];
+  int rc = read_stamps(C, dev, grid, o);
+  if (rc) return rc;
+  fprintf(stderr, "[pdec stamps] critic pass, mean shader cycles per phase over %d WGs:", grid);
   static const char* nm[10] = {"load+rbar", "target", "loadQ", "fwdQ", "passA", "loadW2T", "dz1", "passC", "passB", "stats"};
-  for (int k = 0; k < 10; ++k) fprintf(stderr, " %s=%.0f", nm[k], d[k] / grid);
-  fprintf(stderr, " | span=%llu\n", tmax - tmin);
+  for (int k = 0; k < 10; ++k) fprintf(stderr, " %s=%.0f", nm[k], o[k]);
+  fprintf(stderr, " | total=%.0f cycles, clock=%.3f GHz\n", o[10], o[11]);
   return PDEC_OK;
 }
 
@@ -1186,7 +1204,8 @@ static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  static const bool want_stamps = getenv("PDEC_STAMPS") != nullptr;
+  static const bool env_stamps = getenv("PDEC_STAMPS") != nullptr;
+  const bool want_stamps = env_stamps || C->stamps_armed;
   FusedArgs ga = g;
   if (want_stamps) {
     if (C->stamps.bytes < (size_t)grid * 16 * 8) PDEC_HIP(C->stamps.alloc((size_t)grid * 16 * 8));
@@ -1200,6 +1219,10 @@ static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
       hipLaunchKernelGGL(kern, dim3(grid), dim3(FTHREADS), lds, C->stream, ga);
   }
   PDEC_HIP(hipGetLastError());
+  if (C->stamps_armed) {          // pdec_debug_critic_stamps: keep the figures of this launch for the caller
+    C->stamps_armed = false;
+    return read_stamps(C, ga.stamps, grid, C->stamps_last);
+  }
   if (want_stamps) return dump_stamps(C, ga.stamps, grid);
   return PDEC_OK;
 }

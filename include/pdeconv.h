@@ -194,6 +194,13 @@ int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, cons
  * (sgn > 0) with FFTW's conventions (src/fluid_rk4.jl uses FFTW's fft / ifft).  len in {128,256,384,512,768}. */
 int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, int nlines, int sgn);
 
+/* Measurement aid of bench.py (no reference counterpart): arm = 1 makes the NEXT fused critic pass launched on `critic`
+ * (the behaviour critic of a 3-layer pair, src/PDEagent.jl:385-400) record s_memtime / s_memrealtime stamps at its phase
+ * boundaries; arm = 0 copies the record of that launch to out13[13] (host): the mean shader cycles of the ten phases per
+ * workgroup, their sum, the shader clock in GHz (d s_memtime / d s_memrealtime x 100 MHz) and the workgroup count.
+ * Synchronises the stream of the pass. */
+int pdec_debug_critic_stamps(pdec_handle critic, int arm, double* out13);
+
 /* ---------------------------------------------------------------- networks ----------- */
 /* Chain(Dense...) with weights shared across columns (src/PDEagent.jl:14-56).
  * dims[n_layers+1], acts[n_layers].  params_host: Flux.params order W1,b1,W2,b2,... each W

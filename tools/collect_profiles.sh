@@ -1,26 +1,47 @@
 #!/bin/bash
 # Collects the per-round profile artifacts on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r02l      -> gpurun_out/<tag>_*; copy what is to be judged into profiles/
+#   bash tools/collect_profiles.sh r03z [c2|c4|c5|all]   -> gpurun_out/<tag>_*; copy what is to be judged into profiles/
 set -u
 TAG=${1:-rXX}
+WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench_default.json
-python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --issue eager > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.log
-cp $(ls $O/${TAG}_trace/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats.csv
-python3 tools/trace_timeline.py $O/${TAG}_trace > $O/${TAG}_timeline.txt
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --issue eager > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --issue eager > /dev/null 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $O/${TAG}_pmc_sq -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --issue eager > /dev/null 2>&1
-python3 tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write > $O/${TAG}_pmc_traffic.json
-python3 tools/pmc_sq_summary.py $O/${TAG}_pmc_sq > $O/${TAG}_sq_counters.json
-python bench.py --steps 200 --warmup 20 --no-cpu-baseline --two-layer 2>/dev/null | tail -1 > $O/${TAG}_bench_two_layer.json
-python bench.py --steps 200 --warmup 20 --no-cpu-baseline --replay 2>/dev/null | tail -1 > $O/${TAG}_bench_replay.json
-python bench.py --steps 100 --warmup 10 --no-cpu-baseline --nx 1024 2>/dev/null | tail -1 > $O/${TAG}_bench_c3_shard.json
-PDEC_BENCH_BACKEND=gloo python bench.py --steps 100 --warmup 10 --no-cpu-baseline --gpus 2 2>/dev/null | tail -1 > $O/${TAG}_bench_n2_gloo_one_gpu.json
-python tools/bench_rollout.py > $O/${TAG}_bench_rollout.jsonl 2>/dev/null
-PDEC_SHARE=0 python bench.py --steps 600 --warmup 60 --no-cpu-baseline --issue eager 2>/dev/null | tail -1 > $O/${TAG}_ab_share0.json
-python bench.py --steps 600 --warmup 60 --no-cpu-baseline --issue eager 2>/dev/null | tail -1 > $O/${TAG}_ab_share1.json
+mkdir -p $O
+SQ="SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"
+prof() {   # prof <name> <pmc-config> <bench args...>: kernel-trace + stats, then three counter-only passes
+  local N=$1 CFG=$2; shift 2
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${N}trace -- python3 bench.py "$@" --no-cpu-baseline > $O/${TAG}_${N}bench_under_rocprof.json 2> $O/${TAG}_${N}rocprof.log
+  cp $(ls $O/${TAG}_${N}trace/*/*kernel_stats.csv | head -1) $O/${TAG}_${N}kernel_stats.csv
+  [ "$N" = "" ] && python3 tools/trace_timeline.py $O/${TAG}_trace > $O/${TAG}_timeline.txt
+  rm -rf $O/${TAG}_${N}trace
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_${N}pmc_fetch -- python3 bench.py "$@" --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_${N}pmc_write -- python3 bench.py "$@" --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $SQ --output-format csv -d $O/${TAG}_${N}pmc_sq -- python3 bench.py "$@" --no-cpu-baseline > /dev/null 2>&1
+  PDEC_PMC_CONFIG=$CFG python3 tools/pmc_traffic.py $O/${TAG}_${N}pmc_fetch $O/${TAG}_${N}pmc_write > $O/${TAG}_${N}pmc_traffic.json
+  PDEC_PMC_CONFIG=$CFG python3 tools/pmc_sq_summary.py $O/${TAG}_${N}pmc_sq > $O/${TAG}_${N}sq_counters.json
+  rm -rf $O/${TAG}_${N}pmc_fetch $O/${TAG}_${N}pmc_write $O/${TAG}_${N}pmc_sq
+}
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "c2" ]; then
+  prof "" C2 --steps 100 --warmup 10 --issue eager
+  python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench_default.json
+  python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench.json
+  PDEC_SPLIT=0 python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_exact_f32_actor_pass.json
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --integrator rk4_fd 2>/dev/null | tail -1 > $O/${TAG}_bench_rk4_fd.json
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --two-layer 2>/dev/null | tail -1 > $O/${TAG}_bench_two_layer.json
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --replay 2>/dev/null | tail -1 > $O/${TAG}_bench_replay.json
+  python bench.py --steps 100 --warmup 10 --no-cpu-baseline --nx 1024 2>/dev/null | tail -1 > $O/${TAG}_bench_c3_shard.json
+  PDEC_BENCH_BACKEND=gloo python bench.py --steps 100 --warmup 10 --no-cpu-baseline --gpus 2 2>/dev/null | tail -1 > $O/${TAG}_bench_n2_gloo_one_gpu.json
+  python tools/bench_rollout.py > $O/${TAG}_bench_rollout.jsonl 2>/dev/null
+fi
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "c4" ]; then
+  prof c4_ C4 --config C4 --steps 10 --warmup 2
+  python bench.py --config C4 2>/dev/null | tail -1 > $O/${TAG}_c4_bench.json
+  PDEC_BENCH_BACKEND=gloo python bench.py --config C4 --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_c4_bench_n2_gloo_one_gpu.json
+fi
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "c5" ]; then
+  prof c5_ C5 --config C5 --steps 1 --warmup 1
+  python bench.py --config C5 2>/dev/null | tail -1 > $O/${TAG}_c5_bench.json
+  PDEC_BENCH_BACKEND=gloo python bench.py --config C5 --gpus 2 --batch 4 --nx 128 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_c5_bench_n2_gloo_one_gpu_128.json
+fi
 ls -la $O | grep ${TAG}_ | awk '{print $5, $9}'
