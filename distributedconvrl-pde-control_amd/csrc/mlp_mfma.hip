@@ -41,7 +41,8 @@ struct FNet {
   int nsmall, nbig;   // padded block sizes (floats, multiples of 256)
   int oS2, oS2T;      // bf16-split blocks of W2 / W2^T (HP = 144 only, else -1), see SPLIT below
 };
-// ---- bf16-split operand format of the 144-wide hidden layer (SPLIT form of the actor pass).  The f32-input MFMA runs at the
+// ---- bf16-split operand format of the 144-wide hidden layer (SPLIT forms of the passes: experimental, PDEC_SPLIT, off by
+// default -- see split_on()).  The f32-input MFMA runs at the
 // f32 VECTOR rate; v_mfma_f32_16x16x32_bf16 at 16x that.  W = Whi + Wmid (two bf16 images: 16 mantissa bits of every
 // weight), an activation X = Xhi + Xmid + Xlo (three bf16 splits made in registers: all 24 bits), and
 //     W X ~ Whi Xlo + Wmid Xmid + Wmid Xhi + Whi Xmid + Whi Xhi          (f32 accumulation)
@@ -368,16 +369,20 @@ __device__ __forceinline__ float block_sum_lds(float v, float* red, int tid) {
 // (dma_even) -- round 2 loaded the small blocks through registers, 3.5 k cycles per load_small with nothing to overlap --
 // and the behaviour critic's small block is copied during the target phase into its own region, so the phase switch is one
 // barrier + the issue of the next big copy.  Copies are waited for in issue order with literal vmcnt counts.
-// (The bf16-split operand format of the actor pass was built and measured for this pass too -- 61 -> 47 us alone -- and
-// taken out again: DESIGN.md §3.2.)
-template <int MT, int MTA>
-__global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g) {
+// SPLIT (HP = 144): the two FORWARD 144 x 144 products (target critic, behaviour critic) run on bf16-split operands
+// (layer_split, see the image layout); W2^T dz2 and the weight-gradient products stay exact f32.  (The form with W2^T dz2 split
+// as well was built, measured -- 61 -> 47 us alone -- and taken out: DESIGN.md §3.2a.  This form keeps the tail of the pass,
+// dz1 onwards, instruction for instruction what the exact-f32 pass runs.)  224 VGPRs: see the actor pass.
+template <int MT, int MTA, bool SPLIT = false>
+__global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) void ddpg_critic_fused_kernel(FusedArgs g) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
   constexpr int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD, NW = FTHREADS / 64;
+  static_assert(!SPLIT || HP == SPL_HP, "the split form is built for the 144-wide layer");
   constexpr int NS = small_floats(HP), NSa = small_floats(HPa), NB = big_floats(HP), NBa = big_floats(HPa);
+  constexpr int NBF = SPLIT ? split_floats() : NB;      // size of a forward image ([hi | mid] pair or padded f32)
   float* Wreg = smem;                                   // [HP][LDW] big weight image / staging images
-  float* sc = Wreg + wreg_floats(MT, MTA);       // target critic's small block
+  float* sc = Wreg + wreg_floats(MT, MTA, SPLIT);       // target critic's small block
   float* sc2 = sc + NS;                                 // behaviour critic's small block
   float* sa = sc2 + NS;                                 // target actor's small block
   float* saW2 = sa + NSa;                               // target actor's W2 [HPa][LDWa]
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]),
                "+v"(rv), "+v"(tv), "+v"(rsum), "+v"(rbar_in));
   dma_wait();                                             // (the small copies; nothing else is outstanding)
-  dma_even<NB, NW>(Wreg, g.Ct.w + g.Ct.oW2, w, l);
+  dma_even<NBF, NW>(Wreg, g.Ct.w + (SPLIT ? g.Ct.oS2 : g.Ct.oW2), w, l);
   dma_even<NS, NW>(sc2, g.C.w, w, l);
   constexpr int N_SC = dma_count<NS, NW>();
   float rbar = block_sum_lds(rsum, red, tid) / (float)g.Bu;   // raw barriers inside (small blocks visible afterwards)
@@ -459,9 +464,17 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
       if (4 * t + q == ns) x[t] = valid ? an : 0.f;
     f32x4 h1[MT], h2[MT];
     layer_in<MT, 4>(h1, x, SCt, lr, q);
-    dma_wait_but<N_SC>();                                 // the target critic's W2 has landed
-    lds_barrier();
-    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SCt.b2, lr, q);
+    if constexpr (SPLIT) {
+      SplitB sb;
+      split_tiles<MT>(sb, h1);
+      dma_wait_but<N_SC>();                               // the target critic's W2 has landed
+      lds_barrier();
+      layer_split<MT, true>(h2, sb, Wreg, SCt.b2, lr, q);
+    } else {
+      dma_wait_but<N_SC>();                               // the target critic's W2 has landed
+      lds_barrier();
+      layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SCt.b2, lr, q);
+    }
     relu_<MT>(h2);
     const float qt = head<MT>(h2, SCt.w3, SCt.b3[0], q);
     tgt = g.gamma * (1.f - tv) * qt;
@@ -470,15 +483,23 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   lds_barrier();                                        // every wave is done with Wreg; sc2 visible
   STAMP(2);
   // ---- phase Q: behaviour critic forward; its W2 lands behind layer 1
-  dma_even<NB, NW>(Wreg, g.C.w + g.C.oW2, w, l);
+  dma_even<NBF, NW>(Wreg, g.C.w + (SPLIT ? g.C.oS2 : g.C.oW2), w, l);
   STAMP(3);
 #pragma unroll
   for (int t = 0; t < 4; ++t) x[t] = xq[t];
   f32x4 h1[MT], h2[MT];
   layer_in<MT, 4>(h1, x, SC, lr, q);
-  dma_wait();
-  lds_barrier();
-  layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
+  if constexpr (SPLIT) {
+    SplitB sb;
+    split_tiles<MT>(sb, h1);
+    dma_wait();
+    lds_barrier();
+    layer_split<MT, true>(h2, sb, Wreg, SC.b2, lr, q);
+  } else {
+    dma_wait();
+    lds_barrier();
+    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
+  }
   relu_<MT>(h2);
   const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
   const float c = valid ? tgt - qv : 0.f;
@@ -553,7 +574,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg_critic_fused_kernel(FusedArgs g
   STAMP(7);
   {
     constexpr int LDP128 = 136;                 // 8 mod 16 floats, like LDP: conflict-free ds_read_b128 operand reads
-    static_assert(16 * MT * LDP128 + 16 * LDP128 <= wreg_floats(MT, MTA), "pass C images do not fit the big LDS region");
+    static_assert(16 * MT * LDP128 + 16 * LDP128 <= wreg_floats(MT, MTA, SPLIT), "pass C images do not fit the big LDS region");
     float* Lc = Wreg;
     float* Rc = Wreg + HP * LDP128;
     const int cw128 = w * 16 + lr;
@@ -824,6 +845,11 @@ __device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float g
     g.pt[i] = tn;
     if (g.fwt) {
       g.fwt[o1] = tn; if (o2 >= 0) g.fwt[o2] = tn;
+      if (spl) {                                 // the target critic's forward image (critic pass, split form)
+        const __bf16 hi = (__bf16)tn, mid = (__bf16)(tn - (float)hi);
+        __bf16* b2 = reinterpret_cast<__bf16*>(g.fwt + g.lay.oS2);
+        b2[e1] = hi; b2[SPL_HP * SPL_RS + e1] = mid;
+      }
     }
   }
 }
@@ -1190,15 +1216,23 @@ static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
   return PDEC_OK;
 }
 
-// bf16-split operands for the 144-wide layers of the ACTOR pass (see SPLIT at the image layout)
-static bool split_on() {                   // default on; PDEC_SPLIT=0 selects the exact-f32 form of the actor pass (A/B runs, tests)
+// bf16-split operands for the 144-wide layers (see SPLIT at the image layout): an EXPERIMENT, off by default.
+// PDEC_SPLIT: 0 = exact f32 everywhere (default), a = actor pass, c = the two forward products of the critic pass, 1 = both.
+// Alone the split passes are bit-stable and faster (actor 31 -> 22 us, critic 60 -> 51 us).  In the two-stream training
+// pipeline, though, a PDE-step wave that shares a CU with a pass issuing v_mfma_f32_16x16x32_bf16 returned wrong fields in a
+// few per cent of 30-step runs (never with the exact-f32 passes, never with the streams on disjoint CU masks, never with the
+// same products issued as two v_mfma_f32_16x16x16_bf16 -- tools/det_probe5.py): TrainPipeline refuses the
+// split forms unless it runs serially.  which: 1 critic pass, 2 actor pass.
+#define PDEC_SPLIT_DEFAULT '0'
+static bool split_on(int which) {
   const char* e = getenv("PDEC_SPLIT");
-  return !(e && e[0] == '0');
+  const char c = (e && e[0]) ? e[0] : PDEC_SPLIT_DEFAULT;
+  return c == '1' || (which == 1 && c == 'c') || (which == 2 && c == 'a');
 }
-template <int MT, int MTA>
-static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
-  const size_t lds = lds_bytes<MT, MTA>(false);
-  auto kern = ddpg_critic_fused_kernel<MT, MTA>;
+template <int MT, int MTA, bool SPLIT>
+static int launch_critic_v(Mlp* C, const FusedArgs& g, int grid) {
+  const size_t lds = lds_bytes<MT, MTA>(false, SPLIT);
+  auto kern = ddpg_critic_fused_kernel<MT, MTA, SPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1226,6 +1260,13 @@ static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
   if (want_stamps) return dump_stamps(C, ga.stamps, grid);
   return PDEC_OK;
 }
+template <int MT, int MTA>
+static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
+  if constexpr (16 * MT == SPL_HP) {
+    if (split_on(1)) return launch_critic_v<MT, MTA, true>(C, g, grid);
+  }
+  return launch_critic_v<MT, MTA, false>(C, g, grid);
+}
 template <int MT, int MTA, bool SPLIT>
 static int launch_actor_v(Mlp* C, const FusedArgs& g, int grid) {
   const size_t lds = lds_bytes<MT, MTA>(true, SPLIT);
@@ -1249,7 +1290,7 @@ static int launch_actor_v(Mlp* C, const FusedArgs& g, int grid) {
 template <int MT, int MTA>
 static int launch_actor(Mlp* C, const FusedArgs& g, int grid) {
   if constexpr (16 * MT == SPL_HP) {
-    if (split_on()) return launch_actor_v<MT, MTA, true>(C, g, grid);
+    if (split_on(2)) return launch_actor_v<MT, MTA, true>(C, g, grid);
   }
   return launch_actor_v<MT, MTA, false>(C, g, grid);
 }

@@ -294,21 +294,22 @@ def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop, 
     assert abs(bp[0] - 0.9 ** (loops + 1)) <= 1e-12
 
 
+@pytest.mark.parametrize("split", ["a", "c", "1"])
 @pytest.mark.parametrize("quirk", [1, 0])
 @pytest.mark.parametrize("Bu", [4096, 77])
-def test_ddpg_update_with_the_exact_f32_actor_pass_matches_oracle(pkg, monkeypatch, quirk, Bu):
-    """The actor pass runs its two 144 x 144 products (critic forward, W2^T dz2) on v_mfma_f32_16x16x32_bf16 with W2 as a bf16 pair
-    and the activation as three bf16 splits, five products accumulated in f32 (csrc/mlp_mfma.hip, SPLIT; default) -- that is
-    what test_ddpg_update_matches_oracle checks.  PDEC_SPLIT=0 selects the exact-f32 MFMA form of the pass: same oracle, same
-    tolerance (src/PDEagent.jl:363-418, 2e-4 relative on losses and all four networks after one and two updates)."""
-    monkeypatch.setenv("PDEC_SPLIT", "0")
+def test_ddpg_update_with_bf16_split_passes_matches_oracle(pkg, monkeypatch, quirk, Bu, split):
+    """EXPERIMENTAL forms of the fused passes (PDEC_SPLIT, off by default; csrc/mlp_mfma.hip SPLIT): the 144 x 144 products on
+    v_mfma_f32_16x16x32_bf16 with W2 as a bf16 pair and the activation as three bf16 splits, five products accumulated in f32 --
+    a: both products of the actor pass, c: the two forward products of the critic pass, 1: both.  Same oracle, same tolerance
+    as the exact-f32 default (src/PDEagent.jl:363-418, 2e-4 relative on losses and all four networks after one and two updates)."""
+    monkeypatch.setenv("PDEC_SPLIT", split)
     test_ddpg_update_matches_oracle(pkg, quirk, "f32", Bu)
 
 
-def test_bf16_split_actor_gradient_tracks_the_exact_f32_form(pkg, monkeypatch):
-    """the actor gradient of one update (pdec_ddpg_actor_grads, flat buffer) with split operands against the exact-f32 MFMA form
-    on the same inputs: <= 2e-5 of the largest gradient entry (16 mantissa bits of the critic's W2 in the forward /
-    backward-to-input products, all 24 bits of the activations); the critic pass has one form only: bit-identical"""
+def test_bf16_split_gradients_track_the_exact_f32_form(pkg, monkeypatch):
+    """the gradients of one update (pdec_ddpg_critic_grads / pdec_ddpg_actor_grads, flat buffers) with split operands against the
+    exact-f32 MFMA form on the same inputs: <= 2e-5 of the largest gradient entry (16 mantissa bits of W2 in the split
+    products, all 24 bits of the activations); the pass a switch value does not name stays bit-identical"""
     import ctypes as C
     from oracle import nn
     rng = np.random.default_rng(5)
@@ -319,7 +320,7 @@ def test_bf16_split_actor_gradient_tracks_the_exact_f32_form(pkg, monkeypatch):
     a = to_dev(rng.uniform(-1, 1, (Bu, na)), torch.float32); r = to_dev(-rng.uniform(0, 1, Bu), torch.float32)
     t = to_dev((rng.uniform(0, 1, Bu) < 0.1).astype(np.float64), torch.float32)
     grads = {}
-    for split in ("0", "1"):
+    for split in ("0", "a", "c"):
         monkeypatch.setenv("PDEC_SPLIT", split)
         r2 = np.random.default_rng(9)
         A, _ = make_net(pkg, r2, da, aa, torch.float32, Bu)
@@ -334,56 +335,9 @@ def test_bf16_split_actor_gradient_tracks_the_exact_f32_form(pkg, monkeypatch):
         torch.cuda.synchronize()
         red = pkg.distributed.GradReducer()
         grads[split] = (red._view(Cn).cpu().numpy().copy(), red._view(A).cpu().numpy().copy(), L.cpu().numpy().copy())
-    assert np.array_equal(grads["0"][0], grads["1"][0])                 # critic pass: one form
-    g0, g1 = grads["0"][1], grads["1"][1]
-    assert np.isfinite(g1).all() and np.abs(g1 - g0).max() <= 2e-5 * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())
-    assert not np.array_equal(g0, g1)                                   # the switch really selected another kernel
-    assert np.abs(grads["1"][2] - grads["0"][2]).max() <= 1e-5 * max(1.0, np.abs(grads["0"][2]).max())
-
-
-def test_pde_step_beside_the_split_actor_pass_is_bit_stable(pkg):
-    """The fused KS step in its SIMD-sharing form (64 VGPRs) shares SIMDs with the 224-VGPR passes in the training pipeline.  On
-    FIXED inputs, repeated on its own stream while the other stream runs the bf16-split actor pass back to back, every
-    repetition must return the same bits as the step alone.  (The split form of the CRITIC pass failed exactly this check --
-    one workgroup of the step slightly wrong every few launches, inputs bit-identical -- and was taken out: DESIGN.md §3.2,
-    tools/corun_probe.py.)"""
-    import ctypes as C
-    B = 512
-    setup = pkg.KSSetup.bench_C2(256)
-    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
-    y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
-    env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
-    assert env.set_simd_sharing(True)
-    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
-                             noise_seed=7, trajectory_length=1)
-    pol = agent.policy
-    A, Cn = pol.behavior_actor.model, pol.behavior_critic.model
-    cols = B * 64
-    g = torch.Generator(device="cuda").manual_seed(3)
-    s = torch.randn(cols, 3, device="cuda", generator=g)
-    act = torch.rand(env._ashape, device="cuda", generator=g) * 2 - 1
-    actp = torch.zeros_like(act)
-    y_in, st_in = env.y.clone(), env.state.clone()
-    out, ref = torch.empty_like(y_in), torch.empty_like(y_in)
-    p_out, st_out = torch.empty(env._pshape, device="cuda"), torch.empty_like(st_in)
-    rew, flags = torch.empty((B, 64), device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda")
-    Lz = torch.zeros(2, device="cuda")
-    P = pkg._lib.ptr
-    torch.cuda.synchronize()
-
-    def step(o):
-        with torch.cuda.stream(s_env):
-            pkg._lib.check(env.lib.pdec_env_step(env.handle, P(y_in), P(act), P(actp), P(st_in), P(o), P(p_out), P(st_out), P(rew), P(flags)))
-
-    step(ref)
-    torch.cuda.synchronize()
-    bad = 0
-    for it in range(800):
-        with torch.cuda.stream(s_upd):
-            pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, P(s), cols, 1.0, C.c_void_p(Lz.data_ptr() + 4)))
-        step(out)
-        if it % 8 == 7:
-            torch.cuda.synchronize()
-            bad += int(not torch.equal(out, ref))
-    env.set_simd_sharing(False)
-    assert bad == 0, f"{bad} of 100 checked repetitions of the step differ from the step alone"
+    for split, other, mine in (("a", 0, 1), ("c", 1, 0)):
+        assert np.array_equal(grads["0"][other], grads[split][other])       # the pass the switch does not name: same kernel
+        g0, g1 = grads["0"][mine], grads[split][mine]
+        assert np.isfinite(g1).all() and np.abs(g1 - g0).max() <= 2e-5 * np.abs(g0).max(), (split, np.abs(g1 - g0).max(), np.abs(g0).max())
+        assert not np.array_equal(g0, g1)                                   # the switch really selected another kernel
+        assert np.abs(grads[split][2] - grads["0"][2]).max() <= 1e-5 * max(1.0, np.abs(grads["0"][2]).max())

@@ -235,3 +235,59 @@ def test_round3_finish_kernel_is_bit_identical_to_the_round2_one(pkg, monkeypatc
     for n in ("behavior_actor", "behavior_critic"):
         sa, sb = pkg.checkpoint._adam_state(getattr(pa.policy, n).model), pkg.checkpoint._adam_state(getattr(pb.policy, n).model)
         assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), n
+
+
+def _snapshot(p):
+    red = p.pkg_distributed.GradReducer()
+    out = [p.y.clone(), red._view(p.policy.behavior_critic.model).clone(), red._view(p.policy.behavior_actor.model).clone()]
+    out += [x.clone() for x in p.aring] + [x.clone() for x in p.rring]
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        out += [torch.as_tensor(x.copy()) for x in getattr(p.policy, n).model.params()]
+    return out
+
+
+@pytest.mark.parametrize("n", [3, 7, 12, 19, 26, 41])
+def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
+    """Two pipelines with the same seeds that differ only in TIMING must agree bit for bit: one issues its n control steps in
+    one call (two streams, env step kicked behind the critic half, recorded-call replay), one is drained after every step, one
+    reduces with the slower round-2 finish kernel.  Fields, action / reward rings, both flat gradient buffers and all four
+    networks.  (This is the check the experimental bf16-split passes FAILED beside the PDE step -- a few per cent of such runs,
+    one step wave wrong, tools/det_probe5.py -- which is why they are off by default and refused by a two-stream pipeline.)"""
+    monkeypatch.delenv("PDEC_SPLIT", raising=False)
+    runs = []
+    for mode in ("free", "drained", "finish_ref"):
+        if mode == "finish_ref":
+            monkeypatch.setenv("PDEC_FINISH_REF", "1")
+        p = _make(pkg, False, B=64, E=23)
+        p.pkg_distributed = pkg.distributed
+        if mode == "drained":
+            for _ in range(n):
+                p.run(1); torch.cuda.synchronize()
+        else:
+            p.run(n)
+        p.sync()
+        runs.append(_snapshot(p))
+        p.close()
+        monkeypatch.delenv("PDEC_FINISH_REF", raising=False)
+    for other in runs[1:]:
+        assert len(other) == len(runs[0]) and all(torch.equal(x, y) for x, y in zip(runs[0], other))
+
+
+def test_two_stream_pipeline_refuses_the_bf16_split_passes(pkg, monkeypatch):
+    """PDEC_SPLIT=a|c|1 selects the experimental bf16-split forms of the fused passes; beside the PDE step they are not
+    bit-stable, so a two-stream TrainPipeline raises instead of training on silently wrong fields; on one
+    stream (nothing runs beside the passes) it is accepted."""
+    monkeypatch.setenv("PDEC_SPLIT", "a")
+    with pytest.raises(pkg.PdecError, match="PDEC_SPLIT"):
+        _make(pkg, False, B=8, E=11)
+    setup = pkg.KSSetup.bench_C2(256)
+    st = torch.cuda.Stream()
+    y0 = setup.generate_random_init(np.random.default_rng(0), 8) * 0.15
+    env = pkg.PDEenv(setup, B=8, dtype=torch.float32, y0=y0, stream=st, autoreset=False)
+    agent = pkg.create_agent(setup=setup, B=8, rng=np.random.default_rng(1), dtype=torch.float32, stream=st, start_steps=-1,
+                             noise_seed=7, trajectory_length=1)
+    p = pkg.TrainPipeline(env, agent, lag=2, episode_steps=11, stream_env=st, stream_upd=st, use_graphs=False, noise_seed=99)
+    assert p.serial
+    p.run(6); p.sync()
+    assert bool(torch.isfinite(p.y).all())
+    p.close()

@@ -5,9 +5,23 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("distributedconvrl-pde-control_amd")
 
+def masked_streams():
+    """two streams on DISJOINT halves of the CUs (hipExtStreamCreateWithCUMask): kernels of the env stream and of the update
+    stream then never share a CU"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    out = []
+    for half in (0, 1):
+        mask = (C.c_uint32 * 8)(*([0xFFFFFFFF] * 4 + [0] * 4 if half == 0 else [0] * 4 + [0xFFFFFFFF] * 4))
+        st = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask)
+        assert rc == 0, rc
+        out.append(torch.cuda.ExternalStream(st.value))
+    return out
+
 def make(use_graphs, B=64, E=17):
     setup = pkg.KSSetup.bench_C2(256)
-    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+    s_env, s_upd = masked_streams() if os.environ.get("CUMASK") == "1" else (torch.cuda.Stream(), torch.cuda.Stream())
     y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
     env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
     agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
