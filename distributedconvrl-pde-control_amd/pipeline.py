@@ -157,10 +157,13 @@ class TrainPipeline:
         # (N > 1: the launch that applies the update after the all-reduce carries the event, pdec_adam_polyak_step)
         self.stop_events = (self.rpart is not None and Ev is _Event and not self.serial
                             and os.environ.get("PDEC_STOP_EVENTS", "1") != "0")
-        # two streams + the fused 3-layer passes: ask for the PDE step's 64-VGPR form, whose waves can share a SIMD with the
-        # 222-VGPR critic pass instead of excluding it per CU (csrc/env.hip, SHARE); PDEC_SHARE=0: the register form
+        # The PDE step beside the fused 3-layer passes.  Round 2: its register form (92 VGPRs) could not share a SIMD with two
+        # waves of the 222-VGPR critic pass, so the pipeline asked for the 64-VGPR form (csrc/env.hip, SHARE) at priority 3.
+        # Round 3: the passes are bounded to 208 allocated VGPRs (2 x 208 + 96 = 512), the register form fits beside them, and
+        # at its own priority 1 it takes less from the passes: 117.7 -> 111.4 us per control step (r03bc).  PDEC_SHARE=1 asks for
+        # the 64-VGPR form again.
         self.simd_sharing = False
-        if not self.serial and self.rpart is not None and os.environ.get("PDEC_SHARE", "1") != "0":
+        if not self.serial and self.rpart is not None and os.environ.get("PDEC_SHARE", "0") == "1":
             eff = C.c_int()
             _lib.check(self.lib.pdec_env_set_simd_sharing(env.handle, 1, C.byref(eff)))
             self.simd_sharing = bool(eff.value)

@@ -174,15 +174,17 @@ def test_checkpoint_keeps_the_device_noise_counter(pkg, tmp_path):
     _same_networks(pa, pb)
 
 
-def test_full_size_c2_pipeline_properties(pkg, monkeypatch):
+@pytest.mark.parametrize("share", [False, True])
+def test_full_size_c2_pipeline_properties(pkg, monkeypatch, share):
     """the exact instance the headline times -- config C2 at FULL size (KS N = 256, B = 512, fp32,
-    3-layer nets, 32 768 update columns, two streams, LAG 2, SIMD-sharing form of the fused step beside the critic pass) --
+    3-layer nets, 32 768 update columns, two streams, LAG 2, register form (default) / SIMD-sharing form of the fused step) --
     through TrainPipeline for 64 control steps including one episode reset (E = 51): every field / network finite, the
     HIP-graph replay bit-identical to the eager issue, and the SIMD-sharing form tracking the register form (same
     arithmetic and order: <= 2e-6 per step on y, checked teacher-forced on the step kernel itself at B = 512)."""
+    monkeypatch.setenv("PDEC_SHARE", "1" if share else "0")      # share: the 64-VGPR form of the step (round-2 default)
     pe = _make(pkg, False, B=512, E=51, chunks=(24, 6, 1))
     pg = _make(pkg, True, B=512, E=51, chunks=(24, 6, 1))
-    assert pe.simd_sharing and pe.rpart is not None and pe.stop_events and pe.kick_env_after_critic
+    assert pe.simd_sharing == share and pe.rpart is not None and pe.stop_events and pe.kick_env_after_critic
     pg.run(5); pg.capture()
     pe.run(pg.tick)
     n = 64 - pg.tick % 64 + 64
@@ -203,14 +205,14 @@ def test_full_size_c2_pipeline_properties(pkg, monkeypatch):
     pe.sync()
     y_in, act = pe.y.clone(), pe.aring[(pe.tick - 1) % 3].clone()
     outs = []
-    for share in (True, False):
-        env.set_simd_sharing(share)
+    for form in (True, False):
+        env.set_simd_sharing(form)
         with torch.cuda.stream(pe.s_env):
             env.y.copy_(y_in)
             env(act.clone())
         pe.sync()
         outs.append(env.y.clone())
-    env.set_simd_sharing(True)
+    env.set_simd_sharing(share)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * max(1.0, float(outs[1].abs().max()))
     pg.close(); pe.close()
 
