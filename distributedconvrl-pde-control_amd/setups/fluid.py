@@ -190,6 +190,23 @@ class FluidSetup:
         """FluidSetup.jl:386-394: ic(4) in evaluation, ic(3) in training; batched -> complex [B, ny, nx]"""
         return np.stack([self.ic(4 if self.evaluation else 3, rng) for _ in range(B)])
 
+    def error_detection(self, y):
+        """scripts/Fluid/setup/FluidSetup.jl:263-273, handed to PDEhook (FluidSetup.jl:373-377; src/PDEhook.jl:78-82): an episode
+        that ended early counts as errored when neighbouring cells of real(ifft(y)) differ by more than 10 along either axis.
+        `y`: the spectral field of the env, [ny, nx] or a batch [B, ny, nx] (device tensor or array); batched: any trajectory."""
+        import torch
+        yt = torch.as_tensor(y)
+        w = torch.fft.ifft2(yt, dim=(-2, -1)).real
+        y_x = (torch.roll(w, 1, dims=-2) - w).abs()
+        y_y = (torch.roll(w, 1, dims=-1) - w).abs()
+        return bool(max(float(y_x.max()), float(y_y.max())) > 10.0)
+
+    def make_hook(self, **kw):
+        """the training hook of the fluid script (FluidSetup.jl:373-377): PDEhook with this setup's error_detection"""
+        from ..hook import PDEhook
+        kw.setdefault("error_detection", self.error_detection)
+        return PDEhook(**kw)
+
     def env_cfg(self, B, dtype_code):
         c = _lib.EnvCfg()
         c.pde_kind, c.dtype, c.B, c.N, c.n_species = _lib.PDE_FLUID_RK4, dtype_code, B, self.nx, 1

@@ -162,6 +162,15 @@ def reward_function(cfg, yhat, action, delta_action):
     return -np.abs(sensors) - cfg.action_punish * a ** 2 - cfg.delta_action_punish * da ** 2
 
 
+def error_detection(yhat):
+    """scripts/Fluid/setup/FluidSetup.jl:263-273: the episode counts as errored when neighbouring cells of the vorticity field
+    (real(ifft(y))) differ by more than 10 along either axis (periodic neighbours, circshift)"""
+    y = np.real(np.fft.ifft2(np.asarray(yhat)))
+    y_x = np.abs(np.roll(y, 1, axis=0) - y)
+    y_y = np.abs(np.roll(y, 1, axis=1) - y)
+    return bool(y_x.max() > 10.0 or y_y.max() > 10.0)
+
+
 def featurize(cfg, yhat, prev_state=None):
     """scripts/Fluid/setup/FluidSetup.jl:204-245 (memory_size=0).  temporal_steps > 1 (:229-237; 1 in the shipped scripts):
     prev_state=None is the `isnothing(env)` branch (fresh rows repeated), otherwise the fresh rows are stacked on the newest

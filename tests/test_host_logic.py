@@ -316,3 +316,42 @@ def test_graph_capture_phase_reachability(pkg):
     assert phases(51, 24) == list(range(6)) and phases(17, 6) == list(range(6))
     assert phases(26, 24) == [1, 3, 5] and phases(27, 24) == [1, 2, 4, 5] and phases(30, 24) == [1, 2, 3, 4, 5]
     assert phases(26, 6) == list(range(6)) and phases(0, 24) == list(range(6))
+
+
+def test_fluid_error_detection_matches_the_restated_reference(pkg):
+    """scripts/Fluid/setup/FluidSetup.jl:263-273 (-> src/PDEhook.jl:78-82): neighbouring cells of real(ifft(y)) more than 10
+    apart along either axis.  FluidSetup.error_detection (torch, single field or batch) against oracle.fluid.error_detection
+    on smooth fields, on a field with one 10.5 jump along each axis, and just below the threshold; make_hook hands it to
+    PDEhook and the hook files the episode as errored only when it ended early."""
+    import torch
+    from oracle import fluid as ofl
+    setup = pkg.FluidSetup.Fluid_8(nx=32)
+    rng = np.random.default_rng(3)
+    smooth = np.fft.fft2(rng.standard_normal((32, 32)))
+    cases = []
+    for axis, amp in ((0, 10.5), (1, 10.5), (0, 9.9), (1, 9.9)):
+        w = np.zeros((32, 32))
+        idx = [slice(None), slice(None)]
+        idx[axis] = slice(5, 6)
+        w[tuple(idx)] = amp
+        cases.append((np.fft.fft2(w), amp > 10.0))
+    cases.append((smooth, ofl.error_detection(smooth)))
+    for yhat, want in cases:
+        assert ofl.error_detection(yhat) == want
+        assert setup.error_detection(yhat) == want
+        assert setup.error_detection(torch.as_tensor(yhat)) == want
+    batch = np.stack([cases[2][0], cases[0][0], cases[3][0]])          # one errored trajectory in the batch
+    assert setup.error_detection(batch) and not setup.error_detection(batch[[0, 2]])
+    hook = setup.make_hook(collect_NNA=False, collect_bestDF=False)
+    assert hook.error_detection(cases[0][0]) and not hook.error_detection(cases[2][0])
+
+    class _Env:                       # the fields PDEhook reads at POST_EPISODE_STAGE (src/PDEhook.jl:65-97)
+        te, steps = 6.0, 3
+    class _Agent:
+        class policy:
+            behavior_actor = None
+    for t, y, errored in ((2.0, cases[0][0], True), (6.0, cases[0][0], False), (2.0, cases[2][0], False)):
+        hook = setup.make_hook(collect_NNA=False, collect_bestDF=False)
+        env = _Env(); env.time, env.y = t, y
+        hook(pkg.POST_EPISODE_STAGE, _Agent(), env)
+        assert (hook.errored_episodes == [1]) == errored, (t, hook.errored_episodes)
