@@ -1464,6 +1464,151 @@ __global__ void kseg_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
   }
 }
 
+// ------------------------------------------------------------------ persistent Keller-Segel rollout (row F2)
+// T control steps of  action = clamp(actor(state) + randn * act_noise);  (env::PDEenv)(action)  in ONE launch for the 1-D
+// Keller-Segel environment (src/PDEagent.jl:175-209 + src/PDEenv.jl:195-241 with scripts/Keller-Segel/setup/KellerSegelSetup.jl:
+// 213-332): the fields u, v stay in registers (one cell per thread, one workgroup per trajectory), state / action / reward rows
+// in LDS, the actor (<= 3 Dense layers of <= RO_W units, 12 -> 20 -> 20 -> 1 in the shipped script) is evaluated in the kernel,
+// one thread per (actuator, unit), and the exploration noise is the same Philox stream element for element (column c = b A + a
+// of step t) as the acting kernel's, so the launch tracks the step-by-step loop to the actor's summation order.
+template <class T>
+__global__ void kseg_rollout_kernel(EnvDev<T> e, RollActor actor, RollArgs<T> g) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = e.N, tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x, A = e.A, ns = e.ns;
+  T* su = reinterpret_cast<T*>(smem_raw);  // [N+2]
+  T* sv = su + N + 2;                      // [N+2]
+  T* act = sv + N + 2;                     // [A]
+  T* actp = act + A;                       // [A]
+  T* dots = actp + A;                      // [2][S]
+  T* part = dots + 2 * e.S;                // [8][2][S]
+  T* red = part + 16 * e.S;                // [16]
+  T* stl = red + 16;                       // [2][A * ns]  state of the trajectory, ping-pong (temporal_steps > 1 shifts the old rows)
+  T* stn = stl + A * ns;
+  T* rsum = stn + A * ns;                  // [A]       accumulated reward
+  T* rnow = rsum + A;                      // [A]       this step's reward
+  const size_t wl_off = (size_t)(reinterpret_cast<unsigned char*>(rnow + A) - smem_raw + 15) & ~(size_t)15;
+  T* wl = reinterpret_cast<T*>(smem_raw + wl_off);   // actor image, 16-byte aligned rows
+  T* hb = wl + ((ro_image_elems(actor.dims, actor.L) + 3) & ~3);   // [2][A][RO_W] activations of the actor, ping-pong
+  const int n = tid;
+  const bool live = n < N;
+  const size_t yo = (size_t)b * 2 * N, cols = (size_t)e.B * A;
+
+  ro_load_image<T>(actor, wl, tid, nt);
+  for (int i = tid; i < A * ns; i += nt) stl[i] = g.state[(size_t)b * A * ns + i];
+  for (int a = tid; a < A; a += nt) {
+    act[a] = g.action[(size_t)b * A + a];
+    rsum[a] = 0;
+  }
+  T u = live ? g.y[yo + 2 * n] : (T)0, v = live ? g.y[yo + 2 * n + 1] : (T)0;
+  int flag = 0, first = -1;
+  const T idx = (T)1 / e.dx, idx2 = (T)1 / (e.dx * e.dx), h = e.hstep;
+  __syncthreads();
+
+  for (int t = 0; t < g.steps; ++t) {
+    // ---- policy (src/PDEagent.jl:183-207): the A actuator columns share the weights (per-actuator agents); one thread per
+    // (actuator, output unit) and layer, k-ordered accumulation like the oracle's W * x + b
+    {
+      const T* in = stl;
+      int istride = ns, off = 0;
+      for (int l = 0; l < actor.L; ++l) {
+        const int din = actor.dims[l], dout = actor.dims[l + 1], fn = actor.acts[l];
+        T* out = hb + (size_t)(l & 1) * A * RO_W;
+        const T* Wt = wl + off;
+        for (int id = tid; id < A * dout; id += nt) {
+          const int a = id / dout, o = id - a * dout;
+          T acc = Wt[din * RO_W + o];
+          for (int k = 0; k < din; ++k) acc += Wt[k * RO_W + o] * in[a * istride + k];
+          out[a * RO_W + o] = ro_act_fn<T>(acc, fn);
+        }
+        __syncthreads();
+        in = out; istride = RO_W;
+        off += (din + 1) * RO_W;
+      }
+      for (int a = tid; a < A; a += nt) {
+        T o = in[a * RO_W];
+        if (g.learning) {
+          const uint64_t c = (uint64_t)b * A + a;                          // global column = element of the noise stream
+          const uint64_t ctr = g.offset + (uint64_t)t * ((cols + 3) / 4) + (c >> 2);
+          uint32_t ph[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+          philox4x32(ph, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+          const int hsel = (int)((c >> 1) & 1);                            // an even / odd pair of columns shares one Box-Muller pair
+          const double sc = 1.0 / 4294967296.0;
+          const double u1 = ((double)ph[2 * hsel] + 0.5) * sc, u2 = ((double)ph[2 * hsel + 1] + 0.5) * sc;
+          const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+          o += (T)((c & 1) ? rad * sin(ang) : rad * cos(ang)) * g.act_noise;
+        }
+        o = o < -g.act_limit ? -g.act_limit : (o > g.act_limit ? g.act_limit : o);
+        actp[a] = act[a];
+        act[a] = o;
+      }
+    }
+    __syncthreads();
+    if (g.log_action)
+      for (int a = tid; a < A; a += nt) g.log_action[((size_t)t * e.B + b) * A + a] = act[a];
+    // ---- prepare_action (KellerSegelSetup.jl:249-262), then the integrator of the step kernel (same order of operations)
+    T p = 0;
+    if (live) {
+      p = actuate_cell<T>(e, act, n);
+      if (g.log_p) g.log_p[((size_t)t * e.B + b) * N + n] = p;
+    }
+    for (int it = 0; it < e.K; ++it) {
+      T k1u = 0, k1v = 0, k2u = 0, k2v = 0, k3u = 0, k3v = 0, k4u = 0, k4v = 0;
+      kseg_rhs<T>(u, v, p, su, sv, n, N, idx, idx2, live, k1u, k1v);
+      if (e.rk2) {
+        kseg_rhs<T>(u + (T)0.5 * h * k1u, v + (T)0.5 * h * k1v, p, su, sv, n, N, idx, idx2, live, k2u, k2v);
+        u = u + h * k2u;
+        v = v + h * k2v;
+        continue;
+      }
+      kseg_rhs<T>(u + (T)0.5 * h * k1u, v + (T)0.5 * h * k1v, p, su, sv, n, N, idx, idx2, live, k2u, k2v);
+      kseg_rhs<T>(u + (T)0.5 * h * k2u, v + (T)0.5 * h * k2v, p, su, sv, n, N, idx, idx2, live, k3u, k3v);
+      kseg_rhs<T>(u + h * k3u, v + h * k3v, p, su, sv, n, N, idx, idx2, live, k4u, k4v);
+      u = u + h / (T)6 * (k1u + (T)2 * (k2u + k3u) + k4u);
+      v = v + h / (T)6 * (k1v + (T)2 * (k2v + k3v) + k4v);
+    }
+    if (live && g.log_y) {
+      g.log_y[((size_t)t * e.B + b) * 2 * N + 2 * n] = u;
+      g.log_y[((size_t)t * e.B + b) * 2 * N + 2 * n + 1] = v;
+    }
+    if (e.check_max == 1) {
+      T m = (live && !(fabs(u) <= e.max_value && fabs(v) <= e.max_value)) ? (T)1 : (T)0;
+      m = block_max<T>(m, red, tid, nt);
+      if (m > 0) { flag = 1; if (first < 0) first = t; }
+    }
+    // ---- reward and featurize from the sensor dots of the new fields
+    __syncthreads();
+    if (live) {
+      su[n] = u;
+      sv[n] = v;
+    }
+    __syncthreads();
+    sense_dots<T>(e, [&](int r, int nn) { return r == 0 ? su[nn] : sv[nn]; }, dots, part, tid, nt);
+    reward_traj<T>(e, dots, act, actp, rnow, tid, nt);
+    featurize_traj<T>(e, dots, stl, stn, tid, nt);       // new rows on top, the previous state's rows shifted down (temporal stack)
+    { T* sw = stl; stl = stn; stn = sw; }
+    __syncthreads();
+    for (int a = tid; a < A; a += nt) {
+      rsum[a] += rnow[a];
+      if (g.log_reward) g.log_reward[((size_t)t * e.B + b) * A + a] = rnow[a];
+    }
+    __syncthreads();
+  }
+  // ---- results back to HBM
+  if (live) {
+    g.y[yo + 2 * n] = u;
+    g.y[yo + 2 * n + 1] = v;
+  }
+  for (int i = tid; i < A * ns; i += nt) g.state[(size_t)b * A * ns + i] = stl[i];
+  for (int a = tid; a < A; a += nt) {
+    g.action[(size_t)b * A + a] = act[a];
+    if (g.reward_sum) g.reward_sum[(size_t)b * A + a] += rsum[a];
+  }
+  if (tid == 0) {
+    if (g.done_any) g.done_any[b] = flag;
+    if (g.done_step) g.done_step[b] = first;
+  }
+}
+
 // ------------------------------------------------------------------ KS, RK4 + periodic 5-point finite differences
 // The north-star variant u_t = -u u_x - u_xx - u_xxxx + p (+ the disturbance of KSSetup.jl:155) on the stencil table
 // the reference defines but never uses (scripts/KS/setup/KSSetup.jl:55-59): d/dx = [0,-1/2,0,1/2,0]/dx,
@@ -1796,6 +1941,47 @@ int ks_rollout_persistent(Env& E, const Mlp& A, int T, void* y, void* state, voi
   RollArgs<float> g{T, learning, (float)act_noise, (float)act_limit, seed, offset, (float*)y, (float*)state, (float*)action,
                     (float*)reward_sum, (float*)log_y, (float*)log_p, (float*)log_action, (float*)log_reward, done_any, done_step};
   return ks_rollout_launch<float>(E, A, g);
+}
+
+// Keller-Segel (1-D): the same service for kseg_rollout_kernel
+static size_t kseg_rollout_lds(const Env& E, const Mlp& A) {
+  const pdec_env_cfg& c = E.cfg;
+  return E.lds_bytes + ((size_t)2 * c.A * env_ns(c) + 2 * (size_t)c.A + ((ro_image_elems(A.dims.data(), A.L) + 3) & ~3) + (size_t)2 * c.A * RO_W) * dtype_size(c.dtype) + 16;
+}
+bool kseg_rollout_supported(const Env& E, const Mlp& A) {
+  const pdec_env_cfg& c = E.cfg;
+  const char* off = getenv("PDEC_ROLLOUT_PERSISTENT");
+  if (off && off[0] == '0') return false;
+  if (c.pde_kind != PDEC_PDE_KSEG_RK4 || c.mono || c.check_max_value == 2) return false;
+  if (A.L < 1 || A.L > 3 || A.dims[A.L] != 1 || A.dtype != c.dtype || A.dims[0] != env_ns(c)) return false;
+  for (int l = 0; l <= A.L; ++l)
+    if (A.dims[l] > RO_W) return false;
+  return kseg_rollout_lds(E, A) <= 64 * 1024;
+}
+template <class T>
+static int kseg_rollout_launch(Env& E, const Mlp& A, const RollArgs<T>& g) {
+  EnvDev<T> e = make_dev<T>(E);
+  RollActor ra{};
+  ra.params = A.params.p; ra.L = A.L; ra.nparams = A.nparams;
+  for (int l = 0; l <= A.L; ++l) { ra.dims[l] = A.dims[l]; ra.rows = std::max(ra.rows, A.dims[l]); }
+  for (int l = 0; l < A.L; ++l) ra.acts[l] = A.acts[l];
+  ProfScope ps(&E, "kseg_rollout");
+  hipLaunchKernelGGL((kseg_rollout_kernel<T>), dim3(E.cfg.B), dim3(E.nthreads), kseg_rollout_lds(E, A), E.stream, e, ra, g);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+int kseg_rollout_persistent(Env& E, const Mlp& A, int T, void* y, void* state, void* action, double act_noise, double act_limit,
+                            int learning, uint64_t seed, uint64_t offset, void* reward_sum, void* log_y, void* log_p,
+                            void* log_action, void* log_reward, int32_t* done_any, int32_t* done_step) {
+  if (!kseg_rollout_supported(E, A)) { set_error("kseg_rollout_persistent: configuration not covered"); return PDEC_E_INVALID; }
+  if (E.cfg.dtype == PDEC_F64) {
+    RollArgs<double> g{T, learning, act_noise, act_limit, seed, offset, (double*)y, (double*)state, (double*)action, (double*)reward_sum,
+                       (double*)log_y, (double*)log_p, (double*)log_action, (double*)log_reward, done_any, done_step};
+    return kseg_rollout_launch<double>(E, A, g);
+  }
+  RollArgs<float> g{T, learning, (float)act_noise, (float)act_limit, seed, offset, (float*)y, (float*)state, (float*)action,
+                    (float*)reward_sum, (float*)log_y, (float*)log_p, (float*)log_action, (float*)log_reward, done_any, done_step};
+  return kseg_rollout_launch<float>(E, A, g);
 }
 
 template <class T>

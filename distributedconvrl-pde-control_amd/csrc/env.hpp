@@ -50,6 +50,10 @@ struct Env : Object {
 // PDEC_E_INVALID without touching anything when the configuration is not covered (the caller then loops per step)
 struct Mlp;
 bool ks_rollout_supported(const Env& E, const Mlp& A);
+bool kseg_rollout_supported(const Env& E, const Mlp& A);
+int kseg_rollout_persistent(Env& E, const Mlp& A, int T, void* y, void* state, void* action, double act_noise, double act_limit,
+                            int learning, uint64_t seed, uint64_t offset, void* reward_sum, void* log_y, void* log_p,
+                            void* log_action, void* log_reward, int32_t* done_any, int32_t* done_step);
 int ks_rollout_persistent(Env& E, const Mlp& A, int T, void* y, void* state, void* action, double act_noise, double act_limit,
                           int learning, uint64_t seed, uint64_t offset, void* reward_sum, void* log_y, void* log_p,
                           void* log_action, void* log_reward, int32_t* done_any, int32_t* done_step);

@@ -1145,8 +1145,12 @@ bool fused_supported(const Mlp* A, const Mlp* C) {
   return (mt == 9 || mt == 2) && (mta == 2 || mta == 1);
 }
 
+static bool split_on(int which);
 static int ensure_prepped(Mlp* M) {
   const FNet f = make_fnet_layout(M->dims[0], M->dims[1]);
+  // the bf16-split blocks are refreshed by the finish kernel only while a split form is selected (PDEC_SPLIT); a net that was
+  // updated without them gets its whole image rebuilt from the parameters before the first split pass reads it
+  if (M->split_stale && (split_on(1) || split_on(2))) M->fw_dirty = true;
   const size_t bytes = (size_t)f.total * 4;
   if (M->fw.bytes < bytes) {
     PDEC_HIP(M->fw.alloc(bytes));
@@ -1163,6 +1167,7 @@ static int ensure_prepped(Mlp* M) {
     PDEC_HIP(hipMemcpyAsync(M->fw_pub[0].p, M->fw.p, bytes, hipMemcpyDeviceToDevice, M->stream));
     PDEC_HIP(hipMemcpyAsync(M->fw_pub[1].p, M->fw.p, bytes, hipMemcpyDeviceToDevice, M->stream));
     M->fw_dirty = false;
+    M->split_stale = false;
   }
   return PDEC_OK;
 }
@@ -1317,6 +1322,11 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
     g.fw = M->fw.as<float>();
     g.fwp = M->fw_pub[M->pub ^ 1].as<float>();       // written now, read by acting kernels enqueued after this launch
     g.lay = make_fnet_layout(M->dims[0], M->dims[1]);
+    if (g.lay.oS2 >= 0 && !(split_on(1) || split_on(2))) {     // exact-f32 passes (default): no bf16-split copies to keep current
+      g.lay.oS2 = g.lay.oS2T = -1;
+      M->split_stale = true;
+      if (Mt) Mt->split_stale = true;
+    }
     g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps;
     if (Mt) {
       g.pt = Mt->params.as<float>(); g.fwt = Mt->fw.as<float>();

@@ -50,6 +50,9 @@ extern "C" int pdec_rollout(pdec_handle henv, pdec_handle hactor, int T, void* y
     return ks_rollout_persistent(*E, *A, T, y, state, action, act_noise, act_limit, learning, seed, offset, reward_sum, log_y,
                                  log_p, log_action, log_reward, done_any, done_step);
   }
+  if (kseg_rollout_supported(*E, *A))     // 1-D Keller-Segel: likewise one launch (csrc/env.hip: kseg_rollout_kernel)
+    return kseg_rollout_persistent(*E, *A, T, y, state, action, act_noise, act_limit, learning, seed, offset, reward_sum, log_y,
+                                   log_p, log_action, log_reward, done_any, done_step);
   const size_t ny = (size_t)c.B * env_y_count(c) * ts, np = (size_t)c.B * env_p_count(c) * ts, nact = (size_t)c.B * c.A * ts;
   const size_t nst = (size_t)c.B * (c.mono ? c.S : (size_t)c.A * ns) * ts, nr = (size_t)c.B * (c.mono ? 1 : c.A) * ts;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };

@@ -341,3 +341,40 @@ def test_bf16_split_gradients_track_the_exact_f32_form(pkg, monkeypatch):
         assert np.isfinite(g1).all() and np.abs(g1 - g0).max() <= 2e-5 * np.abs(g0).max(), (split, np.abs(g1 - g0).max(), np.abs(g0).max())
         assert not np.array_equal(g0, g1)                                   # the switch really selected another kernel
         assert np.abs(grads[split][2] - grads["0"][2]).max() <= 1e-5 * max(1.0, np.abs(grads["0"][2]).max())
+
+
+def test_bf16_split_images_are_rebuilt_after_updates_without_them(pkg, monkeypatch):
+    """The finish kernel refreshes the bf16-split blocks of the weight images only while a split form is selected.  Networks that
+    took ten updates with the default exact-f32 passes and are then read by a split pass must first get their images rebuilt
+    from the parameters (csrc/mlp_mfma.hip: split_stale): the split actor gradient still tracks the exact one to 2e-5 of its
+    largest entry (stale images -- ten ADAM steps at 1e-3 behind -- would be off by per cents)."""
+    import ctypes as C
+    from oracle import nn
+    monkeypatch.setenv("PDEC_SPLIT", "0")
+    rng = np.random.default_rng(11)
+    ns, na, Bu = 3, 1, 4096
+    da, aa = nn.layer_sizes(ns, na, 1.6, True, False)
+    dc, ac = nn.layer_sizes(ns, na, 7.0, False, False)
+    s = to_dev(rng.standard_normal((Bu, ns)), torch.float32); sn = to_dev(rng.standard_normal((Bu, ns)), torch.float32)
+    a = to_dev(rng.uniform(-1, 1, (Bu, na)), torch.float32); r = to_dev(-rng.uniform(0, 1, Bu), torch.float32)
+    t = to_dev((rng.uniform(0, 1, Bu) < 0.1).astype(np.float64), torch.float32)
+    A, _ = make_net(pkg, rng, da, aa, torch.float32, Bu)
+    Cn, _ = make_net(pkg, rng, dc, ac, torch.float32, Bu)
+    At, _ = make_net(pkg, rng, da, aa, torch.float32, Bu)
+    Ct, _ = make_net(pkg, rng, dc, ac, torch.float32, Bu)
+    P = pkg._lib.ptr
+    al, cl = C.c_double(), C.c_double()
+    for _ in range(10):
+        pkg._lib.check(A.lib.pdec_ddpg_update(A.handle, Cn.handle, At.handle, Ct.handle, P(s), P(a), P(r), P(t), P(sn), Bu, 0.99, 0.995, 1,
+                                             1e-3, 1e-3, C.byref(al), C.byref(cl)))
+    L = torch.zeros(2, dtype=torch.float32, device="cuda:0")
+    red = pkg.distributed.GradReducer()
+    grads = {}
+    for split in ("0", "a", "0"):
+        monkeypatch.setenv("PDEC_SPLIT", split)
+        pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, P(s), Bu, 1.0, C.c_void_p(L.data_ptr() + 4)))
+        torch.cuda.synchronize()
+        grads.setdefault(split, []).append(red._view(A).cpu().numpy().copy())
+    g0, g1 = grads["0"][0], grads["a"][0]
+    assert np.array_equal(grads["0"][0], grads["0"][1])
+    assert not np.array_equal(g0, g1) and np.abs(g1 - g0).max() <= 2e-5 * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())
