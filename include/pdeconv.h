@@ -249,7 +249,9 @@ int pdec_adam_polyak_step(pdec_handle h, pdec_handle h_target, double eta, doubl
  * KS (CNAB2, per-actuator agents, temporal_steps = 1, actor of <= 3 Dense layers no wider than 32 with one output):
  * ONE persistent launch for all T steps -- a workgroup keeps its two trajectories in registers and their state / actions
  * in LDS between steps and evaluates the actor itself on the vector unit (k-ordered sums like the oracle; not the
- * summation order of the MFMA acting kernel, so fp32 actions agree with the per-step loop to ~1e-6, not bit for bit);
+ * summation order of the MFMA acting kernel, so fp32 actions agree with the per-step loop to ~1e-6, not bit for bit).
+ * 1-D Keller-Segel (per-actuator agents, any temporal_steps, same actor limits; scripts/Keller-Segel/setup/
+ * KellerSegelSetup.jl:213-332): likewise one launch, one workgroup per trajectory.
  * PDEC_ROLLOUT_PERSISTENT=0 selects the per-step form, which every other configuration uses (same kernels as the loop
  * pdec_policy_act_rng -> pdec_env_step, bit-identical to it). */
 int pdec_rollout(pdec_handle env, pdec_handle actor, int T, void* y, void* state, void* action,
