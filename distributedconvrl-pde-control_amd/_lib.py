@@ -130,10 +130,17 @@ class _Lib:
         self._rec = calls
 
     def note(self, fn, *args):
-        """run a NON-library call (e.g. a torch.distributed all-reduce between two library launches) and, while a
-        recording is active, keep it in the list at its place: the replay re-issues it with the same arguments"""
+        """run a call that must be re-EVALUATED at replay -- a non-library call (a torch.distributed all-reduce between two
+        library launches) or a host function whose library calls take step-dependent scalars (the replay pushes / the sample
+        of the device replay: ring positions, counters) -- and, while a recording is active, keep it in the list at its
+        place.  `fn` must return None (or 0)."""
         if self._rec is not None:
             self._rec.append((fn, args))
+            rec, self._rec = self._rec, None      # the library calls `fn` makes itself are part of `fn`, not of the list
+            try:
+                return fn(*args)
+            finally:
+                self._rec = rec
         return fn(*args)
 
 

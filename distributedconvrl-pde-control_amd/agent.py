@@ -117,13 +117,21 @@ class CircularArraySARTTrajectory:
             t = torch.ones(n) if timeout else (done_flags != 0).to(torch.float32).repeat_interleave(cols_per_traj)
             self.push_rt(r, t.to(r.device))
 
-    def sample_device(self, seed, offset, batch_size):
-        """pde_sample + pde_fetch! (src/PDEagent.jl:317-340) in one launch: indices from the Philox stream (seed, offset)"""
+    def sample_device(self, seed, offset, batch_size, reuse=False):
+        """pde_sample + pde_fetch! (src/PDEagent.jl:317-340) in one launch: indices from the Philox stream (seed, offset).
+        reuse: write into the batch buffers of the previous call of this size (the training pipeline consumes a batch before
+        it draws the next one; fixed pointers let it replay its recorded step)"""
         kw = dict(dtype=torch.float32, device=self.device)
         ns, na = self.state.shape[1], self.action.shape[1]
-        out = dict(state=torch.empty((batch_size, ns), **kw), action=torch.empty((batch_size, na), **kw),
-                   reward=torch.empty(batch_size, **kw), terminal=torch.empty(batch_size, **kw),
-                   next_state=torch.empty((batch_size, ns), **kw))
+        out = getattr(self, "_sample_out", {}).get(batch_size) if reuse else None
+        if out is None:
+            out = dict(state=torch.empty((batch_size, ns), **kw), action=torch.empty((batch_size, na), **kw),
+                       reward=torch.empty(batch_size, **kw), terminal=torch.empty(batch_size, **kw),
+                       next_state=torch.empty((batch_size, ns), **kw))
+            if reuse:
+                if not hasattr(self, "_sample_out"):
+                    self._sample_out = {}
+                self._sample_out[batch_size] = out
         _lib.check(self._lib.pdec_replay_sample(
             self._h, _lib.ptr(self.state), _lib.ptr(self.action), _lib.ptr(self.reward), _lib.ptr(self.terminal), ns, na,
             self.capacity, self.stride, len(self), self.n_rt, int(seed), int(offset), int(batch_size), _lib.ptr(out["state"]),

@@ -150,7 +150,10 @@ class TrainPipeline:
         self.act_in_place = not bool(yes.value)
         # start env_k behind the critic half of update_k instead of beside the critic pass (see _issue); for the
         # reference-shaped 2-layer nets the env branch is as long as the whole update, so it is not held back there
-        self.kick_env_after_critic = (not self.act_in_place) if kick_env_after_critic is None else bool(kick_env_after_critic)
+        # (device replay: the sample of update_{k+1} waits for the pushes behind env_k, so a step held back behind the critic
+        # half stalls the update stream -- 158.7 vs 129.1 us per step, r03cm -- and the step is enqueued at once there)
+        self.kick_env_after_critic = ((not self.act_in_place and not self.use_replay) if kick_env_after_critic is None
+                                      else bool(kick_env_after_critic))
         if os.environ.get("PDEC_KICK") in ("0", "1"):               # diagnostic override
             self.kick_env_after_critic = os.environ["PDEC_KICK"] == "1"
         # events attached to the reduction launches instead of recorded behind them (see _issue); PDEC_STOP_EVENTS=0: records
@@ -181,7 +184,9 @@ class TrainPipeline:
         # records / waits are torch calls it would not see, so it is off for that event type
         # N > 1: the gradient all-reduce is one more recorded call (a library call with NativeGradReducer, a noted torch call
         # with GradReducer -- _Lib.note), so the multi-rank pipeline issues its steps the same fast way
-        self.fast_eager = os.environ.get("PDEC_FAST_EAGER", "1") == "1" and Ev is _Event and self._batch_aliases
+        # (device replay: the batch is the trajectory's fixed fp32 sample buffers, handed through unchanged to fp32 nets)
+        aliases = (self.policy.behavior_critic.model.dtype == torch.float32) if self.use_replay else self._batch_aliases
+        self.fast_eager = os.environ.get("PDEC_FAST_EAGER", "1") == "1" and Ev is _Event and aliases
         self._key = None          # per-step scalars baked into _progs / the graphs (see _scalar_key)
         self._recapture = False
         self._captured = False
@@ -264,7 +269,8 @@ class TrainPipeline:
                 if self.pre_rbar and self.rpart is None:
                     L.check(lib.pdec_reward_mean(env.handle, L.ptr(rew), self.cols, L.ptr(self.rbar[k % 3])))
                 if self.use_replay:
-                    self._replay_push(k, s_in, act, rew, term, s_out, first, last)
+                    # a host function with step-dependent ring positions: re-evaluated, not replayed verbatim (_Lib.note)
+                    lib.note(self._replay_push, self.ev_push[k % 2], s_in, act, rew, term, s_out, first, last)
                 if not self.serial and self.LAG < 2:
                     # LAG = 1: update_{k+1} trains on the transition env_k is producing, so the event it waits on is
                     # recorded behind the whole env branch, not behind the acting kernel
@@ -276,16 +282,9 @@ class TrainPipeline:
         batch = None
         if j >= self._first_tick:
             if self.use_replay:
-                if not self.serial and k > 0:
-                    # the host counters the sample is drawn against already include env_{k-1}'s pushes: wait for them
-                    # (the update stream has otherwise only waited for act_{k-1}, which precedes them on the env stream)
-                    self.ev_push[(k - 1) % 2].wait(self.s_upd)
                 with torch.cuda.stream(self.s_upd):
-                    batch = self._replay_batch()
-                if batch is not None and not self.serial:
-                    # ... and env_k's pushes overwrite the oldest rows of a full ring: they wait for this sample
-                    self.ev_samp.record(self.s_upd)
-                    self._samp_pending = True
+                    lib.note(self._replay_sample, self.ev_push[(k - 1) % 2] if (not self.serial and k > 0) else None)
+                batch = self._batch_cur
             else:
                 batch = dict(state=self.sring[j % PERIOD].view(self.cols, self.ns), action=self.aring[j % 3].view(self.cols, self.na),
                              reward=self.rring[j % 3].view(self.cols), terminal=self.tring[j % 3].view(self.cols),
@@ -345,7 +344,7 @@ class TrainPipeline:
         return e % self.E == 0, e % self.E == self.E - 1
 
     # ------------------------------------------------------------------ device replay route (row F1)
-    def _replay_push(self, k, s_in, act, rew, term, s_out, first, last):
+    def _replay_push(self, ev_done, s_in, act, rew, term, s_out, first, last):
         """the stage pushes of step k (src/PDEagent.jl:237-314).  They run on the ENV stream (launched through the env's
         handle), behind the env step / the time-out fill that produce their inputs; `ev_push[k % 2]` marks them done and
         the update that samples the replay next waits for it (see _issue).  (launched through the critic's
@@ -376,15 +375,26 @@ class TrainPipeline:
         if last:
             push_sa(s_out, None)                                    # POST_EPISODE dummy
         if not self.serial:
-            self.ev_push[k % 2].record(self.s_env)
+            ev_done.record(self.s_env)
 
-    def _replay_batch(self):
+    def _replay_sample(self, ev_pushed):
+        """the sampled batch of this step's update (pde_sample / pde_fetch!, src/PDEagent.jl:317-340) into the trajectory's
+        fixed batch buffers -> self._batch_cur (None while the replay holds less than one step).  Re-evaluated at every step,
+        recorded or not: the sample count, the ring fill and the Philox offset are host counters."""
         tr, pol = self.agent.trajectory, self.policy
+        self._batch_cur = None
+        if ev_pushed is not None:
+            # the host counters the sample is drawn against already include env_{k-1}'s pushes: wait for them
+            # (the update stream has otherwise only waited for act_{k-1}, which precedes them on the env stream)
+            ev_pushed.wait(self.s_upd)
         if len(tr) <= tr.stride:
-            return None
-        b = tr.sample_device(pol._sample_seed, pol._sample_off, self.cols)
+            return
+        self._batch_cur = tr.sample_device(pol._sample_seed, pol._sample_off, self.cols, reuse=True)
         pol._sample_off += (self.cols + 3) // 4
-        return b
+        if not self.serial:
+            # ... and env_k's pushes overwrite the oldest rows of a full ring: they wait for this sample
+            self.ev_samp.record(self.s_upd)
+            self._samp_pending = True
 
     # ------------------------------------------------------------------ graphs
     def capture(self):
@@ -467,7 +477,7 @@ class TrainPipeline:
         phase (the property the HIP graphs rest on), so the calls of the first such step are recorded and later ones
         replay the list -- ~20 raw C calls instead of the Python layers of PDEenv / policy / torch stream contexts"""
         k = self.tick
-        fast = (self.fast_eager and not self.use_replay and not self.drain_between and not self._after_graph and k > 0
+        fast = (self.fast_eager and not self.drain_between and not self._after_graph and k > 0
                 and self._interior(k, 1) and self._interior(k - 1, 1))
         prog = self._progs.get(k % PERIOD) if fast else None
         if prog is not None:
