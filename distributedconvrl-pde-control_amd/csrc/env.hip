@@ -1718,6 +1718,135 @@ __global__ void ksfd_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
   }
 }
 
+// ---- the same step with ONE WAVE per trajectory (N = 64 CPL; used at N = 256, the grid of configs C1 / C2): lane l keeps the CPL consecutive
+// cells CPL l .. CPL l + CPL - 1 in registers, the two neighbours on either side come from lanes l -+ 1 (periodic) by four
+// lane exchanges per right-hand side -- no LDS line, no workgroup barrier inside the 4 K right-hand sides of a control step
+// (the form above: two barriers each) -- and a 64-thread workgroup fits beside the update passes on every CU in one round
+// (the 256-thread form: 72 VGPRs on all four SIMDs, one workgroup per CU at a time beside the passes, two rounds at B = 512).
+// Same stencils and the same order of operations per cell as ksfd_rhs / the RK4 above.
+// value of the same register in lane l - 1 (FROM_BELOW) or l + 1, periodic over the 64 lanes: one DPP wave rotate per 32-bit word
+// (gfx9 wave_ror:1 / wave_rol:1) instead of a ds_bpermute round trip through the LDS crossbar
+template <bool FROM_BELOW>
+__device__ __forceinline__ float lane_neighbour(float x) {
+  constexpr int ctrl = FROM_BELOW ? 0x13C : 0x134;      // DPP_WF_RR1 : DPP_WF_RL1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false));
+}
+template <bool FROM_BELOW>
+__device__ __forceinline__ double lane_neighbour(double x) {
+  constexpr int ctrl = FROM_BELOW ? 0x13C : 0x134;
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <class T, int CPL>
+__device__ __forceinline__ void ksfd_rhs_wave(const T (&w)[CPL], const T (&force)[CPL], T (&f)[CPL], int up, int dn, T i2dx, T idx2, T idx4) {
+  T ext[CPL + 4];
+  (void)up; (void)dn;
+  ext[0] = lane_neighbour<true>(w[CPL - 2]);
+  ext[1] = lane_neighbour<true>(w[CPL - 1]);
+  ext[CPL + 2] = lane_neighbour<false>(w[0]);
+  ext[CPL + 3] = lane_neighbour<false>(w[1]);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) ext[c + 2] = w[c];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const T m2 = ext[c], m1 = ext[c + 1], u = ext[c + 2], p1 = ext[c + 3], p2 = ext[c + 4];
+    const T ux = i2dx * (p1 - m1);
+    const T uxx = idx2 * (m1 - (T)2 * u + p1);
+    const T uxxxx = idx4 * (m2 - (T)4 * m1 + (T)6 * u - (T)4 * p1 + p2);
+    f[c] = -u * ux - uxx - uxxxx + force[c];
+  }
+}
+
+template <class T, int CPL>
+__global__ void __launch_bounds__(64) ksfd_wave_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ action,
+                                                            const T* __restrict__ action_prev, const T* __restrict__ state_prev,
+                                                            T* __restrict__ y_out, T* __restrict__ p_out, T* __restrict__ state_out,
+                                                            T* __restrict__ reward_out, int32_t* __restrict__ done) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = e.N, tid = threadIdx.x, nt = 64, b = blockIdx.x;
+  T* su = reinterpret_cast<T*>(smem_raw);  // [2][N] sensing image
+  T* act = su + 2 * N + 4;                 // [A]
+  T* actp = act + e.A;                     // [A]
+  T* dots = actp + e.A;                    // [2][S]
+  T* part = dots + 2 * e.S;                // [8][2][S]
+  T* red = part + 16 * e.S;                // [16]
+  set_wave_prio(e.prio);
+  const size_t yo = (size_t)b * N;
+  const int n0 = CPL * tid, up = (tid + 63) & 63, dn = (tid + 1) & 63;
+  T u[CPL], force[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) u[c] = y_in[yo + n0 + c];
+  for (int a = tid; a < e.A; a += nt) {
+    act[a] = action[(size_t)b * e.A + a];
+    actp[a] = action_prev[(size_t)b * e.A + a];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int n = n0 + c;
+    const T p = actuate_cell<T>(e, act, n);
+    if (p_out) p_out[yo + n] = p;
+    // forcing = actuation + disturbance mu cos(2 + pi + x/(Lx/2)), x = dx (n+1)   (KSSetup.jl:36,155)
+    force[c] = p + e.dist_mu * (T)cos(2.0 + 3.14159265358979323846 + (double)e.dx * (n + 1) / ((double)e.dx * N / 2));
+  }
+  const T i2dx = (T)0.5 / e.dx, idx2 = (T)1 / (e.dx * e.dx), idx4 = idx2 * idx2, h = e.hstep;
+  for (int it = 0; it < e.K; ++it) {
+    T k1[CPL], k2[CPL], k3[CPL], k4[CPL], w[CPL];
+    ksfd_rhs_wave<T, CPL>(u, force, k1, up, dn, i2dx, idx2, idx4);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) w[c] = u[c] + (T)0.5 * h * k1[c];
+    ksfd_rhs_wave<T, CPL>(w, force, k2, up, dn, i2dx, idx2, idx4);
+    if (e.rk2) {     // PDEenv's built-in integrator (src/PDEenv.jl:208-214): explicit midpoint, `oversampling` sub-steps
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) u[c] = u[c] + h * k2[c];
+      continue;
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) w[c] = u[c] + (T)0.5 * h * k2[c];
+    ksfd_rhs_wave<T, CPL>(w, force, k3, up, dn, i2dx, idx2, idx4);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) w[c] = u[c] + h * k3[c];
+    ksfd_rhs_wave<T, CPL>(w, force, k4, up, dn, i2dx, idx2, idx4);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) u[c] = u[c] + h / (T)6 * (k1[c] + (T)2 * (k2[c] + k3[c]) + k4[c]);
+  }
+  T m = 0;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    y_out[yo + n0 + c] = u[c];
+    if (!(fabs(u[c]) <= e.max_value)) m = 1;
+  }
+  if (done) {
+    m = block_max<T>(m, red, tid, nt);
+    if (tid == 0) done[b] = (e.check_max == 1 && m > 0) ? 1 : 0;
+    if (e.check_max != 2) write_terminal<T>(e, b, e.check_max == 1 && m > 0, tid, nt);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    su[n0 + c] = u[c];
+    su[N + n0 + c] = 0;
+  }
+  __syncthreads();
+  sense_dots<T>(e, [&](int r, int nn) { return su[r * N + nn]; }, dots, part, tid, nt);
+  const int rw = e.mono ? 1 : e.A;
+  const size_t sw = e.mono ? (size_t)e.S : (size_t)e.A * e.ns;
+  reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b * rw, tid, nt);
+  featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, state_out + b * sw, tid, nt);
+  if (done && e.check_max == 2) {
+    __syncthreads();
+    if (tid == 0) {
+      T mm = 0;
+      for (int a = 0; a < rw; ++a)
+        if (!(fabs(reward_out[(size_t)b * rw + a]) <= e.max_value)) mm = 1;
+      done[b] = mm > 0 ? 1 : 0;
+      write_terminal<T>(e, b, mm > 0, 0, 1);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ stand-alone closures
 // MODE 0: prepare_action, 1: featurize, 2: reward
 template <class T, int MODE>
@@ -1876,9 +2005,17 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
   hipLaunchKernelGGL((ksfd_env_step_kernel<T, M>), grid, block, E.lds_bytes, E.stream, e, (const T*)y_in,      \
                      (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out,   \
                      (T*)p_out, (T*)state_out, (T*)reward_out, done)
-    if (mode == 0) KSFD_LAUNCH(0);
+    // fused step at N = 256: one wave per trajectory (ksfd_wave_step_kernel); PDEC_KSFD_LDS=1: the general form
+    const bool lds_form = getenv("PDEC_KSFD_LDS") != nullptr;
+#define KSFD_WAVE(CPL)                                                                                                 \
+  hipLaunchKernelGGL((ksfd_wave_step_kernel<T, CPL>), grid, dim3(64), E.lds_bytes, E.stream, e, (const T*)y_in,           \
+                     (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out, (T*)p_out, (T*)state_out,  \
+                     (T*)reward_out, done)
+    if (mode == 0 && !lds_form && c.N == 256) KSFD_WAVE(4);      // (N = 1024 would need 168 VGPRs per wave: no room beside the passes)
+    else if (mode == 0) KSFD_LAUNCH(0);
     else if (mode == 1) KSFD_LAUNCH(1);
     else KSFD_LAUNCH(2);
+#undef KSFD_WAVE
 #undef KSFD_LAUNCH
   } else {
     set_error("pde_kind %d not implemented", c.pde_kind);

@@ -165,13 +165,16 @@ def test_host_pointer_wrapper(pkg):
     assert np.abs(out - g["y"][4]).max() <= 1e-12 and done[0] == 0
 
 
+@pytest.mark.parametrize("nx", [240, 256])
 @pytest.mark.parametrize("integ", ["rk4_fd", "midpoint_fd"])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 2e-4)])
-def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol, integ):
+def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol, integ, nx, monkeypatch):
     """north-star variant: RK4 + periodic 5-point FD (stencils of KSSetup.jl:55-59); rhs, do_step and the fused
-    (env)(action) against oracle/ks.py rhs_fd / do_step_rk4_fd (relative to max|value|)"""
+    (env)(action) against oracle/ks.py rhs_fd / do_step_rk4_fd (relative to max|value|).  nx = 256: the fused step runs in
+    its one-wave-per-trajectory form (four cells per lane, neighbours by lane exchange, csrc/env.hip: ksfd_wave_step_kernel);
+    it must also agree with the general one-cell-per-thread form (PDEC_KSFD_LDS=1) to round-off."""
     from oracle import ks
-    nx, Lx, K, dtc = 240, 200.0, 30, 0.1
+    Lx, K, dtc = 200.0, 30, 0.1
     pos = np.arange(1, nx + 1, 3)
     setup = pkg.KSSetup(nx, Lx, pos, integrator=integ, mu=0.02, dt=dtc, oversampling=K, window_size=3)
     step = ks.do_step_rk4_fd if integ == "rk4_fd" else ks.do_step_midpoint_fd     # midpoint: src/PDEenv.jl:208-214
@@ -200,6 +203,15 @@ def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol, integ):
         r = ks.reward_function(cfg, ref, a1[b][None], (a1[b] - a0[b])[None])
         assert np.abs(env.reward[b].cpu().numpy() - r).max() <= 10 * tol
     assert int(flags.sum()) == 0
+    if nx == 256:
+        y_wave, st_wave, r_wave = env.y.clone(), env.state.clone(), env.reward.clone()
+        monkeypatch.setenv("PDEC_KSFD_LDS", "1")
+        env2 = pkg.PDEenv(setup, B=B, dtype=dt, y0=y)
+        env2.action.copy_(to_dev(a0, dt).reshape(env2._ashape))
+        env2(to_dev(a1, dt).reshape(env2._ashape))
+        rt = 1e-13 if prec == "f64" else 1e-5
+        assert float((env2.y - y_wave).abs().max()) <= rt * float(y_wave.abs().max())
+        assert float((env2.state - st_wave).abs().max()) <= 10 * rt and float((env2.reward - r_wave).abs().max()) <= 10 * rt
 
 
 @pytest.mark.parametrize("nx", [1024, 4096, 600, 250, 60])
