@@ -77,12 +77,14 @@ static FNet make_fnet_layout(int K0, int H) {
   f.oW2T = f.oW2 + f.nbig;
   f.total = f.oW2T + f.nbig;
   f.oS2 = f.oS2T = -1;
+#ifdef PDEC_EXPERIMENTAL_SPLIT      // the bf16-split image blocks exist in the experimental build only (see split_on())
   if (f.HP == SPL_HP) {
     static_assert(split_floats() % 256 == 0, "split blocks are copied in whole 1-KiB pieces");
     f.oS2 = f.total;
     f.oS2T = f.oS2 + split_floats();
     f.total = f.oS2T + split_floats();
   }
+#endif
   return f;
 }
 
@@ -1228,11 +1230,34 @@ static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
 // few per cent of 30-step runs (never with the exact-f32 passes, never with the streams on disjoint CU masks, never with the
 // same products issued as two v_mfma_f32_16x16x16_bf16 -- tools/det_probe5.py): TrainPipeline refuses the
 // split forms unless it runs serially.  which: 1 critic pass, 2 actor pass.
+// The PRODUCT library does not contain these kernels (round-2 verdict, item 3: "otherwise record the number and delete the
+// kernel"): they are compiled only with -DPDEC_EXPERIMENTAL_SPLIT (`make EXPERIMENTAL_SPLIT=1 OUT=...`), which is how the
+// measurements and the reproducer of DESIGN.md §3.2a were built; the product refuses PDEC_SPLIT != 0 with an error.
 #define PDEC_SPLIT_DEFAULT '0'
-static bool split_on(int which) {
+static char split_request() {
   const char* e = getenv("PDEC_SPLIT");
-  const char c = (e && e[0]) ? e[0] : PDEC_SPLIT_DEFAULT;
+  return (e && e[0]) ? e[0] : PDEC_SPLIT_DEFAULT;
+}
+static bool split_on(int which) {
+#ifdef PDEC_EXPERIMENTAL_SPLIT
+  const char c = split_request();
   return c == '1' || (which == 1 && c == 'c') || (which == 2 && c == 'a');
+#else
+  (void)which;
+  return false;
+#endif
+}
+// product build: a request for a split form is an error, not a silent exact-f32 run
+static int split_refused() {
+#ifndef PDEC_EXPERIMENTAL_SPLIT
+  const char c = split_request();
+  if (c != '0') {
+    set_error("PDEC_SPLIT=%c: this libpdeconv.so was built without the experimental bf16-split passes (DESIGN.md 3.2a; "
+              "make -C csrc EXPERIMENTAL_SPLIT=1 OUT=<other file> builds them)", c);
+    return PDEC_E_INVALID;
+  }
+#endif
+  return PDEC_OK;
 }
 template <int MT, int MTA, bool SPLIT>
 static int launch_critic_v(Mlp* C, const FusedArgs& g, int grid) {
@@ -1267,9 +1292,12 @@ static int launch_critic_v(Mlp* C, const FusedArgs& g, int grid) {
 }
 template <int MT, int MTA>
 static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
+  if (int rc = split_refused()) return rc;
+#ifdef PDEC_EXPERIMENTAL_SPLIT
   if constexpr (16 * MT == SPL_HP) {
     if (split_on(1)) return launch_critic_v<MT, MTA, true>(C, g, grid);
   }
+#endif
   return launch_critic_v<MT, MTA, false>(C, g, grid);
 }
 template <int MT, int MTA, bool SPLIT>
@@ -1294,9 +1322,12 @@ static int launch_actor_v(Mlp* C, const FusedArgs& g, int grid) {
 
 template <int MT, int MTA>
 static int launch_actor(Mlp* C, const FusedArgs& g, int grid) {
+  if (int rc = split_refused()) return rc;
+#ifdef PDEC_EXPERIMENTAL_SPLIT
   if constexpr (16 * MT == SPL_HP) {
     if (split_on(2)) return launch_actor_v<MT, MTA, true>(C, g, grid);
   }
+#endif
   return launch_actor_v<MT, MTA, false>(C, g, grid);
 }
 

@@ -296,6 +296,34 @@ def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop, 
     assert abs(bp[0] - 0.9 ** (loops + 1)) <= 1e-12
 
 
+def _need_split(pkg):
+    """the bf16-split passes exist only in the experimental build of the library (make -C csrc EXPERIMENTAL_SPLIT=1
+    OBJDIR=../../build_exp OUT=../../build_exp/libpdeconv_split.so; run these tests with PDEC_LIB_PATH pointing at it)"""
+    if not pkg._lib.load().pdec_debug_split_available():
+        pytest.skip("product build of libpdeconv.so: no bf16-split passes (DESIGN.md 3.2a)")
+
+
+def test_product_build_refuses_a_split_request(pkg, monkeypatch):
+    """PDEC_SPLIT != 0 with the product library is an error of the fused passes, never a silent exact-f32 run"""
+    import ctypes as C
+    from oracle import nn
+    if pkg._lib.load().pdec_debug_split_available():
+        pytest.skip("experimental build: the split passes exist")
+    rng = np.random.default_rng(2)
+    da, aa = nn.layer_sizes(3, 1, 1.6, True, False)
+    dc, ac = nn.layer_sizes(3, 1, 7.0, False, False)
+    A, _ = make_net(pkg, rng, da, aa, torch.float32, 256)
+    Cn, _ = make_net(pkg, rng, dc, ac, torch.float32, 256)
+    s = to_dev(rng.standard_normal((256, 3)), torch.float32)
+    L = torch.zeros(2, dtype=torch.float32, device="cuda:0")
+    monkeypatch.setenv("PDEC_SPLIT", "a")
+    with pytest.raises(pkg.PdecError, match="without the experimental"):
+        pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, pkg._lib.ptr(s), 256, 1.0, C.c_void_p(L.data_ptr() + 4)))
+    monkeypatch.setenv("PDEC_SPLIT", "0")
+    pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, pkg._lib.ptr(s), 256, 1.0, C.c_void_p(L.data_ptr() + 4)))
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("split", ["a", "c", "1"])
 @pytest.mark.parametrize("quirk", [1, 0])
 @pytest.mark.parametrize("Bu", [4096, 77])
@@ -304,6 +332,7 @@ def test_ddpg_update_with_bf16_split_passes_matches_oracle(pkg, monkeypatch, qui
     v_mfma_f32_16x16x32_bf16 with W2 as a bf16 pair and the activation as three bf16 splits, five products accumulated in f32 --
     a: both products of the actor pass, c: the two forward products of the critic pass, 1: both.  Same oracle, same tolerance
     as the exact-f32 default (src/PDEagent.jl:363-418, 2e-4 relative on losses and all four networks after one and two updates)."""
+    _need_split(pkg)
     monkeypatch.setenv("PDEC_SPLIT", split)
     test_ddpg_update_matches_oracle(pkg, quirk, "f32", Bu)
 
@@ -312,6 +341,7 @@ def test_bf16_split_gradients_track_the_exact_f32_form(pkg, monkeypatch):
     """the gradients of one update (pdec_ddpg_critic_grads / pdec_ddpg_actor_grads, flat buffers) with split operands against the
     exact-f32 MFMA form on the same inputs: <= 2e-5 of the largest gradient entry (16 mantissa bits of W2 in the split
     products, all 24 bits of the activations); the pass a switch value does not name stays bit-identical"""
+    _need_split(pkg)
     import ctypes as C
     from oracle import nn
     rng = np.random.default_rng(5)
@@ -350,6 +380,7 @@ def test_bf16_split_images_are_rebuilt_after_updates_without_them(pkg, monkeypat
     took ten updates with the default exact-f32 passes and are then read by a split pass must first get their images rebuilt
     from the parameters (csrc/mlp_mfma.hip: split_stale): the split actor gradient still tracks the exact one to 2e-5 of its
     largest entry (stale images -- ten ADAM steps at 1e-3 behind -- would be off by per cents)."""
+    _need_split(pkg)
     import ctypes as C
     from oracle import nn
     monkeypatch.setenv("PDEC_SPLIT", "0")

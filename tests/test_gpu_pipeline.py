@@ -278,7 +278,8 @@ def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
 def test_two_stream_pipeline_refuses_the_bf16_split_passes(pkg, monkeypatch):
     """PDEC_SPLIT=a|c|1 selects the experimental bf16-split forms of the fused passes; beside the PDE step they are not
     bit-stable, so a two-stream TrainPipeline raises instead of training on silently wrong fields; on one
-    stream (nothing runs beside the passes) it is accepted."""
+    stream (nothing runs beside the passes) it is accepted -- by the experimental build of the library; the product build
+    does not contain those passes and refuses the request itself."""
     monkeypatch.setenv("PDEC_SPLIT", "a")
     with pytest.raises(pkg.PdecError, match="PDEC_SPLIT"):
         _make(pkg, False, B=8, E=11)
@@ -290,6 +291,11 @@ def test_two_stream_pipeline_refuses_the_bf16_split_passes(pkg, monkeypatch):
                              noise_seed=7, trajectory_length=1)
     p = pkg.TrainPipeline(env, agent, lag=2, episode_steps=11, stream_env=st, stream_upd=st, use_graphs=False, noise_seed=99)
     assert p.serial
-    p.run(6); p.sync()
-    assert bool(torch.isfinite(p.y).all())
+    if pkg._lib.load().pdec_debug_split_available():      # experimental build of the library: the split passes run
+        p.run(6); p.sync()
+        assert bool(torch.isfinite(p.y).all())
+    else:                                                 # product build: the passes themselves refuse the request
+        with pytest.raises(pkg.PdecError, match="without the experimental"):
+            p.run(6)
+        monkeypatch.setenv("PDEC_SPLIT", "0")
     p.close()
