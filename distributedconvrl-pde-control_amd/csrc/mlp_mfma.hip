@@ -133,7 +133,7 @@ __device__ __forceinline__ SmallLds carve_small(float* base, int HP) {
 // floats of the big region: the padded W2 image (in whole DMA pieces), or the staging images that later overlay it
 __host__ __device__ constexpr int wreg_floats(int MT, int MTA, bool split = false) {
   const int HP = 16 * MT, HPa = 16 * MTA;
-  int a = split ? split_floats() : big_floats(HP), b = 2 * HP * LDP, c = (32 + 4 * HPa) * LDP;
+  int a = split ? split_floats() : big_floats(HP), b = 2 * HP * LDP, c = (32 + 4 * HPa) * 136;      // c: the actor's staging images, LDPA = 136
   int m = a > b ? a : b;
   return m > c ? m : c;
 }
@@ -739,41 +739,60 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   for (int m = 0; m < MTA; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dza1[m][r] = ha1[m][r] > 0.f ? dza1[m][r] : 0.f;
-  // ---- weight gradients of the actor (three small column contractions)
+  // ---- weight gradients of the actor: three small column contractions over all 128 columns in ONE staging round, one output
+  // tile per wave (2 + 4 + 2 tiles at MTA = 2).  (Until round 3: two 64-column halves, the tiles of each product handed to waves
+  // 0, 1, ..: waves 0 and 1 carried three dependent MFMA chains per half while waves 4 - 7 idled -- 7.7 k cycles of the pass.)
+  // Columns are contracted in the same order as before, so the sums are bit-identical.
   const int nslab = gridDim.x;
-  float* I0 = Wreg;                       // DZ3 [16][LDP]
-  float* I1 = I0 + 16 * LDP;              // HA2aug [HPa][LDP]
-  float* I2 = I1 + HPa * LDP;             // DZA2 [HPa][LDP]
-  float* I3 = I2 + HPa * LDP;             // HA1aug [HPa][LDP]
-  float* I4 = I3 + HPa * LDP;             // DZA1 [HPa][LDP]
-  float* I5 = I4 + HPa * LDP;             // Xaug [16][LDP]
-  const int cw = (w & 3) * 16 + lr;
+  constexpr int LDPA = 136;               // 8 mod 16 floats: conflict-free ds_read_b128 operand reads
+  static_assert((32 + 4 * HPa) * LDPA <= wreg_floats(MT, MTA, SPLIT), "the actor's staging images do not fit the big LDS region");
+  static_assert(2 * MTA + MTA * MTA <= FTHREADS / 64, "one output tile per wave");
+  float* I0 = Wreg;                       // DZ3 [16][LDPA]
+  float* I1 = I0 + 16 * LDPA;             // HA2aug [HPa][LDPA]
+  float* I2 = I1 + HPa * LDPA;            // DZA2 [HPa][LDPA]
+  float* I3 = I2 + HPa * LDPA;            // HA1aug [HPa][LDPA]
+  float* I4 = I3 + HPa * LDPA;            // DZA1 [HPa][LDPA]
+  float* I5 = I4 + HPa * LDPA;            // Xaug [16][LDPA]
+  const int cw = w * 16 + lr;
   lds_barrier();
-  for (int i = tid; i < 16 * LDP; i += FTHREADS) { I0[i] = 0.f; I5[i] = 0.f; }
-  f32x4 acc3[1], acc2[(MTA * MTA + 7) / 8], acc1[1];
-  zero_(acc3); zero_(acc2); zero_(acc1);
-  for (int half = 0; half < 2; ++half) {
-    lds_barrier();
-    if ((w >> 2) == half) {
-      if (q == 0) I0[cw] = dza3;
-      stage_rows<MTA>(I1, ha2, cw, q, g.A.H);
-      stage_rows<MTA>(I2, dza2, cw, q, -1);
-      stage_rows<MTA>(I3, ha1, cw, q, g.A.H);
-      stage_rows<MTA>(I4, dza1, cw, q, -1);
+  for (int i = tid; i < 16 * LDPA; i += FTHREADS) { I0[i] = 0.f; I5[i] = 0.f; }
+  lds_barrier();
+  if (q == 0) I0[cw] = dza3;
+  stage_rows_ld<MTA>(I1, LDPA, ha2, cw, q, g.A.H);
+  stage_rows_ld<MTA>(I2, LDPA, dza2, cw, q, -1);
+  stage_rows_ld<MTA>(I3, LDPA, ha1, cw, q, g.A.H);
+  stage_rows_ld<MTA>(I4, LDPA, dza1, cw, q, -1);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = 4 * t + q;
-        I5[row * LDP + cw] = row == ns ? 1.f : xs[t];
-      }
-    }
-    lds_barrier();
-    gemm_pass(acc3, I0, I1, 1, MTA, w, lr, q);
-    gemm_pass(acc2, I2, I3, MTA, MTA, w, lr, q);
-    gemm_pass(acc1, I4, I5, MTA, 1, w, lr, q);
+  for (int t = 0; t < 4; ++t) {
+    const int row = 4 * t + q;
+    I5[row * LDPA + cw] = row == ns ? 1.f : xs[t];
   }
-  store_pass(acc3, g.slab, nslab, 0, 1, MTA, w, l);
-  store_pass(acc2, g.slab, nslab, MTA, MTA, MTA, w, l);
-  store_pass(acc1, g.slab, nslab, MTA + MTA * MTA, MTA, 1, w, l);
+  lds_barrier();
+  {
+    // tile numbering of the slab (store_pass): dW3a tiles 0 .. MTA-1, dW2a MTA .. MTA+MTA^2-1, dW1a the next MTA
+    const float *Lp = nullptr, *Rp = nullptr;
+    int T = -1;
+    if (w < MTA) { Lp = I0; Rp = I1 + 16 * w * LDPA; T = w; }
+    else if (w < MTA + MTA * MTA) { const int u = w - MTA, ti = u / MTA, tk = u - ti * MTA; Lp = I2 + 16 * ti * LDPA; Rp = I3 + 16 * tk * LDPA; T = w; }
+    else if (w < 2 * MTA + MTA * MTA) { const int u = w - MTA - MTA * MTA; Lp = I4 + 16 * u * LDPA; Rp = I5; T = w; }
+    if (T >= 0) {
+      const float* lrow = Lp + lr * LDPA + 4 * q;
+      const float* rrow = Rp + lr * LDPA + 4 * q;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(lrow + 16 * t);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(rrow + 16 * t);
+        a = mfma4(av[0], bv[0], a);
+        a = mfma4(av[1], bv[1], a);
+        a = mfma4(av[2], bv[2], a);
+        a = mfma4(av[3], bv[3], a);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __builtin_nontemporal_store(a[r], &g.slab[((size_t)(4 * T + r) * nslab + blockIdx.x) * 64 + l]);
+    }
+  }
   st0 = block_sum_lds(st0, red, tid);
   if (tid == 0) {
     float* st = g.slab + ((size_t)(4 * (2 * MTA + MTA * MTA)) * nslab + blockIdx.x) * 64;
