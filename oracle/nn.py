@@ -117,8 +117,15 @@ def ddpg_losses_and_grads(A, C, At, Ct, acts_a, acts_c, s, a, r, t, snext, gamma
     q, zs, as_ = forward(C, acts_c, np.concatenate([s, a]), keep=True)        # :392
     q = q.reshape(-1)
     if quirk:
-        e = r[None, :] + (tgt_i - q)[:, None]                                 # [i,j]
-        closs = np.mean(e ** 2)                                               # :393
+        d = tgt_i - q
+        if Bu <= 2048:
+            e = r[None, :] + d[:, None]                                       # [i,j]
+            closs = np.mean(e ** 2)                                           # :393
+        else:
+            # the same double mean without the Bu x Bu matrix (8.6 GB at Bu = 32 768):
+            # mean_ij (r_j + d_i)^2 = mean(r^2) + 2 mean(r) mean(d) + mean(d^2); fp64 accumulation
+            r64, d64 = r.astype(np.float64), d.astype(np.float64)
+            closs = dt.type(np.mean(r64 * r64) + 2.0 * r64.mean() * d64.mean() + np.mean(d64 * d64))
         dq = -(2.0 / Bu) * (r.mean() + tgt_i - q)
     else:
         e = r + tgt_i - q

@@ -150,6 +150,24 @@ def test_nn_ddpg_matches_torch_autograd_golden():
             assert np.abs(out2["gA"][i] - g[f"gA{i}"]).max() <= 1e-12
 
 
+def test_quirk_loss_closed_form_equals_the_explicit_broadcast():
+    """oracle/nn.py evaluates the reference's (1xBu).+(Bu) double mean (src/PDEagent.jl:388-393) without the Bu x Bu matrix
+    above Bu = 2048: the closed form must be the explicit broadcast (checked at a size where both run), gradients untouched"""
+    from oracle import nn
+    rng = np.random.default_rng(4)
+    da, aa = nn.layer_sizes(3, 1, 1.6, True, False)
+    dc, ac = nn.layer_sizes(3, 1, 7.0, False, False)
+    mk = lambda d: [p if i % 2 == 0 else rng.standard_normal(p.shape) * 0.1 for i, p in enumerate(nn.glorot_uniform(rng, d, np.float64))]
+    PA, PC, PAt, PCt = mk(da), mk(dc), mk(da), mk(dc)
+    Bu = 2500
+    s, sn = rng.standard_normal((3, Bu)), rng.standard_normal((3, Bu))
+    a, r, t = rng.uniform(-1, 1, (1, Bu)), -rng.uniform(0, 1, Bu), (rng.uniform(0, 1, Bu) < 0.1) * 1.0
+    out = nn.ddpg_losses_and_grads(PA, PC, PAt, PCt, aa, ac, s, a, r, t, sn, 0.99, True)
+    d = 0.99 * (1 - t) * out["qt"] - out["q"]
+    explicit = np.mean((r[None, :] + d[:, None]) ** 2)
+    assert abs(out["critic_loss"] - explicit) <= 1e-13 * explicit
+
+
 def test_c_agent_matches_numpy_oracle():
     from oracle import c_oracle, nn
     rng = np.random.default_rng(2)
