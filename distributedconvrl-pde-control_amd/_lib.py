@@ -100,6 +100,7 @@ SIGNATURES = {
     "pdec_ddpg_actor_grads": [Handle, Handle, _vp, _i, _d, _vp],
     "pdec_ddpg_update": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _pd, _pd],
     "pdec_comm_unique_id": [_vp], "pdec_comm_create": [C.POINTER(Handle), _i, _i, _vp],
+    "pdec_comm_create_timeout": [C.POINTER(Handle), _i, _i, _vp, _i],
     "pdec_allreduce_grads": [Handle, Handle], "pdec_allreduce": [Handle, _vp, _sz, _i, _vp],
 }
 _RESTYPES = {"pdec_last_error": C.c_char_p}

@@ -247,7 +247,7 @@ class CustomDDPGPolicy:
         L = self._losses
         oc, oa = self.behavior_critic.optimizer, self.behavior_actor.optimizer
         self._batch_keepalive = (s, a, r, t, sn)
-        if self.reducer is None or self.reducer.world_size == 1:
+        if self.reducer is None or not self.reducer.active:
             # single device: nothing to all-reduce, so gradient reduction, ADAM and Polyak fuse (4 launches)
             if before_actor_half is None:
                 _lib.check(self.lib.pdec_ddpg_update_async(
@@ -286,7 +286,7 @@ class CustomDDPGPolicy:
 
     def small_update_ok(self):
         A, Cn = self.behavior_actor.model, self.behavior_critic.model
-        return (self.use_small_update and (self.reducer is None or self.reducer.world_size == 1) and self.batch_size <= 16
+        return (self.use_small_update and (self.reducer is None or not self.reducer.active) and self.batch_size <= 16
                 and A.dtype == torch.float32 and Cn.dtype == torch.float32 and len(A.acts) <= 4 and len(Cn.acts) <= 4)
 
     def update_small(self, tr, slots):

@@ -4,6 +4,12 @@
 // At ~21 k floats the op is latency-bound, so it is a single fused buffer per network.
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
 #include "common.hpp"
 #include "mlp.hpp"
 
@@ -46,6 +52,62 @@ int pdec_comm_create(pdec_handle* c, int nranks, int rank, const void* id128) {
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   PDEC_NCCL(ncclCommInitRank(&C->comm, nranks, id, rank));
+  C->nranks = nranks;
+  C->rank = rank;
+  *c = register_object(std::move(C));
+  return PDEC_OK;
+}
+
+// The rendezvous of ncclCommInitRank blocks until every rank has arrived: one rank that never calls it (it failed earlier, or
+// died) leaves the others inside it for ever.  Here the blocking call runs on a helper thread and the caller waits for it with a
+// deadline; past the deadline the caller gets PDEC_E_COMM and carries on (the helper stays parked inside RCCL, owning only its
+// own shared state, and its communicator -- should the rendezvous complete after all -- is destroyed by the helper itself).  The
+// communicator stays an ordinary BLOCKING one: a non-blocking config (ncclCommInitRankConfig, blocking = 0) would make every
+// later ncclAllReduce on the update stream an asynchronous call that has to be polled.
+int pdec_comm_create_timeout(pdec_handle* c, int nranks, int rank, const void* id128, int timeout_ms) {
+  PDEC_REQUIRE(c && id128 && nranks >= 1 && rank >= 0 && rank < nranks, "pdec_comm_create_timeout: bad arguments");
+  if (timeout_ms <= 0) return pdec_comm_create(c, nranks, rank, id128);
+  struct Shared {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclResult_t res = ncclSuccess;
+    ncclComm_t comm = nullptr;
+  };
+  auto sh = std::make_shared<Shared>();
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  int dev = 0;
+  PDEC_HIP(hipGetDevice(&dev));
+  std::thread([sh, id, nranks, rank, dev]() {
+    ncclComm_t cm = nullptr;
+    ncclResult_t r = hipSetDevice(dev) == hipSuccess ? ncclCommInitRank(&cm, nranks, id, rank) : ncclUnhandledCudaError;
+    std::unique_lock<std::mutex> lk(sh->m);
+    if (sh->abandoned) {                  // the caller gave up: nobody will ever use this communicator
+      lk.unlock();
+      if (r == ncclSuccess && cm) ncclCommAbort(cm);
+      return;
+    }
+    sh->res = r;
+    sh->comm = cm;
+    sh->done = true;
+    sh->cv.notify_all();
+  }).detach();
+  {
+    std::unique_lock<std::mutex> lk(sh->m);
+    if (!sh->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return sh->done; })) {
+      sh->abandoned = true;
+      set_error("ncclCommInitRank(nranks=%d, rank=%d) did not return within %d ms (a rank missing from the rendezvous?)", nranks, rank,
+                timeout_ms);
+      return PDEC_E_COMM;
+    }
+  }
+  if (sh->res != ncclSuccess) {
+    set_error("ncclCommInitRank(&C->comm, nranks, id, rank) failed: %s", ncclGetErrorString(sh->res));
+    return PDEC_E_COMM;
+  }
+  auto C = std::make_unique<Comm>();
+  C->comm = sh->comm;
   C->nranks = nranks;
   C->rank = rank;
   *c = register_object(std::move(C));

@@ -85,7 +85,7 @@ class TrainPipeline:
         self.serial = self.s_env.cuda_stream == self.s_upd.cuda_stream
         self.use_replay = bool(use_replay)
         reducer = self.policy.reducer
-        self.multi_rank = reducer is not None and reducer.world_size > 1
+        self.multi_rank = reducer is not None and reducer.active      # the split update sequence (N > 1, or forced)
         # a recorded step / a graph holds POINTERS: policy.update must hand the ring tensors through unchanged, which it
         # does only when no dtype conversion makes a temporary (`.to(dt).contiguous()` is the identity then)
         self._batch_aliases = env.dtype == self.policy.behavior_critic.model.dtype
@@ -208,6 +208,15 @@ class TrainPipeline:
             # would be bootstrapped across the reset with terminal = 0 -- and the recorded interior steps are dropped
             self._first_tick = self.tick
             self._progs = {}
+            tr = self.agent.trajectory
+            if self.use_replay and tr.n_rt > 0 and tr.n_sa == tr.n_rt:
+                # device-replay route: transition tick-1 is already in the ring with terminal = 0 and no
+                # POST_EPISODE dummy follows it, so the first (s, a) row of the new episode becomes its next_state and later
+                # samples would bootstrap across the reset.  Its rows are cut off instead: terminal = 1 (the layout a regular
+                # episode end leaves once its dummy row has been popped and overwritten).  On the env stream, behind the pushes.
+                with torch.cuda.stream(self.s_env):
+                    lo = (tr.n_rt - self.cols) % tr.capacity
+                    tr.terminal[lo:lo + self.cols].fill_(1.0)
 
     @property
     def y(self):

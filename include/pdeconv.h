@@ -431,6 +431,10 @@ int pdec_stream_wait_event(void* hip_stream, pdec_handle ev);
  * this is the build's data-parallel addition). */
 int pdec_comm_unique_id(void* id128);
 int pdec_comm_create(pdec_handle* c, int nranks, int rank, const void* id128);
+/* the same with a bounded wait: RCCL's rendezvous blocks until every rank has arrived, so one missing rank would park the
+ * others for ever; past timeout_ms (> 0) this returns PDEC_E_COMM instead and the caller can agree on another path
+ * (bench.py: torch.distributed).  timeout_ms <= 0 = pdec_comm_create. */
+int pdec_comm_create_timeout(pdec_handle* c, int nranks, int rank, const void* id128, int timeout_ms);
 /* sum-all-reduce the internal gradient buffer of an MLP in place (fp32/fp64) */
 int pdec_allreduce_grads(pdec_handle comm, pdec_handle mlp);
 int pdec_allreduce(pdec_handle comm, void* dptr, size_t n, int dtype, void* hip_stream);

@@ -260,6 +260,12 @@ function comm_create(nranks, rank, id::Vector{UInt8})
     check(ccall((:pdec_comm_create, LIB), Cint, (Ref{UInt64}, Cint, Cint, Ptr{Cvoid}), c, nranks, rank, id))
     c[]
 end
+# bounded wait for the rendezvous (a rank that never arrives must not park the others for ever)
+function comm_create(nranks, rank, id::Vector{UInt8}, timeout_ms::Integer)
+    c = Ref{UInt64}(0)
+    check(ccall((:pdec_comm_create_timeout, LIB), Cint, (Ref{UInt64}, Cint, Cint, Ptr{Cvoid}, Cint), c, nranks, rank, id, timeout_ms))
+    c[]
+end
 allreduce_grads(comm::UInt64, m::HipMLP) = check(ccall((:pdec_allreduce_grads, LIB), Cint, (UInt64, UInt64), comm, m.h))
 
 end # module

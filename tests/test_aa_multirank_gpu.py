@@ -255,3 +255,40 @@ def test_bench_c4_two_ranks_on_one_gpu():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["n_ranks_observed"] == 2 and d["config"]["global_batch"] == 16
     assert d["checks"]["finite"] and d["value"] > 0 and d["roofline"]["kernel"] and d["unit"] == "env-steps/s"
+
+
+def test_bench_c5_two_ranks_on_one_gpu():
+    """`bench.py --config C5 --gpus 2` (reduced grid 128 x 128, B = 2 per rank): the data-parallel RL
+    step of the 2-D fluid config (scripts/Fluid/setup/FluidSetup.jl:163-261) through the self-launcher -- fp64 env + act +
+    update per step, gradients all-reduced over gloo"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PDEC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C5", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--nx", "128", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["n_ranks_observed"] == 2 and d["config"]["global_batch"] == 4 and d["dtype"] == "f64"
+    assert d["checks"]["finite"] and d["value"] > 0 and d["roofline"]["kernel"].startswith("fluid_") and d["unit"] == "env-steps/s"
+
+
+def test_bench_split_update_on_one_rank():
+    """`bench.py --split-update` end to end: the N > 1 launch sequence with a 1-rank native RCCL communicator (created,
+    verified against the closed-form sum) in the timed pipeline; reports through the same JSON line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--split-update", "--dp-sync", "all", "--steps", "20", "--warmup", "5",
+                        "--batch", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    sel = d["collective_selection"]
+    assert sel["native_created"] and sel["native_verified"] and d["collective_issued_by"].startswith("libpdeconv")
+    assert d["checks"]["finite"] and d["value"] > 0 and "split-update" in d["config"]["workload"] and "variants" not in d
+
+
+def test_self_launcher_kills_its_ranks_at_the_deadline():
+    """a rank that never finishes (here: --deadline-s shorter than the import + set-up) must not hang the caller: the parent
+    kills exactly its own children and exits non-zero"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PDEC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3000000", "--warmup", "4", "--batch", "64",
+                        "--no-cpu-baseline", "--deadline-s", "20"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and ("did not finish within" in r.stderr or "not finished after" in r.stderr), (r.returncode, r.stderr[-2000:])

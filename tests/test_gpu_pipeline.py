@@ -152,6 +152,60 @@ def test_restart_in_the_middle_of_an_episode(pkg):
     _same_networks(pa, pb)
 
 
+def test_restart_in_the_middle_of_an_episode_on_the_replay_route(pkg):
+    """the same restart with use_replay=True.  Transition tick-1 sits in the ring with terminal = 0 and the
+    reset state becomes its next_state; reset_from() must cut it off (terminal = 1 on its rows), so that no sample bootstraps
+    across the reset -- and only on ITS rows."""
+    p = _make(pkg, use_replay=True, replay_steps=32)
+    p.run(9); p.sync()
+    tr = p.agent.trajectory
+    assert tr.n_sa == tr.n_rt == 9 * p.cols
+    before = tr.terminal.clone()
+    assert float(before[8 * p.cols:9 * p.cols].max()) == 0.0          # step 8 is interior (E = 17): not terminal
+    p.reset_from(p.env.y0)
+    p.sync()
+    assert float(tr.terminal[8 * p.cols:9 * p.cols].min()) == 1.0     # ... and now it is
+    assert torch.equal(tr.terminal[:8 * p.cols], before[:8 * p.cols])
+    p.run(12); p.sync()
+    assert tr.n_sa == tr.n_rt == 21 * p.cols                          # the ring stays aligned: one (s, a) row per (r, t) row
+    assert float(tr.terminal[8 * p.cols:9 * p.cols].min()) == 1.0
+    assert float(tr.terminal[9 * p.cols:21 * p.cols].max()) == 0.0
+    # the first row block of the new episode is the featurized reset state, i.e. the (cut-off) next_state of transition 8
+    assert torch.equal(tr.state[9 * p.cols:10 * p.cols].view_as(p.state0), p.state0.to(tr.state.dtype))
+    assert bool(torch.isfinite(p.y).all())
+    p.close()
+
+
+def test_split_update_sequence_on_one_rank_equals_the_fused_finish(pkg):
+    """`bench.py --split-update`: the data-parallel launch sequence -- gradient pass -> slab reduction ->
+    pdec_allreduce_grads on a ONE-rank RCCL communicator -> pdec_adam_polyak_step -- inside the two-stream pipeline leaves
+    bit for bit the networks and fields of the fused single-GPU finish (an all-reduce over one rank is the identity)."""
+    L = pkg._lib
+    pa = _make(pkg, False)
+    lib = pa.lib
+    for sync in ("all", "policy"):
+        red = pkg.distributed.NativeGradReducer(lib, rank=0, world_size=1, reduce_critic=(sync == "all"), force_split=True)
+        assert red.active and red.verify_against_torch("cuda:0")
+        setup = pkg.KSSetup.bench_C2(256)
+        s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+        y0 = setup.generate_random_init(np.random.default_rng(0), 64) * 0.15
+        env = pkg.PDEenv(setup, B=64, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
+        agent = pkg.create_agent(setup=setup, B=64, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
+                                 noise_seed=7, trajectory_length=1, reducer=red)
+        agent.policy.act_noise = 0.3
+        torch.cuda.synchronize()
+        pb = pkg.TrainPipeline(env, agent, lag=2, episode_steps=17, stream_env=s_env, stream_upd=s_upd, use_graphs=False, noise_seed=99)
+        assert pb.multi_rank and not pb.use_graphs
+        pf = _make(pkg, False)
+        pf.run(40); pb.run(40)
+        pf.sync(); pb.sync()
+        assert torch.equal(pf.y, pb.y) and bool(torch.isfinite(pb.y).all())
+        _same_networks(pf, pb)
+        pb.close(); pf.close()
+        red.close()
+    pa.close()
+
+
 def test_checkpoint_keeps_the_device_noise_counter(pkg, tmp_path):
     """TrainPipeline's acting kernel advances a DEVICE-resident Philox counter
     (pdec_policy_act_rng_dev); save_agent stores it and load_agent restores it, so a resumed pipeline continues the
