@@ -21,6 +21,9 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#else
+static int omp_get_max_threads(void) { return 1; }
+static int omp_get_thread_num(void) { return 0; }
 #endif
 
 typedef double complex cpx;
@@ -230,10 +233,13 @@ static void adam(double* const* W, double* const* b, const mlp* M, double* flatg
 static void grads_pass(agent* G, int mode, const double* s, const double* a, const double* dq_or_null, int Bu, double* flatg, double* qout) {
   const mlp *A = &G->A, *C = &G->C; const mlp* M = mode == 0 ? C : A; const int n = mode == 0 ? G->nC : G->nA;
   const int ns = A->dims[0], na = A->dims[A->L];
-  memset(flatg, 0, 8 * (size_t)n);
+  /* per-thread partial gradients, combined in THREAD ORDER (deterministic for a given thread count; the static schedule
+   * gives thread k the k-th contiguous block of columns), the combination itself parallel over the parameters */
+  const int T = omp_get_max_threads();
+  double* part = calloc((size_t)T * n, 8);
 #pragma omp parallel
   {
-    double* loc = calloc(n, 8); double *gW[MAXL], *gb[MAXL]; size_t o = 0;
+    double* loc = part + (size_t)omp_get_thread_num() * n; double *gW[MAXL], *gb[MAXL]; size_t o = 0;
     for (int l = 0; l < M->L; ++l) { gW[l] = loc + o; o += (size_t)M->dims[l] * M->dims[l + 1]; gb[l] = loc + o; o += M->dims[l + 1]; }
     double *hc[MAXL + 1], *dc[MAXL + 1], *ha[MAXL + 1], *da[MAXL + 1];
     for (int l = 0; l <= C->L; ++l) { hc[l] = malloc(8 * C->dims[l]); dc[l] = malloc(8 * C->dims[l]); }
@@ -251,12 +257,13 @@ static void grads_pass(agent* G, int mode, const double* s, const double* a, con
         memcpy(da[A->L], dc[0] + ns, 8 * na); mlp_bwd1(A, ha, da, gW, gb);
       }
     }
-#pragma omp critical
-    for (int i = 0; i < n; ++i) flatg[i] += loc[i];
-    free(loc);
+    /* (implicit barrier of the loop above: every partial is complete) */
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; ++i) { double acc = 0; for (int k = 0; k < T; ++k) acc += part[(size_t)k * n + i]; flatg[i] = acc; }
     for (int l = 0; l <= C->L; ++l) { free(hc[l]); free(dc[l]); }
     for (int l = 0; l <= A->L; ++l) { free(ha[l]); free(da[l]); }
   }
+  free(part);
 }
 
 /* one DDPG update, PDEagent.jl:363-418.  s,snext [Bu][ns]; a [Bu][na]; r,t [Bu] */

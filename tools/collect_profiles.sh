@@ -11,13 +11,13 @@ mkdir -p $O
 SQ="SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"
 prof() {   # prof <name> <pmc-config> <bench args...>: kernel-trace + stats, then three counter-only passes
   local N=$1 CFG=$2; shift 2
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${N}trace -- python3 bench.py "$@" --no-cpu-baseline > $O/${TAG}_${N}bench_under_rocprof.json 2> $O/${TAG}_${N}rocprof.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${N}trace -- python3 bench.py "$@" --no-cpu-baseline --no-variants > $O/${TAG}_${N}bench_under_rocprof.json 2> $O/${TAG}_${N}rocprof.log
   cp $(ls $O/${TAG}_${N}trace/*/*kernel_stats.csv | head -1) $O/${TAG}_${N}kernel_stats.csv
   [ "$N" = "" ] && python3 tools/trace_timeline.py $O/${TAG}_trace > $O/${TAG}_timeline.txt
   rm -rf $O/${TAG}_${N}trace
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_${N}pmc_fetch -- python3 bench.py "$@" --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_${N}pmc_write -- python3 bench.py "$@" --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc $SQ --output-format csv -d $O/${TAG}_${N}pmc_sq -- python3 bench.py "$@" --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_${N}pmc_fetch -- python3 bench.py "$@" --no-cpu-baseline --no-variants > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_${N}pmc_write -- python3 bench.py "$@" --no-cpu-baseline --no-variants > /dev/null 2>&1
+  rocprofv3 --pmc $SQ --output-format csv -d $O/${TAG}_${N}pmc_sq -- python3 bench.py "$@" --no-cpu-baseline --no-variants > /dev/null 2>&1
   PDEC_PMC_CONFIG=$CFG python3 tools/pmc_traffic.py $O/${TAG}_${N}pmc_fetch $O/${TAG}_${N}pmc_write > $O/${TAG}_${N}pmc_traffic.json
   PDEC_PMC_CONFIG=$CFG python3 tools/pmc_sq_summary.py $O/${TAG}_${N}pmc_sq > $O/${TAG}_${N}sq_counters.json
   rm -rf $O/${TAG}_${N}pmc_fetch $O/${TAG}_${N}pmc_write $O/${TAG}_${N}pmc_sq
