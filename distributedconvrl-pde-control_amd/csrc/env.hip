@@ -1636,6 +1636,27 @@ __device__ __forceinline__ T ksfd_rhs(T u, T force, T* su, int n, int N, T i2dx,
   return f;
 }
 
+// per-workgroup reward sum of the RK4 + FD steps (one trajectory per workgroup), for the batch-mean reward of the DDPG update's
+// reward broadcast -- the same hand-over as the CNAB2 step's (pdec_env_set_reward_partials_out): lanes by xor-shuffle, then the
+// waves in order
+template <class T>
+__device__ __forceinline__ void ksfd_reward_partial(const EnvDev<T>& e, T rmine, T* red, int tid, int nt) {
+  float v = (float)rmine;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if (nt <= 64) {
+    if (tid == 0) e.rsum_out[blockIdx.x] = v;
+    return;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = (T)v;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < (nt + 63) / 64; ++i) tot += (float)red[i];
+    e.rsum_out[blockIdx.x] = tot;
+  }
+}
+
 template <class T, int MODE>  // MODE 0: fused env step, 1: integrate only, 2: rhs only
 __global__ void ksfd_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
                                      const T* __restrict__ action, const T* __restrict__ action_prev,
@@ -1704,8 +1725,9 @@ __global__ void ksfd_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, co
   sense_dots<T>(e, [&](int r, int nn) { return su[r * N + nn]; }, dots, part, tid, nt);
   const int rw = e.mono ? 1 : e.A;
   const size_t sw = e.mono ? (size_t)e.S : (size_t)e.A * e.ns;
-  reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b * rw, tid, nt);
+  const T rmine = reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b * rw, tid, nt);
   featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, state_out + b * sw, tid, nt);
+  if (e.rsum_out) ksfd_reward_partial<T>(e, rmine, red, tid, nt);
   if (done && e.check_max == 2) {
     __syncthreads();
     if (tid == 0) {
@@ -1833,8 +1855,9 @@ __global__ void __launch_bounds__(64) ksfd_wave_step_kernel(EnvDev<T> e, const T
   sense_dots<T>(e, [&](int r, int nn) { return su[r * N + nn]; }, dots, part, tid, nt);
   const int rw = e.mono ? 1 : e.A;
   const size_t sw = e.mono ? (size_t)e.S : (size_t)e.A * e.ns;
-  reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b * rw, tid, nt);
+  const T rmine = reward_traj<T>(e, dots, act, actp, reward_out + (size_t)b * rw, tid, nt);
   featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, state_out + b * sw, tid, nt);
+  if (e.rsum_out) ksfd_reward_partial<T>(e, rmine, red, tid, nt);
   if (done && e.check_max == 2) {
     __syncthreads();
     if (tid == 0) {
@@ -2328,10 +2351,12 @@ int pdec_env_set_simd_sharing(pdec_handle h, int on, int* effective) {
 int pdec_env_set_reward_partials_out(pdec_handle h, void* partial_sums, int* n_partials) {
   Env* E = lookup_as<Env>(h, Kind::Env);
   if (!E) { set_error("pdec_env_set_reward_partials_out: bad handle"); return PDEC_E_HANDLE; }
-  PDEC_REQUIRE(E->cfg.pde_kind == PDEC_PDE_KS_CNAB2 || partial_sums == nullptr,
-               "pdec_env_set_reward_partials_out: provided by the fused KS step only (use pdec_reward_mean elsewhere)");
+  const bool ks = E->cfg.pde_kind == PDEC_PDE_KS_CNAB2, ksfd = E->cfg.pde_kind == PDEC_PDE_KS_RK4_FD;
+  PDEC_REQUIRE(ks || ksfd || partial_sums == nullptr,
+               "pdec_env_set_reward_partials_out: provided by the fused KS steps only (use pdec_reward_mean elsewhere)");
   E->rsum_out = (float*)partial_sums;
-  if (n_partials) *n_partials = (E->cfg.B + 1) / 2;      // one workgroup integrates two trajectories
+  // CNAB2: one workgroup integrates two trajectories; RK4 + FD: one trajectory per workgroup
+  if (n_partials) *n_partials = ks ? (E->cfg.B + 1) / 2 : E->cfg.B;
   return PDEC_OK;
 }
 

@@ -643,6 +643,119 @@ __global__ __launch_bounds__(64 * TC >> (6 - LB)) void fluid_k2w_kernel(FluidDev
   }
 }
 
+// K2p (round 4): the same x-pass as a PERSISTENT, software-pipelined kernel -- one 8-wave workgroup per CU walks its share of
+// the (trajectory, 8-column) tiles; the field tile needed NEXT streams into LDS by LDS-DMA (no VGPR staging) while the waves
+// run the line transforms of the current one out of registers.
+//   * a tile is TC = 8 columns wide: every global access of W and W2 is a whole 128-byte line (8 complex fp64) -- K2w's TC = 4
+//     moves 64-byte half lines -- and only the nl non-zero lines of a column are ever fetched or kept in LDS (pad() is an index map);
+//   * LDS: one field region R, [nl rounded up to 8][8] complex (65 KiB at n = 512), an output staging region S, [n][8] (64 KiB), and
+//     the radix-Q twiddle table (8 KiB).  A DMA piece (1 KiB per wave instruction) is 8 lines x 8 columns, lane l fetching line
+//     8c + (l >> 3), column (l & 7) ^ ((line >> 2) & 7): the column swizzle spreads the 16-byte reads of one wave (lines a
+//     multiple of 4 apart in the digit-reversed order the transforms consume) over the banks; S is swizzled the same way;
+//   * per tile:  [f0 landed] read column | barrier | DMA f1 -> R | inverse -> r0 | [f1 landed] read column | barrier |
+//     DMA f0 of the NEXT tile -> R | inverse -> a | product, forward | column -> S | barrier | 128-byte-line stores of S.
+//     f1 has one transform (~5 us) to land, the next f0 two.  Vector-memory operations retire in issue order on vmcnt (loads
+//     and stores alike): "f0(next) has landed" = at most the 8 store instructions issued behind its DMA are outstanding; the
+//     barriers are raw (s_waitcnt lgkmcnt(0); s_barrier) -- __syncthreads() would drain the prefetch.
+//     (First cut: two field regions, outputs stored straight from the transform's registers -- 16-byte pieces of 64 different
+//     lines per instruction: 9.4 M partial-line writes per launch cost 23-34 us that no amount of overlap hid.)
+// Same arithmetic per column as K2w (bit-identical W2).
+__device__ __forceinline__ void k2p_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void k2p_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NPW: DMA pieces per wave and field = ceil(ceil(nl / 8) / 8); NSU: output elements per thread = n * 8 / 512
+template <int E, int Q, int NPW, int NSU>
+__global__ __launch_bounds__(512) void fluid_k2p_kernel(FluidDev<double> d, const C2<double>* __restrict__ W,
+                                                        C2<double>* __restrict__ W2, int ntiles, int dbg) {
+  typedef WaveFftD<E, Q, 6, true> F;      // radix-Q twiddles from an LDS table: the kernel sits near the 256-VGPR limit of 2 waves / SIMD
+  typedef C2<double> Z;
+  constexpr int TC = 8;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = d.n, p = d.p, nl = d.nl;
+  const int npieces = (nl + 7) / 8;
+  Z* R = reinterpret_cast<Z*>(smem_raw);
+  Z* S = R + (size_t)npieces * 64;        // [n][8]
+  Z* WQ = S + (size_t)n * TC;             // [(Q - 1) E][64]
+  const int tiles_per_b = p / TC;
+  F f;
+  f.init(d.twp, lane, WQ, wv == 0);
+  __syncthreads();
+  // LDS element of (line of the mode in slot jj, my column) or -1 (a pad() zero); recomputed where used (a few integer
+  // operations per slot against a 768-point transform) instead of held in registers
+  auto src_of = [&](int jj) -> int {
+    const int sl = fl_line_of(f.mode_index(jj), n, p, nl);
+    return sl >= 0 ? sl * TC + (wv ^ ((sl >> 2) & 7)) : -1;
+  };
+  // the transform's twiddles are ordinary global loads: they must have landed BEFORE the first DMA is issued -- the compiler
+  // waits vmcnt(0) at the first use of a global load, which would drain every prefetch in flight behind it
+  f.touch();
+  auto dma_tile = [&](int fld, int tile) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));                         // opaque per call: the offsets below are not hoisted (and spilled)
+    const int b = tile / tiles_per_b, ip0 = (tile - b * tiles_per_b) * TC;
+    const char* base = reinterpret_cast<const char*>(W + ((size_t)b * 2 + fld) * nl * p + ip0);      // wave-uniform
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      // piece c: lines 8c .. 8c+7; this lane's element (recomputed per issue: kept in registers the offsets spill, and a
+      // scratch reload is a vector-memory load whose wait drains the DMA queue)
+      int c = wv + 8 * j;
+      c = c < npieces ? c : npieces - 1;
+      int sl = c * 8 + (lv >> 3);
+      sl = sl < nl ? sl : nl - 1;                        // rows past nl - 1 of the last piece: never read
+      const unsigned off = (unsigned)(sl * p + ((lv & 7) ^ ((sl >> 2) & 7))) * (unsigned)sizeof(Z);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                       (__attribute__((address_space(3))) void*)(R + (size_t)c * 64), 16, 0, 0);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  dma_tile(0, tile);
+  const Z zero = mk<double>(0, 0);
+  bool first = true;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    const bool more = next < ntiles;
+    Z r0[F::R], a[F::R];
+    // ---- field 0 has landed: behind its DMA only the NSU stores of the previous tile were issued
+    if (first) k2p_wait_but<0>(); else k2p_wait_but<NSU>();
+    first = false;
+    k2p_lds_barrier();
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) { const int si = src_of(jj); r0[jj] = si >= 0 ? R[si] : zero; }
+    k2p_lds_barrier();                                   // every wave has read field 0
+    dma_tile(1, tile);
+    if (!(dbg & 2)) f.inverse(r0);
+    // ---- field 1 (nothing younger than its DMA is in flight; the stores of the previous tile are older and retire first)
+    k2p_wait_but<0>();
+    k2p_lds_barrier();
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) { const int si = src_of(jj); a[jj] = si >= 0 ? R[si] : zero; }
+    k2p_lds_barrier();                                   // every wave has read field 1
+    if (more) dma_tile(0, next);
+    if (!(dbg & 2)) f.inverse(a);
+    // ---- -(u wx + v wy), both ifft scalings; forward transform of the real product (one column per wave)
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) a[jj] = mk<double>(-(r0[jj].x * a[jj].x + r0[jj].y * a[jj].y) * d.inv2, 0.0);
+    if (!(dbg & 2)) f.forward(a);
+    if (dbg & 4) continue;
+    // ---- chop() along x: kept modes of my column into S (S was last read two barriers ago), then whole-line stores
+#pragma unroll
+    for (int jj = 0; jj < F::R; ++jj) {
+      const int kk = fl_unpad(f.mode_index(jj), n, p);
+      if (kk >= 0) S[kk * TC + (wv ^ ((kk >> 2) & 7))] = a[jj];
+    }
+    k2p_lds_barrier();
+    const int b = tile / tiles_per_b, ip0 = (tile - b * tiles_per_b) * TC;
+    Z* out = W2 + (size_t)b * n * p + ip0;
+#pragma unroll
+    for (int u = 0; u < NSU; ++u) {
+      const int idx = tid + 512 * u, kk = idx >> 3, col = idx & 7;
+      out[(size_t)kk * p + col] = S[kk * TC + (col ^ ((kk >> 2) & 7))];
+    }
+  }
+}
+
 // K3w: one wave per kept line j.  LDS: per wave one n-complex line (digit-reversed -> natural for coalesced global access).
 template <int E, int Q, int LB>
 __global__ __launch_bounds__(256) void fluid_k3w_kernel(FluidDev<double> d, const C2<double>* __restrict__ W2,
@@ -877,12 +990,59 @@ static int fluid_set_attrs(const FluidEnv& E) {
   return PDEC_OK;
 }
 
+// K2 of the wave path: the persistent pipelined form (fluid_k2p_kernel) where it is built -- one line per wave, p a multiple of 8,
+// the DMA piece count instantiated -- else the tile form.  PDEC_FLUID_K2P=0 / 1 forces the choice.
+template <int E, int Q, int LB>
+static int fluid_k2_launch(FluidEnv& Ev, const FluidDev<double>& d) {
+  typedef C2<double> Z;
+  const int B = Ev.cfg.B, p = Ev.p;
+  constexpr int LPW = 64 >> LB;
+  if constexpr (LB == 6) {
+    static const char* env = getenv("PDEC_FLUID_K2P");
+    const int npw = ((Ev.nl + 7) / 8 + 7) / 8;
+    const bool want = env ? env[0] == '1' : Ev.n >= 512;
+    // instantiated: n = 512 (nl = 513 -> 9 DMA pieces per wave, 8 output elements per thread) and n = 256 (257 -> 5, 4)
+    const int nsu = Ev.n * 8 / 512;
+    if (want && p % 8 == 0 && Ev.cfg.ifpad && Ev.n * 8 % 512 == 0 && ((npw == 9 && nsu == 8) || (npw == 5 && nsu == 4))) {
+      static int ncu = 0;
+      if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        PDEC_HIP(hipGetDevice(&dev));
+        PDEC_HIP(hipGetDeviceProperties(&pr, dev));
+        ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+      }
+      const int ntiles = B * (p / 8);
+      static const int dbg = getenv("PDEC_K2P_DBG") ? atoi(getenv("PDEC_K2P_DBG")) : 0;
+      const size_t lds = ((size_t)((Ev.nl + 7) / 8) * 64 + (size_t)Ev.n * 8 + (size_t)(Q > 1 ? (Q - 1) * E : 1) * 64) * 16;
+      const int grid = ntiles < ncu ? ntiles : ncu;
+#define PDEC_K2P(NPW, NSU)                                                                                                     \
+  {                                                                                                                            \
+    static bool attr = false;                                                                                                  \
+    if (!attr) {                                                                                                               \
+      PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fluid_k2p_kernel<E, Q, NPW, NSU>),                            \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                   \
+      attr = true;                                                                                                             \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((fluid_k2p_kernel<E, Q, NPW, NSU>), dim3(grid), dim3(512), lds, Ev.stream, d, Ev.W.as<Z>(),             \
+                       Ev.W2.as<Z>(), ntiles, dbg);                                                                            \
+  }
+      if (npw == 9) PDEC_K2P(9, 8) else PDEC_K2P(5, 4)
+#undef PDEC_K2P
+      return PDEC_OK;
+    }
+  }
+  hipLaunchKernelGGL((fluid_k2w_kernel<E, Q, FL_K2_TC, LB>), dim3((p + FL_K2_TC - 1) / FL_K2_TC, B), dim3(64 * FL_K2_TC / LPW),
+                     (size_t)FL_K2_TC * (p + 1) * 16, Ev.stream, d, Ev.W.as<Z>(), Ev.W2.as<Z>());
+  return PDEC_OK;
+}
+
 // one rhs evaluation fused with an RK4 stage update (mode as in fluid_k3_kernel)
 template <int E, int Q, int LB>
 static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const void* omg_s, const void* phat, const void* f0,
                                  void* acc, void* out, int mode, double ca, double cb) {
   typedef C2<double> Z;
-  const int B = Ev.cfg.B, n = Ev.n, p = Ev.p;
+  const int B = Ev.cfg.B, n = Ev.n;
   constexpr int LPW = 64 >> LB, LPB = 4 * LPW;               // line slots per wave / per 256-thread workgroup
   static bool attr = false;
   if (!attr) {
@@ -900,9 +1060,10 @@ static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const 
   }
   {
     ProfScope ps(&Ev, "fluid_k2", true);
-    for (int r = 0; r < ps.reps; ++r)
-      hipLaunchKernelGGL((fluid_k2w_kernel<E, Q, FL_K2_TC, LB>), dim3((p + FL_K2_TC - 1) / FL_K2_TC, B), dim3(64 * FL_K2_TC / LPW),
-                         (size_t)FL_K2_TC * (p + 1) * 16, Ev.stream, d, Ev.W.as<Z>(), Ev.W2.as<Z>());
+    for (int r = 0; r < ps.reps; ++r) {
+      const int rc = fluid_k2_launch<E, Q, LB>(Ev, d);
+      if (rc) return rc;
+    }
   }
   {
     ProfScope ps(&Ev, "fluid_k3", mode == 0);
@@ -954,7 +1115,7 @@ static int fluid_rhs_launch(FluidEnv& E, const void* omg_s, const void* phat, co
 template <int E, int Q, int LB>
 static int fluid_integrate_wave(FluidEnv& Ev, const FluidDev<double>& d, void* f, const void* phat) {
   typedef C2<double> Z;
-  const int B = Ev.cfg.B, n = Ev.n, p = Ev.p;
+  const int B = Ev.cfg.B, n = Ev.n;
   constexpr int LPW = 64 >> LB, LPB = 4 * LPW;
   static bool attr = false;
   if (!attr) {
@@ -970,8 +1131,7 @@ static int fluid_integrate_wave(FluidEnv& Ev, const FluidDev<double>& d, void* f
   const size_t lds2 = (size_t)LPB * 2 * n * 16;
   auto k2 = [&]() {
     ProfScope ps(&Ev, "fluid_k2");
-    hipLaunchKernelGGL((fluid_k2w_kernel<E, Q, FL_K2_TC, LB>), dim3((p + FL_K2_TC - 1) / FL_K2_TC, B), dim3(64 * FL_K2_TC / LPW),
-                       (size_t)FL_K2_TC * (p + 1) * 16, Ev.stream, d, Ev.W.as<Z>(), Ev.W2.as<Z>());
+    (void)fluid_k2_launch<E, Q, LB>(Ev, d);
   };
   auto k31 = [&](const Z* omg_s, Z* out, int mode, double ca, double cb) {
     ProfScope ps(&Ev, "fluid_k31");

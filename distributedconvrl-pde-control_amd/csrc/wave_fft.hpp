@@ -71,24 +71,42 @@ __device__ __forceinline__ void wx_pair(C2<double>& a, C2<double>& b) {
 // LB = 6: one line per wave (64 lanes).  LB = 5 (E = 2 only): one line per HALF wave -- N = 32 * 2 * Q, e.g. 192 for the
 // fluid's 128^2 training grid padded by 3/2 -- two independent lines per wave (lanes 0-31 and 32-63); the exchanges
 // then only use lane bits 4..0, none of which crosses the halves.
-template <int E, int Q, int LB = 6>
+// WQ_MEM: the radix-Q stage twiddles are read from a [(Q - 1) E][LANES] table (LDS) at use instead of held in (Q - 1) E
+// complex registers -- 32 VGPRs at E = 4, Q = 3 -- for callers at the register limit (fluid_k2p_kernel).
+template <int E, int Q, int LB = 6, bool WQ_MEM = false>
 struct WaveFftD {
   static_assert(LB == 6 || (LB == 5 && E == 2), "half-wave lines need the 1-bit exchange digit");
   static constexpr int LANES = 1 << LB, LPW = 64 / LANES;   // lanes per line, lines per wave
   static constexpr int R = E * Q, N = LANES * R, M = LANES * E;
   static constexpr int NST = E == 4 ? LB / 2 : LB;    // lane-digit stages
-  C2<double> wq[Q > 1 ? (Q - 1) * E : 1];             // radix-Q stage twiddles  tw_N[kq (lane + 64 e)]
+  C2<double> wq[(Q > 1 && !WQ_MEM) ? (Q - 1) * E : 1];   // radix-Q stage twiddles  tw_N[kq (lane + 64 e)]
+  const C2<double>* wq_tab = nullptr;                  // WQ_MEM: the same numbers, element (i, lane) at i * LANES + lane
+  __device__ __forceinline__ C2<double> wqv(int i) const {
+    if constexpr (WQ_MEM) return wq_tab[i * LANES + lane];
+    else return wq[i];
+  }
   C2<double> we[E - 1];                               // register-digit stage     tw_M[k lane]
   C2<double> wl[NST > 1 ? (NST - 1) * (E - 1) : 1];   // lane-digit stages (the last one has none)
   int lane;
 
   // tw: exp(-2 pi i m / N), m < N (global or LDS)
-  __device__ __forceinline__ void init(const C2<double>* tw, int lane_) {
+  // tab (WQ_MEM only): the table's storage; fill: this wave writes it (the caller synchronises before the first transform)
+  __device__ __forceinline__ void init(const C2<double>* tw, int lane_, C2<double>* tab = nullptr, bool fill = false) {
     lane = lane_ & (LANES - 1);      // position inside the line
+    if constexpr (WQ_MEM) {
+      wq_tab = tab;
+      if (fill) {
 #pragma unroll
-    for (int kq = 1; kq < Q; ++kq)
+        for (int kq = 1; kq < Q; ++kq)
 #pragma unroll
-      for (int e = 0; e < E; ++e) wq[(kq - 1) * E + e] = tw[(kq * (lane + LANES * e)) % N];
+          for (int e = 0; e < E; ++e) tab[((kq - 1) * E + e) * LANES + lane] = tw[(kq * (lane + LANES * e)) % N];
+      }
+    } else {
+#pragma unroll
+      for (int kq = 1; kq < Q; ++kq)
+#pragma unroll
+        for (int e = 0; e < E; ++e) wq[(kq - 1) * E + e] = tw[(kq * (lane + LANES * e)) % N];
+    }
 #pragma unroll
     for (int k = 1; k < E; ++k) we[k - 1] = tw[(Q * k * lane) % N];
     int msize = LANES;
@@ -100,6 +118,17 @@ struct WaveFftD {
       for (int k = 1; k < E; ++k) wl[st * (E - 1) + k - 1] = tw[(Q * k * low * (M / msize)) % N];
       msize = msub;
     }
+  }
+  // names every twiddle register in an empty asm statement: the compiler places its wait for the global loads of init()
+  // HERE instead of at their first use (callers that keep LDS-DMA prefetches in flight need those loads retired before the
+  // first DMA is issued, or the first-use wait drains the prefetch queue)
+  __device__ __forceinline__ void touch() const {
+#pragma unroll
+    for (int i = 0; i < ((Q > 1 && !WQ_MEM) ? (Q - 1) * E : 1); ++i) asm volatile("" ::"v"(wq[i].x), "v"(wq[i].y));
+#pragma unroll
+    for (int i = 0; i < E - 1; ++i) asm volatile("" ::"v"(we[i].x), "v"(we[i].y));
+#pragma unroll
+    for (int i = 0; i < (NST > 1 ? (NST - 1) * (E - 1) : 1); ++i) asm volatile("" ::"v"(wl[i].x), "v"(wl[i].y));
   }
   // mode index held in slot j after forward()
   __device__ __forceinline__ int mode_index(int j) const {
@@ -156,7 +185,7 @@ struct WaveFftD {
         for (int qd = 0; qd < Q; ++qd) t[qd] = a[qd * E + e];
         dft_small<Q, -1, double>(t);
 #pragma unroll
-        for (int qd = 1; qd < Q; ++qd) t[qd] = cmul(t[qd], wq[(qd - 1) * E + e]);
+        for (int qd = 1; qd < Q; ++qd) t[qd] = cmul(t[qd], wqv((qd - 1) * E + e));
 #pragma unroll
         for (int qd = 0; qd < Q; ++qd) a[qd * E + e] = t[qd];
       }
@@ -195,7 +224,7 @@ struct WaveFftD {
 #pragma unroll
         for (int qd = 0; qd < Q; ++qd) t[qd] = a[qd * E + e];
 #pragma unroll
-        for (int qd = 1; qd < Q; ++qd) t[qd] = tmul<+1>(t[qd], wq[(qd - 1) * E + e]);
+        for (int qd = 1; qd < Q; ++qd) t[qd] = tmul<+1>(t[qd], wqv((qd - 1) * E + e));
         dft_small<Q, +1, double>(t);
 #pragma unroll
         for (int qd = 0; qd < Q; ++qd) a[qd * E + e] = t[qd];

@@ -118,7 +118,7 @@ class TrainPipeline:
         self.rpart, self.n_rpart = None, 0
         if self.pre_rbar:
             npart = C.c_int()
-            probe = torch.zeros((B + 1) // 2, dtype=torch.float32, device=dev)
+            probe = torch.zeros(B, dtype=torch.float32, device=dev)
             ok = self.lib.pdec_env_set_reward_partials_out(env.handle, _lib.ptr(probe), C.byref(npart)) == 0
             hc = self.policy.behavior_critic.model.handle
             ok = ok and self.lib.pdec_ddpg_set_reward_partials(hc, _lib.ptr(probe), npart.value) == 0    # refused unless fused 3-layer

@@ -339,9 +339,10 @@ int pdec_reward_mean(pdec_handle any_handle, const void* r, int n, void* mean_ou
  * (and being excluded by it) per CU; that form also runs at wave priority 3.  Alone it is slower (37 vs 29 us at C2), so
  * it is off by default.  *effective = 1 when the environment has such a form (KS CNAB2, N = 256, fp32), else 0. */
 int pdec_env_set_simd_sharing(pdec_handle env, int on, int* effective);
-/* the same without any extra launch for the fused KS step + 3-layer fused critic: every later pdec_env_step also writes the
- * sum of the rewards of each of its workgroups (two trajectories each) to partial_sums [*n_partials] (fp32; NULL switches it
- * off), and pdec_ddpg_set_reward_partials hands them to the next critic pass, which adds them in a fixed order. */
+/* the same without any extra launch for the fused KS steps + 3-layer fused critic: every later pdec_env_step also writes the
+ * sum of the rewards of each of its workgroups (CNAB2: two trajectories each, RK4 + FD: one) to partial_sums [*n_partials]
+ * (fp32; NULL switches it off), and pdec_ddpg_set_reward_partials hands them to the next critic pass, which adds them in a
+ * fixed order. */
 int pdec_env_set_reward_partials_out(pdec_handle env, void* partial_sums, int* n_partials);
 int pdec_ddpg_set_reward_partials(pdec_handle critic, const void* partial_sums, int n);
 int pdec_ddpg_set_reward_mean(pdec_handle critic, const void* mean_dev);

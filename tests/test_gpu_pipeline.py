@@ -11,8 +11,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _make(pkg, use_graphs=False, B=64, E=17, lag=2, chunks=(6, 1), use_replay=False, replay_steps=8, nx=256):
-    setup = pkg.KSSetup.bench_C2(nx)
+def _make(pkg, use_graphs=False, B=64, E=17, lag=2, chunks=(6, 1), use_replay=False, replay_steps=8, nx=256, **setup_kw):
+    setup = pkg.KSSetup.bench_C2(nx, **setup_kw)
     s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
     y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
     env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
@@ -226,6 +226,31 @@ def test_checkpoint_keeps_the_device_noise_counter(pkg, tmp_path):
     assert c2.value == ctr.value
     assert pb.policy.rng.integers(0, 1 << 30) == np.random.Generator(np.random.MT19937(3)).integers(0, 1 << 30)
     _same_networks(pa, pb)
+
+
+@pytest.mark.parametrize("nx", [256, 192])
+def test_rk4_fd_step_hands_reward_partials_to_the_critic_pass(pkg, nx):
+    """round 4: the RK4 + periodic-FD steps (one wave per trajectory at N = 256, the general form elsewhere) leave one reward
+    sum per workgroup like the CNAB2 step, so the pipeline needs no pdec_reward_mean launch on the env stream for the
+    reference's reward broadcast (quirk, src/PDEagent.jl:388-393): the partials add up to the rewards written, the pipeline
+    uses them (rpart, stop events), and eager == graph replay bit for bit"""
+    pe = _make(pkg, False, B=64, integrator="rk4_fd", nx=nx)
+    pg = _make(pkg, True, B=64, integrator="rk4_fd", nx=nx)
+    assert pe.rpart is not None and pe.n_rpart == 64 and pe.stop_events
+    pe.run(9); pe.sync()
+    k = pe.tick - 1
+    tot, ref = float(pe.rpart[k % 3].double().sum()), float(pe.rring[k % 3].double().sum())
+    assert abs(tot - ref) <= 1e-5 * abs(ref) and ref != 0.0
+    per_traj = pe.rring[k % 3].double().sum(dim=1)
+    assert torch.allclose(pe.rpart[k % 3].double(), per_traj, rtol=1e-5, atol=1e-6)
+    pg.run(5); pg.capture()
+    pe.run(pg.tick - pe.tick)
+    pg.run(30); pe.run(30)
+    pg.sync(); pe.sync()
+    assert pg.n_graph_launches > 0 and torch.equal(pe.y, pg.y)
+    _same_networks(pe, pg)
+    assert bool(torch.isfinite(pe.y).all())
+    pe.close(); pg.close()
 
 
 @pytest.mark.parametrize("share", [False, True])
