@@ -667,7 +667,7 @@ __device__ __forceinline__ void k2p_wait_but() { asm volatile("s_waitcnt vmcnt(%
 // NPW: DMA pieces per wave and field = ceil(ceil(nl / 8) / 8); NSU: output elements per thread = n * 8 / 512
 template <int E, int Q, int NPW, int NSU>
 __global__ __launch_bounds__(512) void fluid_k2p_kernel(FluidDev<double> d, const C2<double>* __restrict__ W,
-                                                        C2<double>* __restrict__ W2, int ntiles, int dbg) {
+                                                        C2<double>* __restrict__ W2, int ntiles) {
   typedef WaveFftD<E, Q, 6, true> F;      // radix-Q twiddles from an LDS table: the kernel sits near the 256-VGPR limit of 2 waves / SIMD
   typedef C2<double> Z;
   constexpr int TC = 8;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(512) void fluid_k2p_kernel(FluidDev<double> d, cons
     for (int jj = 0; jj < F::R; ++jj) { const int si = src_of(jj); r0[jj] = si >= 0 ? R[si] : zero; }
     k2p_lds_barrier();                                   // every wave has read field 0
     dma_tile(1, tile);
-    if (!(dbg & 2)) f.inverse(r0);
+    f.inverse(r0);
     // ---- field 1 (nothing younger than its DMA is in flight; the stores of the previous tile are older and retire first)
     k2p_wait_but<0>();
     k2p_lds_barrier();
@@ -733,12 +733,11 @@ __global__ __launch_bounds__(512) void fluid_k2p_kernel(FluidDev<double> d, cons
     for (int jj = 0; jj < F::R; ++jj) { const int si = src_of(jj); a[jj] = si >= 0 ? R[si] : zero; }
     k2p_lds_barrier();                                   // every wave has read field 1
     if (more) dma_tile(0, next);
-    if (!(dbg & 2)) f.inverse(a);
+    f.inverse(a);
     // ---- -(u wx + v wy), both ifft scalings; forward transform of the real product (one column per wave)
 #pragma unroll
     for (int jj = 0; jj < F::R; ++jj) a[jj] = mk<double>(-(r0[jj].x * a[jj].x + r0[jj].y * a[jj].y) * d.inv2, 0.0);
-    if (!(dbg & 2)) f.forward(a);
-    if (dbg & 4) continue;
+    f.forward(a);
     // ---- chop() along x: kept modes of my column into S (S was last read two barriers ago), then whole-line stores
 #pragma unroll
     for (int jj = 0; jj < F::R; ++jj) {
@@ -1000,7 +999,7 @@ static int fluid_k2_launch(FluidEnv& Ev, const FluidDev<double>& d) {
   if constexpr (LB == 6) {
     static const char* env = getenv("PDEC_FLUID_K2P");
     const int npw = ((Ev.nl + 7) / 8 + 7) / 8;
-    const bool want = env ? env[0] == '1' : Ev.n >= 512;
+    const bool want = env ? env[0] == '1' : Ev.n >= 256;
     // instantiated: n = 512 (nl = 513 -> 9 DMA pieces per wave, 8 output elements per thread) and n = 256 (257 -> 5, 4)
     const int nsu = Ev.n * 8 / 512;
     if (want && p % 8 == 0 && Ev.cfg.ifpad && Ev.n * 8 % 512 == 0 && ((npw == 9 && nsu == 8) || (npw == 5 && nsu == 4))) {
@@ -1013,7 +1012,6 @@ static int fluid_k2_launch(FluidEnv& Ev, const FluidDev<double>& d) {
         ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
       }
       const int ntiles = B * (p / 8);
-      static const int dbg = getenv("PDEC_K2P_DBG") ? atoi(getenv("PDEC_K2P_DBG")) : 0;
       const size_t lds = ((size_t)((Ev.nl + 7) / 8) * 64 + (size_t)Ev.n * 8 + (size_t)(Q > 1 ? (Q - 1) * E : 1) * 64) * 16;
       const int grid = ntiles < ncu ? ntiles : ncu;
 #define PDEC_K2P(NPW, NSU)                                                                                                     \
@@ -1025,7 +1023,7 @@ static int fluid_k2_launch(FluidEnv& Ev, const FluidDev<double>& d) {
       attr = true;                                                                                                             \
     }                                                                                                                          \
     hipLaunchKernelGGL((fluid_k2p_kernel<E, Q, NPW, NSU>), dim3(grid), dim3(512), lds, Ev.stream, d, Ev.W.as<Z>(),             \
-                       Ev.W2.as<Z>(), ntiles, dbg);                                                                            \
+                       Ev.W2.as<Z>(), ntiles);                                                                                 \
   }
       if (npw == 9) PDEC_K2P(9, 8) else PDEC_K2P(5, 4)
 #undef PDEC_K2P
