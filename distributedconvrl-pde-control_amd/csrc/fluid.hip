@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
 template <int E, int Q, int LB>
 __device__ __forceinline__ void fluid_k1w_body(const FluidDev<double>& d, const C2<double>* Lj, const C2<double>* Lm, int j0, int j1,
                                                int t, int s_mirror, int nhalf, C2<double>* __restrict__ W, int b,
-                                               WaveFftD<E, Q, LB>& f, int l) {
+                                               WaveFftD<E, Q, LB>& f, int l, const double* __restrict__ kt) {
   typedef WaveFftD<E, Q, LB> F;
   typedef C2<double> Z;
   const int n = d.n, p = d.p;
@@ -509,7 +509,7 @@ __device__ __forceinline__ void fluid_k1w_body(const FluidDev<double>& d, const 
     const Z* La = half ? Lm : Lj;     // the line's own spectrum / its mirror's
     const Z* Lb = half ? Lj : Lm;
     const int j = half ? j1 : j0, jm = half ? j0 : j1, s = half ? s_mirror : t;
-    const double kj = j >= 0 ? d.k[j] : 0.0, kjm = jm >= 0 ? d.k[jm] : 0.0;
+    const double kj = j >= 0 ? kt[j] : 0.0, kjm = jm >= 0 ? kt[jm] : 0.0;
 #pragma unroll 1
     for (int fld = 0; fld < 2; ++fld) {
       Z a[F::R];
@@ -522,8 +522,8 @@ __device__ __forceinline__ void fluid_k1w_body(const FluidDev<double>& d, const 
         const bool va = j >= 0 && i >= 0, vm = jm >= 0 && im >= 0;
         Z oa = zero, om_ = zero;
         double ki = 0.0, kim = 0.0;
-        if (va) { oa = La[i]; ki = d.k[i]; }
-        if (vm) { om_ = Lb[im]; kim = d.k[im]; }
+        if (va) { oa = La[i]; ki = kt[i]; }
+        if (vm) { om_ = Lb[im]; kim = kt[im]; }
         if (fld == 0) {   // Z1 = Herm(u) + i Herm(v),  u = i ky psi, v = -i kx psi
           // one reciprocal serves the four quotients of the pair (k^2 of a mode and of its mirror are the same number;
           // omghat * (1 / k^2) instead of omghat / k^2: <= 1 ulp from the reference's quotient)
@@ -562,13 +562,18 @@ __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, cons
   const int n = d.n, p = d.p;
   Z* Lj = reinterpret_cast<Z*>(smem_raw) + (size_t)slot * 2 * n;
   Z* Lm = Lj + n;
+  // the wavenumber table in LDS (round 4): the spectral part reads k of every mode and of its mirror -- 48 dependent global
+  // loads per wave item, each with its own wait, in the middle of the fp64 arithmetic
+  double* kt = reinterpret_cast<double*>(smem_raw + (size_t)4 * F::LPW * 2 * n * sizeof(Z));
+  for (int i = threadIdx.x; i < n; i += 256) kt[i] = d.k[i];
+  __syncthreads();
   // work item t = carried line t (jp = t <= n/2) TOGETHER WITH its mirror line (jp' = p - t): both need exactly the
   // spectrum lines j and mirror(j) -- with the roles swapped -- so one load of the two lines serves two output lines
   // (half the reads of omg and half the exposed load latency per transform); line 0 is its own mirror
   // (pair = 0: one carried line per slot, every line loads its two spectrum lines itself -- more, shorter waves: better
   // for the small grids, n = 128: 12.8 vs 15.2 us)
   const int t = blockIdx.x * 4 * F::LPW + slot, b = blockIdx.y;
-  if (t >= (pair ? n / 2 + 1 : d.nl)) return;             // whole line slot; the kernel has no workgroup barrier
+  if (t >= (pair ? n / 2 + 1 : d.nl)) return;             // whole line slot; no workgroup barrier below this point
   const int jp = fl_line_jp(t, n, p, d.nl), jpm = (p - jp) % p;
   const int s_mirror = fl_line_of(jpm, n, p, d.nl);
   const int j0 = fl_unpad(jp, n, p), j1 = fl_unpad(jpm, n, p);
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(256) void fluid_k1w_kernel(FluidDev<double> d, cons
   F f;
   f.init(d.twp, lane);
   const int nhalf = (pair && s_mirror >= 0 && s_mirror != t) ? 2 : 1;
-  fluid_k1w_body<E, Q, LB>(d, Lj, Lm, j0, j1, t, s_mirror, nhalf, W, b, f, l);
+  fluid_k1w_body<E, Q, LB>(d, Lj, Lm, j0, j1, t, s_mirror, nhalf, W, b, f, l, kt);
 }
 
 // K2w: TC columns per workgroup, one wave per column.  LDS: the [TC][p] column tile (transposition + permuted access).
@@ -879,7 +884,7 @@ __global__ __launch_bounds__(256) void fluid_k31w_kernel(FluidDev<double> d, con
   // ---- K1 of the next right-hand side from the two lines
   const Z* Lmm = (j1 == j0) ? Lj : Lm;              // line 0 is its own mirror
   const int nhalf = (s_mirror >= 0 && s_mirror != t) ? 2 : 1;
-  fluid_k1w_body<E, Q, LB>(d, Lj, Lmm, j0, j1, t, s_mirror, nhalf, W, b, f, l);
+  fluid_k1w_body<E, Q, LB>(d, Lj, Lmm, j0, j1, t, s_mirror, nhalf, W, b, f, l, d.k);
 }
 
 // ------------------------------------------------------------------ wave FFT unit-test entry (pdec_debug_wave_fft)
@@ -1054,7 +1059,7 @@ static int fluid_rhs_launch_wave(FluidEnv& Ev, const FluidDev<double>& d, const 
     ProfScope ps(&Ev, "fluid_k1", true);
     for (int r = 0; r < ps.reps; ++r)
       hipLaunchKernelGGL((fluid_k1w_kernel<E, Q, LB>), dim3(((pair ? n / 2 + 1 : Ev.nl) + LPB - 1) / LPB, B), dim3(256),
-                         (size_t)LPB * 2 * n * 16, Ev.stream, d, (const Z*)omg_s, Ev.W.as<Z>(), pair);
+                         (size_t)LPB * 2 * n * 16 + (size_t)n * 8, Ev.stream, d, (const Z*)omg_s, Ev.W.as<Z>(), pair);
   }
   {
     ProfScope ps(&Ev, "fluid_k2", true);
@@ -1138,7 +1143,7 @@ static int fluid_integrate_wave(FluidEnv& Ev, const FluidDev<double>& d, void* f
   };
   {
     ProfScope ps(&Ev, "fluid_k1");
-    hipLaunchKernelGGL((fluid_k1w_kernel<E, Q, LB>), gpair, dim3(256), lds2, Ev.stream, d, (const Z*)fz, Ev.W.as<Z>(), 1);
+    hipLaunchKernelGGL((fluid_k1w_kernel<E, Q, LB>), gpair, dim3(256), lds2 + (size_t)n * 8, Ev.stream, d, (const Z*)fz, Ev.W.as<Z>(), 1);
   }
   for (int it = 0; it < Ev.cfg.K; ++it) {
     k2(); k31(fz, fs, 1, 0.5 * h, h / 6.0);

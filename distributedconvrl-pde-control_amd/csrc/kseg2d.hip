@@ -16,6 +16,11 @@
 // registers, and only the stage value is exchanged through LDS.  Each thread owns strips of 4 consecutive cells of a
 // row: the west/east neighbours inside a strip come from registers, the north/south rows are 128-bit LDS reads.
 // HBM traffic per sub-step: (1 + 2H/64)^2 reads + 1 write of the tile instead of 4 x (5 fields).
+// (Round 4, tried and dropped: the sub-step as a persistent kernel -- one 512-thread workgroup per CU walking its tiles, the
+// next tile's region, actuator indices and actions streamed into 66 KiB of LDS staging by LDS-DMA behind the current tile's
+// stages, results stored one tile late.  Bit-identical, 75 us per launch against 50: the staging leaves room for ONE
+// workgroup per CU, and the four stages -- LDS write, barrier, LDS reads, ~160 packed instructions, barrier -- are latency
+// chains that need the 16 waves per CU of two independent workgroups more than they need the HBM latency hidden.)
 #include "env.hpp"
 
 namespace pdec {

@@ -1,4 +1,4 @@
-// fp64 / DPP issue-rate micro-benchmark for gfx950 (round 4): cycles per wave-instruction of v_fma_f64, v_add_f64, v_mul_f64 and
+// fp64 / packed-fp32 / DPP issue-rate micro-benchmark for gfx950 (round 4): cycles per wave-instruction of v_fma_f64, v_add_f64, v_mul_f64 and
 // v_cndmask_b32_dpp with 1, 2, 4 waves per SIMD and 1..8 independent chains per wave.  Build: hipcc -O3 --offload-arch=gfx950
 // tools/fp64_issue_micro.hip -o tools/fp64_issue_micro; run on the GPU box.  Output: one line per (op, waves/SIMD, chains).
 #include <hip/hip_runtime.h>
@@ -23,6 +23,9 @@ __global__ void k(double* out, long long* cyc, int iters) {
         if (OP == 2) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
         if (OP == 3) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(u[i]));
         if (OP == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(1.0f), "v"(0.5f));
+        if (OP == 5) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        if (OP == 6) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+        if (OP == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
       }
     }
   }
@@ -59,10 +62,11 @@ void run(const char* name, int wps) {
 }
 
 int main() {
-  for (int w : {1, 2, 4, 8}) {
+  for (int w : {1, 2, 4}) {
     run<0, 1>("fma_f64", w); run<0, 2>("fma_f64", w); run<0, 4>("fma_f64", w); run<0, 8>("fma_f64", w);
     run<1, 4>("add_f64", w); run<2, 4>("mul_f64", w); run<3, 4>("mov_dpp", w); run<3, 1>("mov_dpp", w);
     run<4, 4>("fma_f32", w); run<4, 1>("fma_f32", w);
+    run<5, 4>("pk_fma_f32", w); run<6, 4>("pk_add_f32", w); run<7, 4>("pk_mul_f32", w); run<5, 1>("pk_fma_f32", w);
   }
   return 0;
 }

@@ -5,7 +5,7 @@ pkg = importlib.import_module("distributedconvrl-pde-control_amd")
 L = pkg._lib
 lib = L.init(0)
 setup = pkg.FluidSetup(nx=512, sensors_per_axis=16, variance=0.04)
-env = pkg.PDEenv(setup, B=16, dtype=torch.float64, device="cuda:0", autoreset=False)
+env = pkg.PDEenv(setup, B=int(os.environ.get("B", "16")), dtype=torch.float64, device="cuda:0", autoreset=False)
 y0 = setup.random_init_device(env, np.random.default_rng(0)); env.set_y0(y0)
 zero = torch.zeros_like(env.y)
 L.check(lib.pdec_prof_reset(env.handle)); L.check(lib.pdec_prof_enable(env.handle, 4))
