@@ -117,8 +117,15 @@ class _Lib:
         self._c = cdll
         self._rec = None
 
+    # never part of a recorded control step: object teardown reaches the library from __del__ of unrelated Python objects
+    # whenever the garbage collector runs -- also in the middle of a recording -- and a replayed pdec_destroy names a dead handle
+    _NEVER_RECORDED = frozenset({"pdec_destroy", "pdec_free", "pdec_shutdown"})
+
     def __getattr__(self, name):
         f = getattr(self._c, name)
+        if name in self._NEVER_RECORDED:
+            setattr(self, name, f)
+            return f
 
         def call(*a, _f=f):
             if self._rec is not None:

@@ -2,6 +2,24 @@
 // mlp_mfma2.hip: 2-layer nets).  v_mfma_f32_16x16x4_f32 tiles: an output tile D[16 rows][16 cols] lives in 4 VGPRs
 // per lane (col = lane & 15, row = 4 * (lane >> 4) + r).
 #pragma once
+// gradient slab accesses: non-temporal by default (round 2); -DPDEC_SLAB_NT=0 / -DPDEC_SLAB_NT_LOAD=0 build the plain forms (A/B builds)
+#ifndef PDEC_SLAB_NT
+#define PDEC_SLAB_NT 1
+#endif
+#ifndef PDEC_SLAB_NT_LOAD
+#define PDEC_SLAB_NT_LOAD PDEC_SLAB_NT
+#endif
+#if PDEC_SLAB_NT
+#define PDEC_SLAB_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define PDEC_SLAB_STORE(v, p) (*(p) = (v))
+#endif
+#if PDEC_SLAB_NT_LOAD
+#define PDEC_SLAB_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define PDEC_SLAB_LOAD(p) (*(p))
+#endif
+
 #include "common.hpp"
 
 namespace pdec {
@@ -194,8 +212,8 @@ __device__ __forceinline__ void gemm_pass_paired_store(f32x4 (&acc)[NACC], const
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        __builtin_nontemporal_store(a0[r], &slab[((size_t)(4 * (T0 + p0) + r) * nslab + blockIdx.x) * 64 + l]);
-        if (two) __builtin_nontemporal_store(a1[r], &slab[((size_t)(4 * (T0 + p1) + r) * nslab + blockIdx.x) * 64 + l]);
+        PDEC_SLAB_STORE(a0[r], &slab[((size_t)(4 * (T0 + p0) + r) * nslab + blockIdx.x) * 64 + l]);
+        if (two) PDEC_SLAB_STORE(a1[r], &slab[((size_t)(4 * (T0 + p1) + r) * nslab + blockIdx.x) * 64 + l]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -226,7 +244,7 @@ __device__ __forceinline__ void store_pass(const f32x4 (&acc)[NACC], float* slab
 #pragma unroll
       for (int r = 0; r < 4; ++r)      // written once, read once by the reduction kernel: streaming (non-temporal) stores keep
                                        // the 26 MB of partials from sitting dirty in the XCD's L2 at the kernel boundary
-        __builtin_nontemporal_store(acc[pp][r], &slab[((size_t)(4 * (T0 + p) + r) * nslab + blockIdx.x) * 64 + l]);
+        PDEC_SLAB_STORE(acc[pp][r], &slab[((size_t)(4 * (T0 + p) + r) * nslab + blockIdx.x) * 64 + l]);
     }
   }
 }

@@ -790,7 +790,7 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        __builtin_nontemporal_store(a[r], &g.slab[((size_t)(4 * T + r) * nslab + blockIdx.x) * 64 + l]);
+        PDEC_SLAB_STORE(a[r], &g.slab[((size_t)(4 * T + r) * nslab + blockIdx.x) * 64 + l]);
     }
   }
   st0 = block_sum_lds(st0, red, tid);
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(1024) void fused_finish_ref_kernel(FinishArgs g_in)
         for (; z + 240 < g.nslab; z += 256) {
           float v[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(&sp[(size_t)(z + 16 * u) * 64]);
+          for (int u = 0; u < 16; ++u) v[u] = PDEC_SLAB_LOAD(&sp[(size_t)(z + 16 * u) * 64]);
 #pragma unroll
           for (int u = 0; u < 16; ++u) acc += v[u];
         }
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(FIN_THREADS) void fused_finish_kernel(FinishArgs g_
         for (; z + 240 < g.nslab; z += 256) {
           f32x4 v[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(&sp[(size_t)(z + 16 * u) * 16]);
+          for (int u = 0; u < 16; ++u) v[u] = PDEC_SLAB_LOAD(&sp[(size_t)(z + 16 * u) * 16]);
 #pragma unroll
           for (int u = 0; u < 16; ++u) acc += v[u];
         }

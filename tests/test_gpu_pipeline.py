@@ -336,7 +336,7 @@ def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
     one step wave wrong, tools/det_probe5.py -- which is why they are off by default and refused by a two-stream pipeline.)"""
     monkeypatch.delenv("PDEC_SPLIT", raising=False)
     runs = []
-    for mode in ("free", "drained", "finish_ref"):
+    for mode in ("free", "drained", "finish_ref", "stamped"):
         if mode == "finish_ref":
             monkeypatch.setenv("PDEC_FINISH_REF", "1")
         p = _make(pkg, False, B=64, E=23)
@@ -344,8 +344,13 @@ def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
         if mode == "drained":
             for _ in range(n):
                 p.run(1); torch.cuda.synchronize()
-        else:
-            p.run(n)
+        elif mode == "stamped":
+            # every critic pass in its STAMPED form (s_memtime reads and extra global stores between the phases that
+            # wait on literal vmcnt counts for their LDS-DMA copies): a different instruction stream and timing, same data
+            hc = p.policy.behavior_critic.model.handle
+            for _ in range(n):
+                pkg._lib.check(p.lib.pdec_debug_critic_stamps(hc, 1, None))
+                p.run(1)
         p.sync()
         runs.append(_snapshot(p))
         p.close()

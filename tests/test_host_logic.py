@@ -355,3 +355,19 @@ def test_fluid_error_detection_matches_the_restated_reference(pkg):
         env = _Env(); env.time, env.y = t, y
         hook(pkg.POST_EPISODE_STAGE, _Agent(), env)
         assert (hook.errored_episodes == [1]) == errored, (t, hook.errored_episodes)
+
+
+def test_recorded_steps_never_contain_object_teardown(pkg):
+    """a recording (pipeline._eager) logs the library calls of one control step; pdec_destroy reaches the library from __del__
+    of unrelated objects whenever the garbage collector runs -- it must not be logged (a replay would name a dead handle)"""
+    lib = pkg._lib.load()
+    calls = []
+    lib.record_into(calls)
+    try:
+        h = pkg._lib.Handle(0)
+        lib.pdec_destroy(h)                 # bad handle: returns an error code, which is fine here
+        lib.pdec_version()
+    finally:
+        lib.record_into(None)
+    names = [getattr(f, "__name__", str(f)) for f, _a in calls]
+    assert not any("destroy" in n for n in names) and len(calls) == 1

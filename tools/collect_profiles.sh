@@ -24,42 +24,30 @@ prof() {   # prof <name> <pmc-config> <bench args...>: kernel-trace + stats, the
 }
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "c2" ]; then
   prof "" C2 --steps 100 --warmup 10 --issue eager
-  python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench_default.json
-  python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench.json
-  PDEC_SHARE=1 python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_step_in_64vgpr_form.json
-  # the experimental bf16-split passes, for the record (not bit-stable beside the PDE step: DESIGN.md 3.2a).  They are not in the
-  # product library: make -C distributedconvrl-pde-control_amd/csrc EXPERIMENTAL_SPLIT=1 OBJDIR=../../build_exp OUT=../../build_exp/libpdeconv_split.so
-  XLIB=$PWD/build_exp/libpdeconv_split.so
-  if [ -f $XLIB ]; then
-  PDEC_LIB_PATH=$XLIB PDEC_SPLIT=a PDEC_SPLIT_UNSAFE=1 PDEC_SHARE=1 python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_experimental_split_actor.json
-  PDEC_LIB_PATH=$XLIB PDEC_SPLIT=1 PDEC_SPLIT_UNSAFE=1 PDEC_SHARE=1 PDEC_KICK=0 python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_experimental_split_both.json
-  PDEC_LIB_PATH=$XLIB python -m pytest tests/test_gpu_mlp.py tests/test_gpu_pipeline.py -m gpu -q -k "split" 2>&1 | tail -2 > $O/${TAG}_experimental_split_tests.txt
-  fi
-  # timing independence of the results: exact f32 (default) must give 0; the split actor pass beside the step does not
+  J() { tail -1; }      # the JSON line is the last line of stdout (native libraries' chatter goes to stderr, bench.py protect_stdout)
+  python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-variants 2>/dev/null | J > $O/${TAG}_bench.json
+  PDEC_SHARE=1 python bench.py --steps 200 --warmup 20 --repeats 5 --no-cpu-baseline --no-variants 2>/dev/null | J > $O/${TAG}_bench_step_in_64vgpr_form.json
+  # timing independence of the results: exact f32 (the product) must give 0 differing run lengths
   ( N=120 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
     N=120 SIDE_A="PDEC_FINISH_REF=1" SIDE_B="" python tools/det_probe5.py
     N=60 B=512 E=51 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
-    PDEC_SHARE=1 N=60 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
-    if [ -f $PWD/build_exp/libpdeconv_split.so ]; then
-    export PDEC_LIB_PATH=$PWD/build_exp/libpdeconv_split.so PDEC_SPLIT_UNSAFE=1
-    PDEC_SPLIT=a N=60 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
-    PDEC_SPLIT=a N=60 SIDE_A="" SIDE_B="" python tools/det_probe5.py
-    PDEC_SPLIT=a PDEC_SHARE=1 N=60 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
-    PDEC_SPLIT=a PDEC_SHARE=1 CUMASK=1 N=60 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
-    PDEC_SPLIT=a PDEC_SHARE=1 PDEC_KICK=0 N=60 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
-    PDEC_SPLIT=c PDEC_SHARE=1 PDEC_KICK=0 N=60 SIDE_A="SYNC=1" SIDE_B="" python tools/det_probe5.py
-    fi
   ) 2>&1 | grep "^\[" | cut -c1-400 > $O/${TAG}_timing_independence.txt
-  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --integrator rk4_fd 2>/dev/null | tail -1 > $O/${TAG}_bench_rk4_fd.json
-  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --two-layer 2>/dev/null | tail -1 > $O/${TAG}_bench_two_layer.json
-  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --replay 2>/dev/null | tail -1 > $O/${TAG}_bench_replay.json
-  python bench.py --steps 100 --warmup 10 --no-cpu-baseline --nx 1024 2>/dev/null | tail -1 > $O/${TAG}_bench_c3_shard.json
-  PDEC_BENCH_BACKEND=gloo python bench.py --steps 100 --warmup 10 --no-cpu-baseline --gpus 2 2>/dev/null | tail -1 > $O/${TAG}_bench_n2_gloo_one_gpu.json
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --integrator rk4_fd 2>/dev/null | J > $O/${TAG}_bench_rk4_fd.json
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --two-layer 2>/dev/null | J > $O/${TAG}_bench_two_layer.json
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --replay 2>/dev/null | J > $O/${TAG}_bench_replay.json
+  python bench.py --config C3 --no-cpu-baseline 2>/dev/null | J > $O/${TAG}_bench_c3_shard.json
+  python bench.py --config C3 --no-cpu-baseline --overlap on 2>/dev/null | J > $O/${TAG}_bench_c3_shard_overlapped.json
+  # what N > 1 adds to the update chain besides the wire: the data-parallel launch sequence on a 1-rank RCCL communicator
+  python bench.py --steps 200 --warmup 20 --repeats 5 --split-update --no-cpu-baseline 2>/dev/null | J > $O/${TAG}_bench_split_update_policy.json
+  python bench.py --steps 200 --warmup 20 --repeats 5 --split-update --dp-sync all --no-cpu-baseline 2>/dev/null | J > $O/${TAG}_bench_split_update_all.json
+  PDEC_BENCH_BACKEND=gloo python bench.py --steps 100 --warmup 10 --no-cpu-baseline --gpus 2 2>/dev/null | J > $O/${TAG}_bench_n2_gloo_one_gpu.json
   python tools/bench_rollout.py > $O/${TAG}_bench_rollout.jsonl 2>/dev/null
+  ./tools/fp64_issue_micro > $O/${TAG}_issue_micro.txt 2>/dev/null
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "c4" ]; then
-  prof c4_ C4 --config C4 --steps 10 --warmup 2
+  prof c4_ C4 --config C4 --steps 20 --warmup 12
   python bench.py --config C4 2>/dev/null | tail -1 > $O/${TAG}_c4_bench.json
+  python bench.py --config C4 --no-overlap --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_c4_bench_one_stream.json
   PDEC_BENCH_BACKEND=gloo python bench.py --config C4 --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_c4_bench_n2_gloo_one_gpu.json
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "c5" ]; then
@@ -67,4 +55,7 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "c5" ]; then
   python bench.py --config C5 2>/dev/null | tail -1 > $O/${TAG}_c5_bench.json
   PDEC_BENCH_BACKEND=gloo python bench.py --config C5 --gpus 2 --batch 4 --nx 128 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_c5_bench_n2_gloo_one_gpu_128.json
 fi
+# the driver's own command last (headline + variants + CPU baselines): the PMC traffic files this build's lines cite must be
+# in profiles/ for roofline.traffic -- copy gpurun_out/${TAG}_*pmc_traffic.json there and re-run `python bench.py` if they were not
+python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench_default.json
 ls -la $O | grep ${TAG}_ | awk '{print $5, $9}'

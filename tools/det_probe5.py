@@ -6,7 +6,36 @@ call; the first n at which any quantity differs is reported with the quantities 
 import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from det_probe import make, pkg  # noqa
+pkg = importlib.import_module("distributedconvrl-pde-control_amd")
+
+
+def masked_streams():
+    """two streams on DISJOINT halves of the CUs (hipExtStreamCreateWithCUMask): kernels of the env stream and of the update
+    stream then never share a CU"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    out = []
+    for half in (0, 1):
+        mask = (C.c_uint32 * 8)(*([0xFFFFFFFF] * 4 + [0] * 4 if half == 0 else [0] * 4 + [0xFFFFFFFF] * 4))
+        st = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask)
+        assert rc == 0, rc
+        out.append(torch.cuda.ExternalStream(st.value))
+    return out
+
+
+def make(use_graphs, B=64, E=17):
+    setup = pkg.KSSetup.bench_C2(256)
+    s_env, s_upd = masked_streams() if os.environ.get("CUMASK") == "1" else (torch.cuda.Stream(), torch.cuda.Stream())
+    y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
+                             noise_seed=7, trajectory_length=1)
+    agent.policy.act_noise = 0.3
+    torch.cuda.synchronize()
+    return pkg.TrainPipeline(env, agent, lag=2, episode_steps=E, stream_env=s_env, stream_upd=s_upd, use_graphs=use_graphs,
+                             chunks=(6, 1), noise_seed=99)
+
 
 BASE = {k: os.environ[k] for k in ("PDEC_FINISH_REF", "PDEC_STOP_EVENTS", "PDEC_KICK", "PDEC_SHARE", "PDEC_FAST_EAGER", "SYNC") if k in os.environ}
 B, E = int(os.environ.get("B", "64")), int(os.environ.get("E", "23"))
