@@ -640,6 +640,83 @@ struct FftWave256 {
   }
 };
 
+// ---- N = 1024 (BASELINE configs[2]) on four waves: ONE cross-wave radix-4 stage + the single-wave 256-point engine (round 4).
+// Thread tid of 256 owns x[tid + 256 j], j = 0..3 -- exactly the inputs of the first radix-4 DIF butterfly.  After that
+// butterfly and its twiddle W_1024^(tid k2), slot k2 holds element n1 = tid of the length-256 sub-sequence k2; one LDS round
+// trip hands sub-sequence w to wave w as element lane + 64 j in slot j, and the wave transforms it in registers (FftWave256:
+// lane-digit exchanges by permlane swaps / DPP, no LDS, no barrier).  A transform therefore costs ONE LDS round trip and ONE
+// workgroup barrier where the Stockham engine FftR4<5> needs four of each; the two buffers alternate so the next
+// transform's writes need no second barrier.  Forward leaves mode k = w + 4 (perm(lane) + 64 j) in slot j of wave w (the CNAB2
+// update is pointwise in wave space: only the per-mode constant loads are permuted); the inverse runs the steps backwards
+// and returns to the natural order.
+template <class T>
+struct FftWave1024 {
+  static constexpr int kThreads = 256;
+  static constexpr int N = 1024, NT = 256;
+  FftWave256<T> core;
+  C2<T>* buf[2];
+  C2<T> wx[3];          // W_1024^(tid k), k = 1..3
+  int tid, lane, wv, par;
+  __device__ __forceinline__ void init(unsigned char* smem, const EnvDev<T>& e, int tid_, int) {
+    tid = tid_; lane = tid & 63; wv = tid >> 6; par = 0;
+    buf[0] = reinterpret_cast<C2<T>*>(smem);
+    buf[1] = buf[0] + N;
+    core.tid = lane;
+    core.b1 = (lane & 2) != 0; core.b0 = (lane & 1) != 0;
+    core.buf = buf[0];
+    const int low[3] = {lane, 4 * (lane & 15), 16 * (lane & 3)};
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+      for (int k = 1; k < 4; ++k) core.w[st][k - 1] = e.tw[(4 * k * low[st]) & 1023];      // W_256^x = W_1024^(4x)
+#pragma unroll
+    for (int k = 1; k < 4; ++k) wx[k - 1] = e.tw[(k * tid) & 1023];
+  }
+  static __host__ __device__ size_t lds_complex(int) { return 2 * (size_t)N; }
+  __device__ __forceinline__ int mode_index(int j) const {
+    return wv + 4 * ((lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3) + 64 * j);
+  }
+  __device__ __forceinline__ int phys_index(int j) const { return tid + NT * j; }
+  template <int SGN>
+  __device__ __forceinline__ void run(C2<T> (&a)[KS_MPT]) {
+    C2<T>* X = buf[par];
+    par ^= 1;
+    if (SGN < 0) {   // forward: natural -> (wave, digit-reversed)
+      core.template dft4<-1>(a);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) a[k] = cmul(a[k], wx[k - 1]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) X[k * 256 + tid] = a[k];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = X[wv * 256 + lane + 64 * j];
+      core.template run<-1>(a);
+    } else {         // inverse (unnormalised)
+      core.template run<+1>(a);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) X[wv * 256 + lane + 64 * j] = a[j];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = X[k * 256 + tid];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        C2<T> tw = wx[k - 1];
+        tw.y = -tw.y;
+        a[k] = cmul(a[k], tw);
+      }
+      core.template dft4<+1>(a);
+    }
+  }
+  __device__ __forceinline__ C2<T>* publish(const C2<T> (&a)[KS_MPT]) {
+    __syncthreads();
+    C2<T>* X = buf[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X[tid + NT * j] = a[j];
+    __syncthreads();
+    return X;
+  }
+};
+
 // Compile-time mixed-radix engine for the reference's own grid sizes (KS22: 192 = 4.4.3.4, KS200: 240 = 4.5.3.4,
 // KS500: 600 = 4.5.5.2.3).  Stockham stages like FftGeneric, but (i) every radix, stride and index split is a template
 // constant (no runtime plan walk, divisions by constants, fully unrolled), and (ii) the plan has radices <= 4 at both
@@ -1944,7 +2021,7 @@ static EnvDev<T> make_dev(const Env& E) {
 
 static size_t ks_lds_bytes(const pdec_env_cfg& c, int r4_log) {
   const size_t ts = dtype_size(c.dtype);
-  return (r4_log == 1 ? 1 : ((r4_log == 4 || r4_log == 5) ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
+  return (r4_log == 1 ? 1 : ((r4_log == 4 || r4_log == 5 || r4_log == 10) ? 2 : 3)) * (size_t)c.N * 2 * ts + (4 * (size_t)c.A + 2 * c.S + 16 * c.S + 16) * ts;
 }
 static size_t kseg_lds_bytes(const pdec_env_cfg& c) {
   const size_t ts = dtype_size(c.dtype);
@@ -2005,6 +2082,7 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
     }
     else if (E.r4_log == 4) { if (fused) KS_LAUNCH(FftR4<T COMMA 4>, true); else KS_LAUNCH(FftR4<T COMMA 4>, false); }
     else if (E.r4_log == 5) { if (fused) KS_LAUNCH(FftR4<T COMMA 5>, true); else KS_LAUNCH(FftR4<T COMMA 5>, false); }
+    else if (E.r4_log == 10) { if (fused) KS_LAUNCH(FftWave1024<T>, true); else KS_LAUNCH(FftWave1024<T>, false); }
     else if (E.r4_log == 7) { if (fused) KS_LAUNCH(FftFixed192<T>, true); else KS_LAUNCH(FftFixed192<T>, false); }
     else if (E.r4_log == 8) { if (fused) KS_LAUNCH(FftFixed240<T>, true); else KS_LAUNCH(FftFixed240<T>, false); }
     else if (E.r4_log == 9) { if (fused) KS_LAUNCH(FftFixed600<T>, true); else KS_LAUNCH(FftFixed600<T>, false); }
@@ -2080,6 +2158,7 @@ static int ks_rollout_launch(Env& E, const Mlp& A, const RollArgs<T>& g) {
   if (E.r4_log == 1) KS_ROLL(FftWave256<T>);
   else if (E.r4_log == 4) KS_ROLL(FftR4<T COMMA 4>);
   else if (E.r4_log == 5) KS_ROLL(FftR4<T COMMA 5>);
+  else if (E.r4_log == 10) KS_ROLL(FftWave1024<T>);
   else if (E.r4_log == 7) KS_ROLL(FftFixed192<T>);
   else if (E.r4_log == 8) KS_ROLL(FftFixed240<T>);
   else if (E.r4_log == 9) KS_ROLL(FftFixed600<T>);
@@ -2195,9 +2274,10 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
     int nt = ((N + KS_MPT - 1) / KS_MPT + 63) / 64 * 64;
     PDEC_REQUIRE(nt <= 1024, "N=%d too large for the in-LDS KS kernel (max 4096)", N);
     E->nthreads = nt;
-    // engines: 1 = single-wave register FFT (N = 256), 4 / 5 = radix-4 through LDS (N = 256 / 1024), 0 = generic
+    // engines: 1 = single-wave register FFT (N = 256), 10 = four waves x the same + one cross-wave stage (N = 1024),
+    // 4 / 5 = radix-4 through LDS (N = 256 / 1024, PDEC_KS_LDS_FFT=1), 0 = generic
     E->r4_log = (N == 256 && !getenv("PDEC_KS_GENERIC_FFT")) ? (getenv("PDEC_KS_LDS_FFT") ? 4 : 1)
-                                                              : ((N == 1024 && !getenv("PDEC_KS_GENERIC_FFT")) ? 5 : 0);
+                                                              : ((N == 1024 && !getenv("PDEC_KS_GENERIC_FFT")) ? (getenv("PDEC_KS_LDS_FFT") ? 5 : 10) : 0);
     if (E->r4_log == 0 && !getenv("PDEC_KS_GENERIC_FFT")) {
       // engines 7 / 8 / 9: compile-time plans for the grids of the shipped experiments (KS22, KS200, KS500); one
       // butterfly per thread and stage -> nt = the largest N / radix, rounded up to whole waves

@@ -351,6 +351,8 @@ def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
             for _ in range(n):
                 pkg._lib.check(p.lib.pdec_debug_critic_stamps(hc, 1, None))
                 p.run(1)
+        else:
+            p.run(n)
         p.sync()
         runs.append(_snapshot(p))
         p.close()
