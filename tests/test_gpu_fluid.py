@@ -63,6 +63,22 @@ def test_rhs_matches_oracle(pkg, n, ifpad, herm):
         assert np.abs(out[b] - ref).max() <= 1e-11 * np.abs(ref).max(), (b, np.abs(out[b] - ref).max(), np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n,B", [(256, 14), (512, 5)])
+def test_rhs_with_several_tiles_per_workgroup(pkg, n, B):
+    """round 4: the x-pass of the padded grids is a persistent kernel (fluid_k2p_kernel) whose workgroups WALK their share of
+    the (trajectory, 8-column) tiles with the next tile prefetched behind the current transforms -- 14 x 48 = 672 and 5 x 96 =
+    480 tiles on 256 CUs: two and three tiles per workgroup, ragged (the B = 2 cases above give every workgroup one tile and
+    never enter the loop's steady state).  Right-hand side of every trajectory against the oracle (src/fluid_rk4.jl:134-190)."""
+    from oracle import fluid
+    setup, cfg = _pair(pkg, n, 1, spa=8, variance=0.04)
+    y, p = _fields(cfg, B, seed=7 * n + B, hermitian=True)
+    env = pkg.PDEenv(setup, B=B, dtype=F64)
+    out = _jul(env.rhs(to_dev(_mem(y), F64), to_dev(_mem(p), F64)))
+    for b in range(B):
+        ref = fluid.rhs(cfg, y[b].copy(), p[b])
+        assert np.abs(out[b] - ref).max() <= 1e-11 * np.abs(ref).max(), (b, np.abs(out[b] - ref).max(), np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n,ifpad", [(16, 1), (32, 1), (32, 0), (256, 1), (128, 0)])
 def test_do_step_rk4_matches_oracle(pkg, n, ifpad):
     from oracle import fluid
