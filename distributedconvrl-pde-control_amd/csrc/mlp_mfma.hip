@@ -1245,9 +1245,14 @@ static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
 // bf16-split operands for the 144-wide layers (see SPLIT at the image layout): an EXPERIMENT, off by default.
 // PDEC_SPLIT: 0 = exact f32 everywhere (default), a = actor pass, c = the two forward products of the critic pass, 1 = both.
 // Alone the split passes are bit-stable and faster (actor 31 -> 22 us, critic 60 -> 51 us).  In the two-stream training
-// pipeline, though, a PDE-step wave that shares a CU with a pass issuing v_mfma_f32_16x16x32_bf16 returned wrong fields in a
-// few per cent of 30-step runs (never with the exact-f32 passes, never with the streams on disjoint CU masks, never with the
-// same products issued as two v_mfma_f32_16x16x16_bf16 -- tools/det_probe5.py): TrainPipeline refuses the
+// pipeline, though, runs with a split pass beside the PDE step were NOT bit-reproducible: in a few per cent of 30-step runs
+// the step's fields -- in some collections also the gradients -- differed between two runs that differ only in timing (never
+// with the exact-f32 passes, never with the streams on disjoint CU masks, never with the same products issued as two
+// v_mfma_f32_16x16x16_bf16 -- tools/det_probe5.py, HISTORY.md round 3).  This is an UNRESOLVED NONDETERMINISM, not an
+// established hardware fault: a timing-dependent race inside the split passes themselves (register overlay of the weight
+// image, literal vmcnt waits) has not been excluded; the product's exact-f32 passes share dma_even / lds_barrier / the literal
+// waits and are checked against timing -- free-running, drained, the round-2 finish kernel and the STAMPED form of the critic
+// pass -- bit for bit (tests/test_gpu_pipeline.py::test_results_do_not_depend_on_stream_timing).  TrainPipeline refuses the
 // split forms unless it runs serially.  which: 1 critic pass, 2 actor pass.
 // The PRODUCT library does not contain these kernels (round-2 verdict, item 3: "otherwise record the number and delete the
 // kernel"): they are compiled only with -DPDEC_EXPERIMENTAL_SPLIT (`make EXPERIMENTAL_SPLIT=1 OUT=...`), which is how the

@@ -171,8 +171,8 @@ class TrainPipeline:
             _lib.check(self.lib.pdec_env_set_simd_sharing(env.handle, 1, C.byref(eff)))
             self.simd_sharing = bool(eff.value)
         # the experimental bf16-split forms of the fused passes (PDEC_SPLIT=a|c|1, csrc/mlp_mfma.hip) are bit-stable alone but
-        # NOT beside the PDE step: a step wave sharing a CU with a pass that issues v_mfma_f32_16x16x32_bf16 returned wrong
-        # fields in a few per cent of 30-step runs (tools/det_probe5.py).  Two streams refuse them.
+        # NOT beside the PDE step: a few per cent of 30-step runs differed from a run with other timing (an unresolved
+        # nondeterminism, not root-caused: tools/det_probe5.py; HISTORY.md round 3).  Two streams refuse them.
         if not self.serial and os.environ.get("PDEC_SPLIT", "0")[:1] not in ("", "0") and os.environ.get("PDEC_SPLIT_UNSAFE") != "1":
             raise _lib.PdecError("PDEC_SPLIT=%s: the bf16-split passes are not bit-stable beside the PDE step of a two-stream "
                                  "pipeline; run the pipeline on one stream, or unset PDEC_SPLIT (PDEC_SPLIT_UNSAFE=1 overrides "
