@@ -292,3 +292,20 @@ def test_self_launcher_kills_its_ranks_at_the_deadline():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3000000", "--warmup", "4", "--batch", "64",
                         "--no-cpu-baseline", "--deadline-s", "20"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and ("did not finish within" in r.stderr or "not finished after" in r.stderr), (r.returncode, r.stderr[-2000:])
+
+
+def test_bench_8gpu_line_carries_config_c3_as_a_variant():
+    """`bench.py --gpus 8` appends BASELINE.json configs[2] (KS N = 1024, 512 trajectories per GPU, gradient all-reduce) as
+    variants.C3, run on the same ranks with the reducer the headline verified.  Here the same code path with two ranks on the one
+    GPU (PDEC_BENCH_C3_VARIANT=1 switches it on below 8 ranks), small batch: the line keeps its headline and gains the variant."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PDEC_BENCH_BACKEND="gloo", PDEC_BENCH_C3_VARIANT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "4", "--batch", "32",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and "config C2" not in d["config"]["workload"]   # custom batch
+    v = d["variants"]["C3"]
+    assert "error" not in v, v
+    assert v["n_gpus"] == 2 and v["global_batch"] == 64 and "N=1024" in v["workload"] and v["finite"] and v["value"] > 0
+    assert v["collective_issued_by"] == "torch.distributed"
