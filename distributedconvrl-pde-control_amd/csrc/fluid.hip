@@ -1164,7 +1164,7 @@ static int fluid_integrate_wave(FluidEnv& Ev, const FluidDev<double>& d, void* f
 
 // (A HIP graph of the whole sub-step loop -- 8 K = 320 kernel nodes at the reference's own shape, one trajectory on the 128^2
 // grid -- was measured and dropped: 232 against 260 env-steps/s eager.  That loop is not launch-bound: its kernels run
-// 17-48 workgroups of ~10 us each on 256 CUs)
+// 17-48 workgroups of ~10 us each on 256 CUs, HISTORY.md.)
 static int fluid_integrate(FluidEnv& E, void* f, const void* phat) {
   // measured (B = 16): n = 256: 650 -> 701 env-steps/s fused; n = 512: 76.6 -> 74.5 (the fused waves run six transforms
   // each and the stage's streaming phase no longer overlaps other waves' transforms) -> fused below 512 only

@@ -373,7 +373,7 @@ __device__ __forceinline__ float block_sum_lds(float v, float* red, int tid) {
 // barrier + the issue of the next big copy.  Copies are waited for in issue order with literal vmcnt counts.
 // SPLIT (HP = 144): the two FORWARD 144 x 144 products (target critic, behaviour critic) run on bf16-split operands
 // (layer_split, see the image layout); W2^T dz2 and the weight-gradient products stay exact f32.  (The form with W2^T dz2 split
-// as well was built, measured -- 61 -> 47 us alone -- and taken out: DESIGN.md §3.2a.  This form keeps the tail of the pass,
+// as well was built, measured -- 61 -> 47 us alone -- and taken out: HISTORY.md §3.2a.  This form keeps the tail of the pass,
 // dz1 onwards, instruction for instruction what the exact-f32 pass runs.)  224 VGPRs: see the actor pass.
 template <int MT, int MTA, bool SPLIT = false>
 __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) void ddpg_critic_fused_kernel(FusedArgs g) {
@@ -1256,7 +1256,7 @@ static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
 // split forms unless it runs serially.  which: 1 critic pass, 2 actor pass.
 // The PRODUCT library does not contain these kernels (round-2 verdict, item 3: "otherwise record the number and delete the
 // kernel"): they are compiled only with -DPDEC_EXPERIMENTAL_SPLIT (`make EXPERIMENTAL_SPLIT=1 OUT=...`), which is how the
-// measurements and the reproducer of DESIGN.md §3.2a were built; the product refuses PDEC_SPLIT != 0 with an error.
+// measurements and the reproducer of HISTORY.md §3.2a were built; the product refuses PDEC_SPLIT != 0 with an error.
 #define PDEC_SPLIT_DEFAULT '0'
 static char split_request() {
   const char* e = getenv("PDEC_SPLIT");
@@ -1276,7 +1276,7 @@ static int split_refused() {
 #ifndef PDEC_EXPERIMENTAL_SPLIT
   const char c = split_request();
   if (c != '0') {
-    set_error("PDEC_SPLIT=%c: this libpdeconv.so was built without the experimental bf16-split passes (DESIGN.md 3.2a; "
+    set_error("PDEC_SPLIT=%c: this libpdeconv.so was built without the experimental bf16-split passes (HISTORY.md §3.2a; "
               "make -C csrc EXPERIMENTAL_SPLIT=1 OUT=<other file> builds them)", c);
     return PDEC_E_INVALID;
   }

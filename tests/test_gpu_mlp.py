@@ -300,7 +300,7 @@ def _need_split(pkg):
     """the bf16-split passes exist only in the experimental build of the library (make -C csrc EXPERIMENTAL_SPLIT=1
     OBJDIR=../../build_exp OUT=../../build_exp/libpdeconv_split.so; run these tests with PDEC_LIB_PATH pointing at it)"""
     if not pkg._lib.load().pdec_debug_split_available():
-        pytest.skip("product build of libpdeconv.so: no bf16-split passes (DESIGN.md 3.2a)")
+        pytest.skip("product build of libpdeconv.so: no bf16-split passes (HISTORY.md §3.2a)")
 
 
 def test_product_build_refuses_a_split_request(pkg, monkeypatch):

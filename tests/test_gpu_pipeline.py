@@ -363,7 +363,7 @@ def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
 
 def test_two_stream_pipeline_refuses_the_bf16_split_passes(pkg, monkeypatch):
     """PDEC_SPLIT=a|c|1 selects the experimental bf16-split forms of the fused passes; beside the PDE step they are not
-    bit-stable, so a two-stream TrainPipeline raises instead of training on silently wrong fields; on one
+    bit-stable (HISTORY.md §3.2a), so a two-stream TrainPipeline raises instead of training on silently wrong fields; on one
     stream (nothing runs beside the passes) it is accepted -- by the experimental build of the library; the product build
     does not contain those passes and refuses the request itself."""
     monkeypatch.setenv("PDEC_SPLIT", "a")
