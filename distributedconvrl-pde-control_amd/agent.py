@@ -328,10 +328,13 @@ class Agent:
 
     def __init__(self, policy, trajectory):
         self.policy, self.trajectory = policy, trajectory
+        self.after_push = None                # optional callable run between the PRE_ACT push of (s, a) and the update (run.py:
+                                              # the overlapped run loop releases the env step there)
 
     def __call__(self, *args):
         if len(args) == 1:                    # agent(env) -> action
-            return self.policy(args[0])
+            with _on_stream(getattr(self.trajectory, "stream", None)):     # (start policies create their actions with torch)
+                return self.policy(args[0])
         stage, env = args[0], args[1]
         # the torch ops of the stages run on the networks' stream, like the library kernels they are ordered with
         with _on_stream(getattr(self.trajectory, "stream", None)):
@@ -346,6 +349,8 @@ class Agent:
             action = args[2]
             s = env.state.reshape(-1, env.state.shape[-1])
             tr.push_sa(s, action.reshape(s.shape[0], -1))
+            if self.after_push is not None:
+                self.after_push()
             self._maybe_update()
         elif stage == POST_ACT_STAGE:         # :276-289
             r = env.reward.reshape(-1)

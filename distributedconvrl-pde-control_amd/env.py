@@ -150,10 +150,11 @@ class PDEenv:
         """per-trajectory episode-end flags (src/PDEenv.jl:224-240), materialised on demand so that a control step
         issues no kernel besides the fused env step"""
         if self._done_stale:
-            if self.time >= self.te:
-                self._done.fill_(True)
-            else:
-                torch.ne(self._done_flags, 0, out=self._done)
+            with _on_stream(self.stream):          # ordered behind the env step that wrote the flags
+                if self.time >= self.te:
+                    self._done.fill_(True)
+                else:
+                    torch.ne(self._done_flags, 0, out=self._done)
             self._done_stale = False
         return self._done
 
@@ -181,7 +182,9 @@ class PDEenv:
             return True
         if self.B > 1 and self.autoreset:
             return False
-        return bool(self.done.all().item()) if self.B > 1 else bool(self.done[0].item())
+        d = self.done
+        with _on_stream(self.stream):              # the read-back waits for the env's stream, not for torch's current one
+            return bool(d.all().item()) if self.B > 1 else bool(d[0].item())
 
     def set_y0(self, y0):
         """new initial condition (PDEhook's PRE_EPISODE random re-initialisation, src/PDEhook.jl:42-49): env.y0, env.y,

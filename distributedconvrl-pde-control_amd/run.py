@@ -27,7 +27,111 @@ class StopAfterEpisodeWithMinSteps:
         return stop
 
 
-def run(agent, env, stop_condition, hook):
+def run(agent, env, stop_condition, hook, overlap=None):
+    """RL.jl's `run(agent, env, stop_condition, hook)`: the stage order of every control step is the reference's
+    (action = agent(env); PRE_ACT: push + update; env(action); POST_ACT: push r, t).
+
+    overlap (default: automatic): when the environment and the agent's networks were created on two DIFFERENT explicit
+    streams (`PDEenv(..., stream=s_env)`, `create_agent(..., stream=s_upd)`), the update of a control step and its env step
+    run side by side -- they are independent in the reference's order too: the update samples what was pushed BEFORE this
+    step's action acts, and the env step needs the action only.  Two events per step carry the true dependencies: the env
+    step waits for the acting kernel and the PRE_ACT push (which read env.state) but not for the update; the POST_ACT push and
+    the next acting kernel wait for the env step.  Same kernels, same arguments, same order per stream: results are bit-identical
+    to the one-stream loop.  (For the reference-shaped single-trajectory loops the 20-update launch and the PDE step are of
+    similar length: KS22 4.8 k -> 7+ k env-steps/s.)"""
+    s_env, s_upd = getattr(env, "stream", None), getattr(getattr(agent, "trajectory", None), "stream", None)
+    two = s_env is not None and s_upd is not None and s_env.cuda_stream != s_upd.cuda_stream
+    if overlap is None:
+        overlap = two
+    if overlap and not two:
+        raise ValueError("run(overlap=True) needs the environment and the agent on two explicit streams")
+    if not overlap:
+        if two:                                # two streams without the event protocol would race: order them every stage
+            return _run_two_streams_serial(agent, env, stop_condition, hook, s_env, s_upd)
+        return _run_plain(agent, env, stop_condition, hook)
+    import torch
+    ev_act, ev_env = torch.cuda.Event(), torch.cuda.Event()
+
+    def release_env_step():                    # between the PRE_ACT push and the update (Agent.after_push)
+        ev_act.record(s_upd)
+        s_env.wait_event(ev_act)
+
+    def join():                                # episode boundaries: both streams see everything the other has done
+        s_upd.wait_stream(s_env)
+        s_env.wait_stream(s_upd)
+
+    prev_hook, agent.after_push = getattr(agent, "after_push", None), release_env_step
+    try:
+        hook(PRE_EXPERIMENT_STAGE, agent, env)
+        agent(PRE_EXPERIMENT_STAGE, env)
+        is_stop = False
+        while not is_stop:
+            join()
+            env.reset()
+            join()
+            agent(PRE_EPISODE_STAGE, env)
+            hook(PRE_EPISODE_STAGE, agent, env)
+            join()
+            while not env.is_terminated():
+                action = agent(env)            # s_upd (behind the update of the previous step; waited for the env step below)
+                agent(PRE_ACT_STAGE, env, action)      # s_upd: push (s, a) | release_env_step | update
+                hook(PRE_ACT_STAGE, agent, env)
+                env(action)                    # s_env, beside the update
+                ev_env.record(s_env)
+                s_upd.wait_event(ev_env)       # POST_ACT push and the next acting kernel read what the step wrote
+                agent(POST_ACT_STAGE, env)
+                hook(POST_ACT_STAGE, agent, env)
+                if stop_condition(agent, env):
+                    is_stop = True
+                    break
+            if env.is_terminated():
+                join()
+                agent(POST_EPISODE_STAGE, env)
+                hook(POST_EPISODE_STAGE, agent, env)
+        join()
+        hook(POST_EXPERIMENT_STAGE, agent, env)
+    finally:
+        agent.after_push = prev_hook
+    return hook
+
+
+def _run_two_streams_serial(agent, env, stop_condition, hook, s_env, s_upd):
+    """the plain stage order for an environment and an agent that live on two streams: every stage sees all the other stream did"""
+    def join():
+        s_upd.wait_stream(s_env)
+        s_env.wait_stream(s_upd)
+
+    def staged(f, *a):
+        join()
+        out = f(*a)
+        join()
+        return out
+
+    staged(hook, PRE_EXPERIMENT_STAGE, agent, env)
+    staged(agent, PRE_EXPERIMENT_STAGE, env)
+    is_stop = False
+    while not is_stop:
+        staged(env.reset)
+        staged(agent, PRE_EPISODE_STAGE, env)
+        staged(hook, PRE_EPISODE_STAGE, agent, env)
+        while not env.is_terminated():
+            action = staged(agent, env)
+            staged(agent, PRE_ACT_STAGE, env, action)
+            staged(hook, PRE_ACT_STAGE, agent, env)
+            staged(env, action)
+            staged(agent, POST_ACT_STAGE, env)
+            staged(hook, POST_ACT_STAGE, agent, env)
+            if stop_condition(agent, env):
+                is_stop = True
+                break
+        if env.is_terminated():
+            staged(agent, POST_EPISODE_STAGE, env)
+            staged(hook, POST_EPISODE_STAGE, agent, env)
+    staged(hook, POST_EXPERIMENT_STAGE, agent, env)
+    return hook
+
+
+def _run_plain(agent, env, stop_condition, hook):
     hook(PRE_EXPERIMENT_STAGE, agent, env)
     agent(PRE_EXPERIMENT_STAGE, env)
     is_stop = False

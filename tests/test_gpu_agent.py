@@ -74,6 +74,42 @@ def test_run_loop_trains_and_logs(pkg, B):
     assert np.isfinite(al) and np.isfinite(cl)
 
 
+@pytest.mark.parametrize("which,B,dtype", [("ks22", 1, "f64"), ("ks22", 4, "f32"), ("kseg", 1, "f64")])
+def test_overlapped_run_loop_is_bit_identical_to_the_plain_one(pkg, which, B, dtype):
+    """round 4: run(agent, env, stop, hook) with the environment and the networks on two streams runs the update of a control
+    step beside its env step (two events per step carry the true dependencies; RL.jl's stage order, src/PDEagent.jl:211-361,
+    src/PDEenv.jl:195-241, is untouched).  Same kernels, arguments and per-stream order as the one-stream loop: episode rewards,
+    all four networks, the replay traces and the logged best trajectory are bit-identical -- in the overlapped form, in the
+    two-stream form with every stage joined, and on the default stream."""
+    dt = torch.float64 if dtype == "f64" else torch.float32
+    out = []
+    for mode in ("default_stream", "two_streams_overlap", "two_streams_joined"):
+        setup = (pkg.KSSetup.KS22(te=1.0, update_loops=3, start_steps=2, update_after=2) if which == "ks22"
+                 else pkg.KellerSegelSetup(te=0.06, update_loops=3, start_steps=2, update_after=1))
+        if mode == "default_stream":
+            s_env = s_upd = None
+        else:
+            s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+        env = pkg.PDEenv(setup, B=B, dtype=dt, stream=s_env)
+        agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), trajectory_length=2000, stream=s_upd)
+        hook = pkg.PDEhook(min_best_episode=1, use_random_init=True)
+        pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(30), hook, overlap=None if mode != "two_streams_joined" else False)
+        torch.cuda.synchronize()
+        pol, tr = agent.policy, agent.trajectory
+        snap = [np.asarray(hook.rewards)]
+        for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+            snap += [x.copy() for x in getattr(pol, n).params()]
+        snap += [t.cpu().numpy().copy() for t in (tr.state, tr.action, tr.reward, tr.terminal)]
+        snap += [np.asarray(r["y"]) for r in hook.bestDF] + [np.asarray(r["reward"]) for r in hook.bestDF]
+        snap.append(np.asarray([tr.n_sa, tr.n_rt, len(hook.bestDF), hook.bestepisode]))
+        out.append(snap)
+    assert len(out[0][0]) >= 2 and np.isfinite(out[0][0]).all()
+    for other in out[1:]:
+        assert len(other) == len(out[0])
+        for x, y in zip(out[0], other):
+            assert x.shape == y.shape and np.array_equal(x, y)
+
+
 def test_native_rccl_comm_single_rank(pkg):
     """pdec_comm_* with nranks = 1: all-reduce of the gradient buffer is the identity"""
     import ctypes as C

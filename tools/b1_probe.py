@@ -21,8 +21,10 @@ elif which == "kseg":
 else:
     setup, step_label = pkg.FluidSetup(nx=128), b"fluid_k1"
 steps_per_ep = int(round((setup.te - setup.t0) / setup.dt)) + 1
-env = pkg.PDEenv(setup, B=1, dtype=torch.float64)
-agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0))
+two = "--two-streams" in sys.argv         # update beside the env step (run(): automatic with two explicit streams)
+s_env, s_upd = (torch.cuda.Stream(), torch.cuda.Stream()) if two else (None, None)
+env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
+agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), stream=s_upd)
 hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, collect_bestDF=False)
 pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(60), hook)          # warm-up
 nsteps = 400 if which != "fluid" else 120
