@@ -24,20 +24,42 @@ def _stream_ptr(stream):
     return C.c_void_p(stream.cuda_stream)
 
 
+_FAST_STREAM_SWITCH = hasattr(torch._C, "_cuda_getCurrentStream") and hasattr(torch._C, "_cuda_setStream")
+
+
 class _on_stream:
     """run the torch ops of a block on the handle's stream, so that they are ordered with the library's kernels
-    (torch streams are non-blocking: work on torch's current stream is NOT ordered with another stream's kernels)"""
+    (torch streams are non-blocking: work on torch's current stream is NOT ordered with another stream's kernels).
+    `torch.cuda.stream(s)` costs ~8 us per enter / exit pair in Python (device-index and current-stream look-ups), and the
+    B = 1 run loop enters eight of them per control step: this does the same switch with the two C calls underneath it and
+    skips it altogether when `s` is current already (one process per GPU: the stream's device is the current device)."""
+    __slots__ = ("s", "prev", "ctx")
 
     def __init__(self, stream):
-        self.ctx = torch.cuda.stream(stream) if stream is not None else None
+        self.s, self.prev, self.ctx = stream, None, None
 
     def __enter__(self):
-        if self.ctx is not None:
+        s = self.s
+        if s is None:
+            return
+        if not _FAST_STREAM_SWITCH:
+            self.ctx = torch.cuda.stream(s)
             self.ctx.__enter__()
+            return
+        cur = torch._C._cuda_getCurrentStream(s.device_index)         # (stream_id, device_index, device_type)
+        if cur[0] == s.stream_id:
+            return
+        self.prev = cur
+        torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
 
     def __exit__(self, *a):
         if self.ctx is not None:
             self.ctx.__exit__(*a)
+            self.ctx = None
+        elif self.prev is not None:
+            p = self.prev
+            self.prev = None
+            torch._C._cuda_setStream(stream_id=p[0], device_index=p[1], device_type=p[2])
 
 
 class PDEenv:
