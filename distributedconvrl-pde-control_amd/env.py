@@ -369,19 +369,32 @@ class PDEenv:
             if self.action.data_ptr() in self._adopted:      # never write into a caller-owned buffer
                 self.action = self.action.clone()
         state = self.state
-        _lib.check(self.lib.pdec_rollout(
-            self._h, actor.handle, T, _lib.ptr(self.y), _lib.ptr(state), _lib.ptr(self.action), float(act_noise),
-            float(act_limit), int(bool(learning)), int(seed), int(offset), _lib.ptr(out["reward_sum"]),
-            _lib.ptr(out.get("y")), _lib.ptr(out.get("p")), _lib.ptr(out.get("action")), _lib.ptr(out.get("reward")),
-            _lib.ptr(out["done_any"]), _lib.ptr(out["done_step"])))
+        # the rollout runs on the environment's stream; an actor that lives on another one (an agent created with its own
+        # stream for the overlapped run loop) is moved over for the call, ordered behind whatever last wrote its parameters
+        astream = getattr(actor, "stream", None)
+        moved = (astream is not None and self.stream is not None and astream.cuda_stream != self.stream.cuda_stream)
+        if moved:
+            self.stream.wait_stream(astream)
+            _lib.check(self.lib.pdec_set_stream(actor.handle, _stream_ptr(self.stream)))
+        try:
+            _lib.check(self.lib.pdec_rollout(
+                self._h, actor.handle, T, _lib.ptr(self.y), _lib.ptr(state), _lib.ptr(self.action), float(act_noise),
+                float(act_limit), int(bool(learning)), int(seed), int(offset), _lib.ptr(out["reward_sum"]),
+                _lib.ptr(out.get("y")), _lib.ptr(out.get("p")), _lib.ptr(out.get("action")), _lib.ptr(out.get("reward")),
+                _lib.ptr(out["done_any"]), _lib.ptr(out["done_step"])))
+        finally:
+            if moved:
+                _lib.check(self.lib.pdec_set_stream(actor.handle, _stream_ptr(astream)))
+                astream.wait_stream(self.stream)
         self.prev_state = None
         self.steps += T
         for _ in range(T):                 # the same floating-point sum as T single steps (50 x 0.1 != 5.0)
             self.time += self.dt
-        if self.time >= self.te:           # done = time >= te or blow-up (src/PDEenv.jl:227), as after a step
-            self._done.fill_(True)
-        else:
-            torch.ne(out["done_any"], 0, out=self._done)
+        with _on_stream(self.stream):
+            if self.time >= self.te:       # done = time >= te or blow-up (src/PDEenv.jl:227), as after a step
+                self._done.fill_(True)
+            else:
+                torch.ne(out["done_any"], 0, out=self._done)
         self._done_stale = False
         return out
 

@@ -110,6 +110,32 @@ def test_overlapped_run_loop_is_bit_identical_to_the_plain_one(pkg, which, B, dt
             assert x.shape == y.shape and np.array_equal(x, y)
 
 
+def test_rollout_with_an_actor_that_lives_on_another_stream(pkg):
+    """env.rollout() enqueues on the environment's stream; an actor created on the agent's own stream (the two-stream run
+    loop) is moved over for the call and ordered behind the last writer of its parameters: same rows as the same actor living
+    on the environment's stream (README example: run(...) on two streams, then a rollout)"""
+    import ctypes as C
+    setup = pkg.KSSetup.KS22(te=1.0, update_loops=2, start_steps=2, update_after=2)
+    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+    env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), stream=s_upd)
+    hook = pkg.PDEhook(min_best_episode=1, use_random_init=True)
+    pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(25), hook)
+    a = agent.policy._actor_for(env.dtype, 8)
+    assert a.stream is s_upd
+    env.reset()
+    o1 = env.rollout(a, 9, log=True)
+    a2 = a.clone()
+    s_env.wait_stream(s_upd)
+    pkg._lib.check(a2.lib.pdec_set_stream(a2.handle, C.c_void_p(s_env.cuda_stream)))
+    a2.stream = s_env
+    env.reset()
+    o2 = env.rollout(a2, 9, log=True)
+    torch.cuda.synchronize()
+    assert torch.equal(o1["y"], o2["y"]) and torch.equal(o1["action"], o2["action"]) and bool(torch.isfinite(o1["y"]).all())
+    assert float(o1["action"].abs().max()) > 0
+
+
 def test_native_rccl_comm_single_rank(pkg):
     """pdec_comm_* with nranks = 1: all-reduce of the gradient buffer is the identity"""
     import ctypes as C
