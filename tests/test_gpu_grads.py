@@ -60,8 +60,11 @@ PAIRS = {
     "ks22": (1, 0.6, 7.0, True),              # 1->6->1 / 2->140->1 (KS22.jl)
 }
 
-CASES = [("c2_3layer", 77), ("c2_3layer", 4096), ("c2_3layer", 32768),
-         ("c4_kseg2d", 1500), ("c4_kseg2d", 100352 // 8), ("kseg10_16", 777), ("fluid", 300), ("fluid", 4096), ("ks22", 4100)]
+# Bu = 131 072: config C3's update (1 024 workgroups; the batch-mean reward reduced by its own launch above 256 x 128 columns);
+# Bu = 100 352: config C4's update (2-layer passes walking FOUR chunks of 128 columns per workgroup)
+CASES = [("c2_3layer", 77), ("c2_3layer", 4096), ("c2_3layer", 32768), ("c2_3layer", 131072),
+         ("c4_kseg2d", 1500), ("c4_kseg2d", 100352 // 8), ("c4_kseg2d", 100352), ("kseg10_16", 777), ("fluid", 300), ("fluid", 4096),
+         ("ks22", 4100)]
 
 
 def _inputs(rng, ns, Bu):
@@ -71,6 +74,33 @@ def _inputs(rng, ns, Bu):
     r = -rng.uniform(0, 1, Bu).astype(np.float32)
     t = (rng.uniform(0, 1, Bu) < 0.1).astype(np.float32)
     return s, a, r, t, sn
+
+
+def _away_from_relu_kinks(nn, PA, PC, aa, ac, s, a, r, t, sn, margin=2e-5):
+    """A gradient is discontinuous where a ReLU pre-activation crosses zero: a column whose z sits within rounding of 0 may take
+    the other branch in fp32 than in the fp64 oracle, and ONE such column moves a whole row of dW by |dq| |w| |x| -- at
+    Bu = 100 352 (34 M pre-activations per forward) that happened (hidden unit 221: 1.2e-4 of the array's largest entry, every
+    other entry <= 2e-7).  The comparison is about the arithmetic, not about that measure-zero set: columns with a ReLU
+    pre-activation closer to 0 than `margin` in any forward the gradients go through -- C(s, a), A(s), C(s, A(s)) -- are
+    replaced by copies of safe columns (same Bu)."""
+    f64 = lambda P: [p.astype(np.float64) for p in P]
+    S, A_ = s.astype(np.float64), a.astype(np.float64)
+
+    def near(P, acts, x):
+        _, zs, _ = nn.forward(f64(P), acts, x, keep=True)
+        bad = np.zeros(x.shape[1], dtype=bool)
+        for z, k in zip(zs, acts):
+            if k == nn.RELU:
+                bad |= (np.abs(z) < margin).any(axis=0)
+        return bad
+
+    bad = near(PC, ac, np.concatenate([S, A_])) | near(PA, aa, S)
+    bad |= near(PC, ac, np.concatenate([S, nn.forward(f64(PA), aa, S)]))
+    good = np.flatnonzero(~bad)
+    assert good.size >= 0.9 * bad.size
+    src = np.arange(bad.size)
+    src[bad] = good[np.arange(int(bad.sum())) % good.size]
+    return s[:, src], a[:, src], r[src], t[src], sn[:, src], int(bad.sum())
 
 
 @pytest.mark.parametrize("grad_scale", [1.0, 0.5])
@@ -90,6 +120,7 @@ def test_fused_pass_gradients_match_the_oracle(pkg, name, Bu, quirk, grad_scale)
     At, PAt = make_net(pkg, rng, da, aa, dtype, Bu)
     Ct, PCt = make_net(pkg, rng, dc, ac, dtype, Bu)
     s, a, r, t, sn = _inputs(rng, ns, Bu)
+    s, a, r, t, sn, _ = _away_from_relu_kinks(nn, PA, PC, aa, ac, s, a, r, t, sn)
     f64 = lambda P: [p.astype(np.float64) for p in P]
     g32 = np.float64(np.float32(0.99))
     out = nn.ddpg_losses_and_grads(f64(PA), f64(PC), f64(PAt), f64(PCt), aa, ac, s.astype(np.float64), a.astype(np.float64),
