@@ -217,7 +217,7 @@ def test_rk4_fd_variant_matches_its_oracle(pkg, prec, tol, integ, nx, monkeypatc
 @pytest.mark.parametrize("nx", [1024, 4096, 600, 250, 60])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 3e-5)])
 def test_every_fft_engine_and_size_limit(pkg, nx, prec, tol):
-    """the fused step at the other engine sizes: 1024 (config C3, radix-4 through LDS), 4096 / 2048 (the largest fp32 / fp64 N the
+    """the fused step at the other engine sizes: 1024 (config C3: four waves, one cross-wave radix-4 stage + the single-wave 256-point engine), 4096 / 2048 (the largest fp32 / fp64 N the
     in-LDS kernel accepts), 600 (KS500's grid: factors 2,3,5), 250 (2 * 5^3), 60 (fewer points than a wave has lanes; the reference's kernels need nx >= 50); odd batch"""
     from oracle import ks
     if nx == 4096 and prec == "f64":
