@@ -166,9 +166,12 @@ static double dactf(double a, int k) { return k == 1 ? (a > 0 ? 1 : 0) : (k == 2
 /* one column forward; h[l] = activations (h[0] = x) */
 static void mlp_fwd1(const mlp* M, double* const* h) {
   for (int l = 0; l < M->L; ++l) { const int in = M->dims[l], out = M->dims[l + 1];
-    for (int o = 0; o < out; ++o) { double acc = M->b[l][o]; const double* w = M->W[l] + (size_t)o * in;
-      for (int i = 0; i < in; ++i) acc += w[i] * h[l][i];
-      h[l + 1][o] = actf(acc, M->acts[l]); } }
+    for (int o = 0; o < out; ++o) { double acc = 0; const double* w = M->W[l] + (size_t)o * in; const double* x = h[l];
+      /* the dot product in SIMD lanes (a reassociated sum: ~1e-16 relative, far inside the 1e-12 the twin is held to against the
+       * NumPy oracle); without the pragma the scalar reduction runs at a quarter of the AVX2 rate */
+#pragma omp simd reduction(+:acc)
+      for (int i = 0; i < in; ++i) acc += w[i] * x[i];
+      h[l + 1][o] = actf(acc + M->b[l][o], M->acts[l]); } }
 }
 /* one column backward; d[L] = dL/da_L on entry; accumulates gW/gb if non-NULL; leaves dL/dx in d[0] */
 static void mlp_bwd1(const mlp* M, double* const* h, double* const* d, double* const* gW, double* const* gb) {
