@@ -309,6 +309,13 @@ struct Kseg2dEnv : Env {
   int nx = 0, ny = 0, Sx = 0, Sy = 0, hw = 0, nsub = 1;
   DevBuf sx, sy, a2s_d, cell_act, sums, pbuf, ytmp, done_tmp;
   size_t lds1 = 0, lds2 = 0;
+  hipStream_t stream2 = nullptr;          // second half of the batch during the RK4 sub-steps (k2_integrate)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ~Kseg2dEnv() override {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (stream2) (void)hipStreamDestroy(stream2);
+  }
 };
 
 static Kseg2dEnv& as_k2(Env& E) { return static_cast<Kseg2dEnv&>(E); }
@@ -335,12 +342,17 @@ static constexpr size_t k2_lds(size_t pair_bytes) {   // two planes [RY][RX + 4]
   return (size_t)((pair_bytes == 8 ? 64 : 32) + 8 * NSUB) * (K2_TX + 8 * NSUB + 4) * pair_bytes;
 }
 
+// b0, nb: the trajectories [b0, b0 + nb) of the batch on stream `st` (the whole batch on the environment's stream by default)
 template <class T, int NSUB, int MODE>
-static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_out, int32_t* done, int last) {
+static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_out, int32_t* done, int last, int b0 = 0, int nb = -1,
+                         hipStream_t st = nullptr) {
   constexpr int K2_TY = K2Tile<T>::TY, K2_NT = K2Tile<T>::NT;
-  const dim3 grid(((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2_TY - 1) / K2_TY) * E.cfg.B);
-  hipLaunchKernelGGL((kseg2d_rk4_kernel<T, NSUB, MODE>), grid, dim3(K2_NT), k2_lds<NSUB>(2 * sizeof(T)), E.stream, k2_dev<T>(E),
-                     (const C2<T>*)y_in, (const T*)p, (C2<T>*)y_out, done, last);
+  if (nb < 0) { nb = E.cfg.B; st = E.stream; }
+  const dim3 grid(((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2_TY - 1) / K2_TY) * nb);
+  const size_t cells = (size_t)E.ny * E.nx;
+  const T* pf = (const T*)p + (size_t)b0 * (MODE == 2 ? (size_t)E.cfg.A : cells);
+  hipLaunchKernelGGL((kseg2d_rk4_kernel<T, NSUB, MODE>), grid, dim3(K2_NT), k2_lds<NSUB>(2 * sizeof(T)), st, k2_dev<T>(E),
+                     (const C2<T>*)y_in + (size_t)b0 * cells, pf, (C2<T>*)y_out + (size_t)b0 * cells, done ? done + b0 : nullptr, last);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
@@ -358,6 +370,39 @@ static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, const voi
   const void* src = y_in;
   const void* f = action ? action : p;
   int left = K;
+  // Round 4: the two halves of the batch on two streams -- trajectories are independent, so sub-step k + 1 of one half starts
+  // while sub-step k of the other still drains its last workgroups (a launch is 2 048 workgroups on 512 slots: its tail runs
+  // at falling occupancy 32 times per control step).  C4: 71.1 -> 72.3 k env-steps/s, same fields bit for bit.  Only when each
+  // half still fills the chip (>= 512 tiles); PDEC_KSEG2D_SPLIT=0 / 1 forces it off / on.  (Per-kernel timing passes,
+  // pdec_prof_enable, take the unsplit path: one event pair around the whole sub-step loop of one stream.)
+  static const char* split_env = getenv("PDEC_KSEG2D_SPLIT");
+  const int tiles_half = ((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2Tile<T>::TY - 1) / K2Tile<T>::TY) * (E.cfg.B / 2);
+  const bool split = split_env ? split_env[0] == '1' : tiles_half >= 512;
+  if (split && sizeof(T) == 4 && ns == 1 && E.cfg.B >= 2 && !E.prof) {
+    if (!E.stream2) {
+      PDEC_HIP(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
+      PDEC_HIP(hipEventCreateWithFlags(&E.ev_fork, hipEventDisableTiming));
+      PDEC_HIP(hipEventCreateWithFlags(&E.ev_join, hipEventDisableTiming));
+    }
+    const int h0 = E.cfg.B / 2, h1 = E.cfg.B - h0;
+    PDEC_HIP(hipEventRecord(E.ev_fork, E.stream));
+    PDEC_HIP(hipStreamWaitEvent(E.stream2, E.ev_fork, 0));
+    for (int l = 0; l < launches; ++l) {
+      void* dst = ((launches - 1 - l) & 1) ? E.ytmp.p : y_out;
+      const int last = l == launches - 1;
+      int rc;
+      if constexpr (sizeof(T) == 4) {
+        rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last, 0, h0, E.stream) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last, 0, h0, E.stream);
+        if (rc) return rc;
+        rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last, h0, h1, E.stream2) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last, h0, h1, E.stream2);
+        if (rc) return rc;
+      }
+      src = dst;
+    }
+    PDEC_HIP(hipEventRecord(E.ev_join, E.stream2));
+    PDEC_HIP(hipStreamWaitEvent(E.stream, E.ev_join, 0));
+    return PDEC_OK;
+  }
   for (int l = 0; l < launches; ++l) {
     void* dst = ((launches - 1 - l) & 1) ? E.ytmp.p : y_out;
     const int last = l == launches - 1;
