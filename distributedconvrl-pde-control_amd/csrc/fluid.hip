@@ -957,15 +957,18 @@ struct FluidEnv : Env {
   // round 4: two child environments of B/2 trajectories each (own work arrays, own stream) that fluid_env_step runs side by
   // side -- trajectories are independent, and the kernels of a right-hand side differ in what bounds them (K1 / K2: fp64
   // issue, K3: HBM), so one half's K3 hides under the other half's transforms (n = 512, B = 16: 96.4 -> 100.8 env-steps/s)
-  std::unique_ptr<FluidEnv> half[2];
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int MAXPART = 4;
+  int nparts = 0;
+  std::unique_ptr<FluidEnv> half[MAXPART];
+  hipStream_t pstream[MAXPART] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused: part 0 runs on the environment's stream
+  hipEvent_t ev_fork = nullptr, ev_join[MAXPART] = {nullptr, nullptr, nullptr, nullptr};
   ~FluidEnv() override {
-    half[0].reset();
-    half[1].reset();
+    for (int i = 0; i < MAXPART; ++i) {
+      half[i].reset();
+      if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+      if (pstream[i]) (void)hipStreamDestroy(pstream[i]);
+    }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (stream2) (void)hipStreamDestroy(stream2);
   }
 };
 
@@ -1311,18 +1314,18 @@ int fluid_pde_step(Env& E0, const void* y_in, const void* p, void* y_out, int32_
 int fluid_env_step(Env& E0, const void* y_in, const void* action, const void* action_prev, const void* state_prev,
                    void* y_out, void* p_out, void* state_out, void* reward_out, int32_t* done) {
   FluidEnv& E = as_fluid(E0);
-  if (E.half[0] && E.half[1] && !E.prof) {
-    // the two halves of the batch side by side: every argument is batch-major, so a half is a pointer offset.  (Per-kernel
+  if (E.nparts >= 2 && !E.prof) {
+    // the parts of the batch side by side: every argument is batch-major, so a part is a pointer offset.  (Per-kernel
     // timing passes, pdec_prof_enable, take the whole batch on one stream.)
     const size_t nn = (size_t)E.n * E.n, A = E.cfg.A, ns = (size_t)E.cfg.window * E.cfg.window * E.cfg.temporal_steps;
     auto off = [](const void* p, size_t bytes) -> const void* { return p ? (const char*)p + bytes : nullptr; };
     auto offm = [](void* p, size_t bytes) -> void* { return p ? (char*)p + bytes : nullptr; };
     PDEC_HIP(hipEventRecord(E.ev_fork, E.stream));
-    PDEC_HIP(hipStreamWaitEvent(E.stream2, E.ev_fork, 0));
     int b0 = 0;
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < E.nparts; ++hh) {
       FluidEnv& H = *E.half[hh];
-      H.stream = hh == 0 ? E.stream : E.stream2;
+      H.stream = hh == 0 ? E.stream : E.pstream[hh];
+      if (hh > 0) PDEC_HIP(hipStreamWaitEvent(H.stream, E.ev_fork, 0));
       H.term_out = E.term_out ? (char*)E.term_out + (size_t)b0 * A * 8 : nullptr;
       const int rc = fluid_env_step(H, off(y_in, b0 * nn * 16), off(action, b0 * A * 8), off(action_prev, b0 * A * 8),
                                     off(state_prev, b0 * A * ns * 8), offm(y_out, b0 * nn * 16), offm(p_out, b0 * nn * 16),
@@ -1330,8 +1333,10 @@ int fluid_env_step(Env& E0, const void* y_in, const void* action, const void* ac
       if (rc) return rc;
       b0 += H.cfg.B;
     }
-    PDEC_HIP(hipEventRecord(E.ev_join, E.stream2));
-    PDEC_HIP(hipStreamWaitEvent(E.stream, E.ev_join, 0));
+    for (int hh = 1; hh < E.nparts; ++hh) {
+      PDEC_HIP(hipEventRecord(E.ev_join[hh], E.pstream[hh]));
+      PDEC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[hh], 0));
+    }
     return PDEC_OK;
   }
   void* ph = p_out ? p_out : E.phat.p;
@@ -1455,20 +1460,26 @@ extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, in
   std::unique_ptr<FluidEnv> E;
   int rc = fluid_make(E, *cfg, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s);
   if (rc) return rc;
-  // two half-batch children for the fused env step where a half still fills the chip (padded 512-point grids and up);
-  // PDEC_FLUID_SPLIT=0 / 1 forces it off / on
+  // part-batch children for the fused env step where a part still fills the chip (padded 512-point grids and up): two by
+  // default; PDEC_FLUID_SPLIT=0 off, 1 / 2 two parts, 3 / 4 that many
   static const char* sp = getenv("PDEC_FLUID_SPLIT");
-  const bool split = sp ? sp[0] == '1' : (cfg->N >= 512 && cfg->B >= 8);
-  if (split && cfg->B >= 2) {
+  int np = sp ? atoi(sp) : ((cfg->N >= 512 && cfg->B >= 8) ? 2 : 0);
+  if (np == 1) np = 2;                                  // (PDEC_FLUID_SPLIT=1: on = two parts; 0: off; 3, 4: that many parts)
+  np = std::min(std::min(np, (int)FluidEnv::MAXPART), cfg->B);
+  if (np >= 2) {
     pdec_env_cfg ch = *cfg;
-    const int hb[2] = {cfg->B / 2, cfg->B - cfg->B / 2};
-    for (int i = 0; i < 2; ++i) {
-      ch.B = hb[i];
+    int left = cfg->B;
+    for (int i = 0; i < np; ++i) {
+      ch.B = left / (np - i);
+      left -= ch.B;
       if ((rc = fluid_make(E->half[i], ch, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s))) return rc;
+      if (i > 0) {
+        PDEC_HIP(hipStreamCreateWithFlags(&E->pstream[i], hipStreamNonBlocking));
+        PDEC_HIP(hipEventCreateWithFlags(&E->ev_join[i], hipEventDisableTiming));
+      }
     }
-    PDEC_HIP(hipStreamCreateWithFlags(&E->stream2, hipStreamNonBlocking));
     PDEC_HIP(hipEventCreateWithFlags(&E->ev_fork, hipEventDisableTiming));
-    PDEC_HIP(hipEventCreateWithFlags(&E->ev_join, hipEventDisableTiming));
+    E->nparts = np;
   }
   *h = register_object(std::move(E));
   return PDEC_OK;
