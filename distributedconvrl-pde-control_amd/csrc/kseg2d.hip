@@ -309,12 +309,15 @@ struct Kseg2dEnv : Env {
   int nx = 0, ny = 0, Sx = 0, Sy = 0, hw = 0, nsub = 1;
   DevBuf sx, sy, a2s_d, cell_act, sums, pbuf, ytmp, done_tmp;
   size_t lds1 = 0, lds2 = 0;
-  hipStream_t stream2 = nullptr;          // second half of the batch during the RK4 sub-steps (k2_integrate)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int MAXPART = 4;       // parts of the batch on their own streams during the RK4 sub-steps (k2_integrate)
+  hipStream_t pstream[MAXPART] = {nullptr, nullptr, nullptr, nullptr};        // [0] unused: part 0 runs on the environment's stream
+  hipEvent_t ev_fork = nullptr, ev_join[MAXPART] = {nullptr, nullptr, nullptr, nullptr};
   ~Kseg2dEnv() override {
+    for (int i = 0; i < MAXPART; ++i) {
+      if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+      if (pstream[i]) (void)hipStreamDestroy(pstream[i]);
+    }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (stream2) (void)hipStreamDestroy(stream2);
   }
 };
 
@@ -372,35 +375,45 @@ static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, const voi
   int left = K;
   // Round 4: the two halves of the batch on two streams -- trajectories are independent, so sub-step k + 1 of one half starts
   // while sub-step k of the other still drains its last workgroups (a launch is 2 048 workgroups on 512 slots: its tail runs
-  // at falling occupancy 32 times per control step).  C4: 71.1 -> 72.3 k env-steps/s, same fields bit for bit.  Only when each
-  // half still fills the chip (>= 512 tiles); PDEC_KSEG2D_SPLIT=0 / 1 forces it off / on.  (Per-kernel timing passes,
+  // at falling occupancy 32 times per control step).  Same fields bit for bit.  Only when each part still fills the chip
+  // (>= 512 tiles); PDEC_KSEG2D_SPLIT=0 off, 1 / 2 halves, 3 / 4 that many parts.  (Per-kernel timing passes,
   // pdec_prof_enable, take the unsplit path: one event pair around the whole sub-step loop of one stream.)
   static const char* split_env = getenv("PDEC_KSEG2D_SPLIT");
-  const int tiles_half = ((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2Tile<T>::TY - 1) / K2Tile<T>::TY) * (E.cfg.B / 2);
-  const bool split = split_env ? split_env[0] == '1' : tiles_half >= 512;
-  if (split && sizeof(T) == 4 && ns == 1 && E.cfg.B >= 2 && !E.prof) {
-    if (!E.stream2) {
-      PDEC_HIP(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
-      PDEC_HIP(hipEventCreateWithFlags(&E.ev_fork, hipEventDisableTiming));
-      PDEC_HIP(hipEventCreateWithFlags(&E.ev_join, hipEventDisableTiming));
-    }
-    const int h0 = E.cfg.B / 2, h1 = E.cfg.B - h0;
+  const int tiles_all = ((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2Tile<T>::TY - 1) / K2Tile<T>::TY) * E.cfg.B;
+  // default: three parts once each still fills the chip (C4: 43 / 43 / 42 trajectories, 75.2 k env-steps/s against 72.1 k with
+  // halves and 71.1 k unsplit; FOUR parts -- 5 streams with the update's on 4 hardware queues -- fall to 65 k)
+  int np = split_env ? atoi(split_env) : (tiles_all >= 1536 ? 3 : (tiles_all >= 1024 ? 2 : 0));   // 0: off, 1 / 2: halves, 3 / 4: parts
+  if (np == 1) np = 2;
+  np = std::min(std::min(np, (int)Kseg2dEnv::MAXPART), E.cfg.B);
+  if (np >= 2 && sizeof(T) == 4 && ns == 1 && !E.prof) {
+    if (!E.ev_fork) PDEC_HIP(hipEventCreateWithFlags(&E.ev_fork, hipEventDisableTiming));
+    for (int i = 1; i < np; ++i)
+      if (!E.pstream[i]) {
+        PDEC_HIP(hipStreamCreateWithFlags(&E.pstream[i], hipStreamNonBlocking));
+        PDEC_HIP(hipEventCreateWithFlags(&E.ev_join[i], hipEventDisableTiming));
+      }
     PDEC_HIP(hipEventRecord(E.ev_fork, E.stream));
-    PDEC_HIP(hipStreamWaitEvent(E.stream2, E.ev_fork, 0));
+    for (int i = 1; i < np; ++i) PDEC_HIP(hipStreamWaitEvent(E.pstream[i], E.ev_fork, 0));
     for (int l = 0; l < launches; ++l) {
       void* dst = ((launches - 1 - l) & 1) ? E.ytmp.p : y_out;
       const int last = l == launches - 1;
-      int rc;
       if constexpr (sizeof(T) == 4) {
-        rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last, 0, h0, E.stream) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last, 0, h0, E.stream);
-        if (rc) return rc;
-        rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last, h0, h1, E.stream2) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last, h0, h1, E.stream2);
-        if (rc) return rc;
+        int b0 = 0, left_b = E.cfg.B;
+        for (int i = 0; i < np; ++i) {
+          const int nb = left_b / (np - i);
+          hipStream_t st = i == 0 ? E.stream : E.pstream[i];
+          const int rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last, b0, nb, st) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last, b0, nb, st);
+          if (rc) return rc;
+          b0 += nb;
+          left_b -= nb;
+        }
       }
       src = dst;
     }
-    PDEC_HIP(hipEventRecord(E.ev_join, E.stream2));
-    PDEC_HIP(hipStreamWaitEvent(E.stream, E.ev_join, 0));
+    for (int i = 1; i < np; ++i) {
+      PDEC_HIP(hipEventRecord(E.ev_join[i], E.pstream[i]));
+      PDEC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[i], 0));
+    }
     return PDEC_OK;
   }
   for (int l = 0; l < launches; ++l) {
