@@ -4,7 +4,7 @@ operator surface.  Compute lives in libpdeconv.so (hand-written HIP for gfx950, 
 include/pdeconv.h); this package is the host-side mirror of the reference's interface.
 Import as:  pkg = importlib.import_module("distributedconvrl-pde-control_amd")"""
 from . import _lib  # noqa: F401
-from ._lib import PdecError  # noqa: F401
+from ._lib import PdecError, make_stream, make_streams, destroy_stream  # noqa: F401
 from .setups import KSSetup, KellerSegelSetup, KellerSegel2DSetup, FluidSetup  # noqa: F401
 from .env import PDEenv  # noqa: F401
 from .nna import (HipMLP, ADAM, CustomNeuralNetworkApproximator, create_NNA, create_chain,  # noqa: F401

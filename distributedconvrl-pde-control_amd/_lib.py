@@ -44,6 +44,8 @@ SIGNATURES = {
     "pdec_malloc": [C.POINTER(_vp), _sz], "pdec_free": [_vp],
     "pdec_memcpy_h2d": [_vp, _vp, _sz], "pdec_memcpy_d2h": [_vp, _vp, _sz], "pdec_memset": [_vp, _i, _sz],
     "pdec_set_stream": [Handle, _vp], "pdec_sync": [Handle], "pdec_destroy": [Handle],
+    "pdec_stream_create": [C.POINTER(_vp), _i], "pdec_stream_destroy": [_vp],
+    "pdec_env_part_streams": [Handle, C.POINTER(_i)], "pdec_env_set_part_streams": [Handle, C.POINTER(_vp), _i],
     "pdec_prof_enable": [Handle, _i], "pdec_prof_reset": [Handle],
     "pdec_prof_get": [Handle, C.c_char_p, _pd, C.POINTER(_i)],
     "pdec_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _pd, _pd, _pi32],
@@ -119,7 +121,7 @@ class _Lib:
 
     # never part of a recorded control step: object teardown reaches the library from __del__ of unrelated Python objects
     # whenever the garbage collector runs -- also in the middle of a recording -- and a replayed pdec_destroy names a dead handle
-    _NEVER_RECORDED = frozenset({"pdec_destroy", "pdec_free", "pdec_shutdown"})
+    _NEVER_RECORDED = frozenset({"pdec_destroy", "pdec_free", "pdec_shutdown", "pdec_stream_create", "pdec_stream_destroy"})
 
     def __getattr__(self, name):
         f = getattr(self._c, name)
@@ -213,3 +215,40 @@ def ptr(t):
         assert t.is_contiguous(), "libpdeconv needs contiguous tensors"
         return C.c_void_p(t.data_ptr())
     return C.c_void_p(t.ctypes.data)
+
+
+_streams = {}   # hipStream_t address -> torch.cuda.ExternalStream, kept for the life of the process (see make_stream)
+
+
+def make_stream(level=0, device=0):
+    """A non-blocking HIP stream of the library at priority LEVEL (-1 high, 0 normal, +1 low), wrapped as a
+    torch.cuda.ExternalStream.  Unlike torch.cuda.Stream(priority=...), which hands out the next of a 32-stream pool per
+    level -- whichever hardware queue that position happens to sit on --, every call makes a NEW stream, so two pipeline
+    streams at two different levels never share a hardware queue (include/pdeconv.h, pdec_stream_create).  The stream
+    lives until destroy_stream() or the end of the process: library objects hold its raw address (pdec_set_stream), so
+    it is never released behind their back by garbage collection."""
+    import torch
+    lib = init(device)
+    out = _vp()
+    check(lib.pdec_stream_create(C.byref(out), int(level)))
+    s = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", int(device)))
+    _streams[out.value] = s
+    return s
+
+
+def make_streams(levels, device=0):
+    """make_stream for each level, BACK TO BACK: hardware queues sit on the GPU's four compute pipes in the order they are
+    made, and two busy queues on one pipe take turns -- so the (at most four) streams that work at the same time are made in
+    one go: e.g. `s_env, s_upd, *parts = make_streams((-1, 0, 1, 1))` for a pipeline whose environment runs three parts."""
+    levels = list(levels)
+    if len(levels) > 4:
+        raise PdecError("make_streams: more than four streams cannot sit on four different compute pipes")
+    return [make_stream(lv, device) for lv in levels]
+
+
+def destroy_stream(s):
+    """Releases a stream made by make_stream (the caller guarantees that no library object is still set to it)."""
+    addr = int(s.cuda_stream)
+    if _streams.pop(addr, None) is None:
+        raise PdecError("destroy_stream: not a stream of make_stream")
+    check(load().pdec_stream_destroy(_vp(addr)))

@@ -167,4 +167,19 @@ struct DevBuf {
 // upload a host double array converted to dtype
 int upload_converted(DevBuf& dst, const double* src, size_t n, int dtype);
 
+// A stream for one part of a batch that an environment splits over several streams (fluid.hip, kseg2d.hip), when the caller
+// has not handed over its own (pdec_env_set_part_streams).  Lowest priority level: the environment's own stream carries the
+// rest of the step.  WHERE its hardware queue lands matters more than its level -- queues sit on the GPU's four compute pipes in
+// the order they are made, and two busy queues on one pipe take turns (include/pdeconv.h, pdec_stream_create); a caller that
+// cares makes env / update / part streams back to back and hands the part streams over.
+inline hipError_t create_part_stream(hipStream_t* st) {
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) return e;
+  static const char* lv = getenv("PDEC_PART_LEVEL");   // experiments: -1 / 0 / 1
+  int prio = lv ? atoi(lv) : least;
+  prio = prio > least ? least : (prio < greatest ? greatest : prio);
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+}
+
 }  // namespace pdec

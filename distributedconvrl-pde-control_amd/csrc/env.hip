@@ -2440,6 +2440,22 @@ int pdec_env_set_reward_partials_out(pdec_handle h, void* partial_sums, int* n_p
   return PDEC_OK;
 }
 
+int pdec_env_part_streams(pdec_handle h, int* n) {
+  Env* E = lookup_as<Env>(h, Kind::Env);
+  if (!E) { set_error("pdec_env_part_streams: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(n, "pdec_env_part_streams: null");
+  *n = E->part_streams();
+  return PDEC_OK;
+}
+
+int pdec_env_set_part_streams(pdec_handle h, void* const* hip_streams, int n) {
+  Env* E = lookup_as<Env>(h, Kind::Env);
+  if (!E) { set_error("pdec_env_set_part_streams: bad handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(n >= 0 && (n == 0 || hip_streams), "pdec_env_set_part_streams: bad arguments");
+  for (int i = 0; i < n; ++i) PDEC_REQUIRE(hip_streams[i], "pdec_env_set_part_streams: stream %d is null", i);
+  return E->set_part_streams((const hipStream_t*)hip_streams, n);
+}
+
 int pdec_actuate(pdec_handle h, const void* action, void* p_out) {
   GET_ENV(E, h);
   PDEC_REQUIRE(action && p_out, "pdec_actuate: null");

@@ -44,6 +44,10 @@ struct Env : Object {
   int r4_log = 0;        // 4 / 5: N = 256 / 1024 use the register-resident radix-4 FFT engine
   size_t lds_bytes = 0;
   Env() : Object(Kind::Env) {}
+  // environments that run parts of their batch on streams of their own (fluid.hip, kseg2d.hip): how many such streams the
+  // step uses besides the environment's, and the caller's streams to use instead of the library's (pdec_env_set_part_streams)
+  virtual int part_streams() const { return 0; }
+  virtual int set_part_streams(const hipStream_t*, int) { return PDEC_OK; }
 };
 
 // env.hip: T acting + env steps of the KS environment in one persistent launch (see ks_rollout_kernel); returns

@@ -961,12 +961,27 @@ struct FluidEnv : Env {
   int nparts = 0;
   std::unique_ptr<FluidEnv> half[MAXPART];
   hipStream_t pstream[MAXPART] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused: part 0 runs on the environment's stream
+  bool own_ps[MAXPART] = {false, false, false, false};                     // made by the library (else the caller's)
   hipEvent_t ev_fork = nullptr, ev_join[MAXPART] = {nullptr, nullptr, nullptr, nullptr};
+  int part_streams() const override { return nparts >= 2 ? nparts - 1 : 0; }
+  // the children exist since pdec_fluid_env_create: the caller's streams replace the library's one for one (all of them, or
+  // PDEC_E_INVALID -- a child without a stream of its own would serialise behind another)
+  int set_part_streams(const hipStream_t* s, int n) override {
+    if (nparts < 2) return PDEC_OK;
+    PDEC_REQUIRE(n >= nparts - 1, "pdec_env_set_part_streams: this environment runs %d parts and needs %d streams, got %d", nparts,
+                 nparts - 1, n);
+    for (int i = 1; i < nparts; ++i) {
+      if (pstream[i] && own_ps[i]) PDEC_HIP(hipStreamDestroy(pstream[i]));
+      own_ps[i] = false;
+      pstream[i] = s[i - 1];
+    }
+    return PDEC_OK;
+  }
   ~FluidEnv() override {
     for (int i = 0; i < MAXPART; ++i) {
       half[i].reset();
       if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-      if (pstream[i]) (void)hipStreamDestroy(pstream[i]);
+      if (pstream[i] && own_ps[i]) (void)hipStreamDestroy(pstream[i]);
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
   }
@@ -1474,7 +1489,8 @@ extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, in
       left -= ch.B;
       if ((rc = fluid_make(E->half[i], ch, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s))) return rc;
       if (i > 0) {
-        PDEC_HIP(hipStreamCreateWithFlags(&E->pstream[i], hipStreamNonBlocking));
+        PDEC_HIP(create_part_stream(&E->pstream[i]));
+        E->own_ps[i] = true;
         PDEC_HIP(hipEventCreateWithFlags(&E->ev_join[i], hipEventDisableTiming));
       }
     }

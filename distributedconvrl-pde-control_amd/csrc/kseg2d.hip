@@ -311,11 +311,15 @@ struct Kseg2dEnv : Env {
   size_t lds1 = 0, lds2 = 0;
   static constexpr int MAXPART = 4;       // parts of the batch on their own streams during the RK4 sub-steps (k2_integrate)
   hipStream_t pstream[MAXPART] = {nullptr, nullptr, nullptr, nullptr};        // [0] unused: part 0 runs on the environment's stream
+  bool own_ps[MAXPART] = {false, false, false, false};                       // made by the library (else the caller's)
+  int given_ps = -1;                                                           // >= 0: the caller handed over that many
   hipEvent_t ev_fork = nullptr, ev_join[MAXPART] = {nullptr, nullptr, nullptr, nullptr};
+  int part_streams() const override;
+  int set_part_streams(const hipStream_t* s, int n) override;
   ~Kseg2dEnv() override {
     for (int i = 0; i < MAXPART; ++i) {
       if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-      if (pstream[i]) (void)hipStreamDestroy(pstream[i]);
+      if (pstream[i] && own_ps[i]) (void)hipStreamDestroy(pstream[i]);
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
   }
@@ -360,6 +364,48 @@ static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_
   return PDEC_OK;
 }
 
+// Parts of the batch that the RK4 sub-steps run on streams of their own (fp32, one sub-step per launch).  Only when each part
+// still fills the chip (>= 512 tiles); PDEC_KSEG2D_SPLIT=0 off, 1 / 2 halves, 3 / 4 that many parts.  Default: three parts
+// (C4: 43 / 43 / 42 trajectories, 75.2 k env-steps/s against 72.1 k with halves and 71.1 k unsplit; FOUR parts -- with the
+// update's five busy streams on the four compute pipes, see create_part_stream -- fall to 65 k).
+static int k2_parts(const Kseg2dEnv& E) {
+  static const char* split_env = getenv("PDEC_KSEG2D_SPLIT");
+  const int tiles_all = ((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2Tile<float>::TY - 1) / K2Tile<float>::TY) * E.cfg.B;
+  int np = split_env ? atoi(split_env) : (tiles_all >= 1536 ? 3 : (tiles_all >= 1024 ? 2 : 0));
+  if (np == 1) np = 2;
+  np = std::min(std::min(np, (int)Kseg2dEnv::MAXPART), E.cfg.B);
+  if (E.given_ps >= 0) np = std::min(np, E.given_ps + 1);     // the caller's part streams: no more parts than it handed over
+  return np >= 2 ? np : 0;
+}
+
+static int k2_make_part_streams(Kseg2dEnv& E, int np) {
+  if (!E.ev_fork) PDEC_HIP(hipEventCreateWithFlags(&E.ev_fork, hipEventDisableTiming));
+  for (int i = 1; i < np; ++i)
+    if (!E.pstream[i]) {
+      PDEC_HIP(create_part_stream(&E.pstream[i]));
+      E.own_ps[i] = true;
+    }
+  for (int i = 1; i < np; ++i)
+    if (!E.ev_join[i]) PDEC_HIP(hipEventCreateWithFlags(&E.ev_join[i], hipEventDisableTiming));
+  return PDEC_OK;
+}
+
+int Kseg2dEnv::part_streams() const {
+  if (cfg.dtype != PDEC_F32 || nsub != 1) return 0;
+  const int np = k2_parts(*this);
+  return np ? np - 1 : 0;
+}
+
+int Kseg2dEnv::set_part_streams(const hipStream_t* s, int n) {
+  for (int i = 1; i < MAXPART; ++i) {
+    if (pstream[i] && own_ps[i]) PDEC_HIP(hipStreamDestroy(pstream[i]));
+    own_ps[i] = false;
+    pstream[i] = i - 1 < n ? s[i - 1] : nullptr;
+  }
+  given_ps = std::min(n, MAXPART - 1);
+  return PDEC_OK;
+}
+
 template <class T>
 static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, const void* action, void* y_out, int32_t* done) {
   // K sub-steps, ping-pong between y_out and the scratch field so that the last launch writes y_out; with `action`
@@ -373,25 +419,13 @@ static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, const voi
   const void* src = y_in;
   const void* f = action ? action : p;
   int left = K;
-  // Round 4: the two halves of the batch on two streams -- trajectories are independent, so sub-step k + 1 of one half starts
-  // while sub-step k of the other still drains its last workgroups (a launch is 2 048 workgroups on 512 slots: its tail runs
-  // at falling occupancy 32 times per control step).  Same fields bit for bit.  Only when each part still fills the chip
-  // (>= 512 tiles); PDEC_KSEG2D_SPLIT=0 off, 1 / 2 halves, 3 / 4 that many parts.  (Per-kernel timing passes,
+  // Round 4: the batch in parts on their own streams (k2_parts) -- trajectories are independent, so sub-step k + 1 of one part
+  // starts while sub-step k of another still drains its last workgroups (a launch is 2 048 workgroups on 512 slots: its tail
+  // runs at falling occupancy 32 times per control step).  Same fields bit for bit.  (Per-kernel timing passes,
   // pdec_prof_enable, take the unsplit path: one event pair around the whole sub-step loop of one stream.)
-  static const char* split_env = getenv("PDEC_KSEG2D_SPLIT");
-  const int tiles_all = ((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2Tile<T>::TY - 1) / K2Tile<T>::TY) * E.cfg.B;
-  // default: three parts once each still fills the chip (C4: 43 / 43 / 42 trajectories, 75.2 k env-steps/s against 72.1 k with
-  // halves and 71.1 k unsplit; FOUR parts -- 5 streams with the update's on 4 hardware queues -- fall to 65 k)
-  int np = split_env ? atoi(split_env) : (tiles_all >= 1536 ? 3 : (tiles_all >= 1024 ? 2 : 0));   // 0: off, 1 / 2: halves, 3 / 4: parts
-  if (np == 1) np = 2;
-  np = std::min(std::min(np, (int)Kseg2dEnv::MAXPART), E.cfg.B);
-  if (np >= 2 && sizeof(T) == 4 && ns == 1 && !E.prof) {
-    if (!E.ev_fork) PDEC_HIP(hipEventCreateWithFlags(&E.ev_fork, hipEventDisableTiming));
-    for (int i = 1; i < np; ++i)
-      if (!E.pstream[i]) {
-        PDEC_HIP(hipStreamCreateWithFlags(&E.pstream[i], hipStreamNonBlocking));
-        PDEC_HIP(hipEventCreateWithFlags(&E.ev_join[i], hipEventDisableTiming));
-      }
+  const int np = sizeof(T) == 4 && ns == 1 && !E.prof ? k2_parts(E) : 0;
+  if (np >= 2) {
+    { const int rc = k2_make_part_streams(E, np); if (rc) return rc; }
     PDEC_HIP(hipEventRecord(E.ev_fork, E.stream));
     for (int i = 1; i < np; ++i) PDEC_HIP(hipStreamWaitEvent(E.pstream[i], E.ev_fork, 0));
     for (int l = 0; l < launches; ++l) {
@@ -583,6 +617,13 @@ extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, i
   if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 1, 2>, k2_lds<1>(8)))) return rc;
   if ((rc = set_lds((const void*)kseg2d_rk4_kernel<float, 2, 2>, k2_lds<2>(8)))) return rc;
   if ((rc = set_lds((const void*)kseg2d_rk4_kernel<double, 1, 2>, k2_lds<1>(16)))) return rc;
+  // the part streams are made HERE, with the environment, not at the first step: a stream's hardware queue is made with it,
+  // and queues made one after the other sit on different compute pipes (common.hpp, create_part_stream) -- a caller that makes
+  // its pipeline streams and then the environment gets env / update / part streams side by side
+  if (c.dtype == PDEC_F32 && E->nsub == 1)
+    if (const int np = k2_parts(*E)) {
+      if ((rc = k2_make_part_streams(*E, np))) return rc;
+    }
   *h = register_object(std::move(E));
   return PDEC_OK;
 }

@@ -145,6 +145,36 @@ int pdec_set_stream(pdec_handle h, void* s) {
   return PDEC_OK;
 }
 
+int pdec_stream_create(void** hip_stream, int level) {
+  if (!hip_stream) {
+    set_error("pdec_stream_create: null out pointer");
+    return PDEC_E_INVALID;
+  }
+  // the null stream's hardware queue first, once per process, if nothing has made it yet: made later it would land BETWEEN
+  // the streams a caller makes back to back (include/pdeconv.h), on a pipe of its own choosing
+  static std::once_flag null_queue;
+  std::call_once(null_queue, [] {
+    void* d = nullptr;
+    if (hipMalloc(&d, 4) != hipSuccess) return;
+    (void)hipMemsetAsync(d, 0, 4, nullptr);
+    (void)hipStreamSynchronize(nullptr);
+    (void)hipFree(d);
+  });
+  int least = 0, greatest = 0;   // numerically: least >= 0 >= greatest
+  PDEC_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  int prio = level > least ? least : (level < greatest ? greatest : level);
+  hipStream_t st = nullptr;
+  PDEC_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+  *hip_stream = (void*)st;
+  return PDEC_OK;
+}
+
+int pdec_stream_destroy(void* hip_stream) {
+  if (!hip_stream) return PDEC_OK;
+  PDEC_HIP(hipStreamDestroy((hipStream_t)hip_stream));
+  return PDEC_OK;
+}
+
 int pdec_sync(pdec_handle h) {
   Object* o = lookup(h);
   if (!o) {

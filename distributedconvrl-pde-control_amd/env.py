@@ -64,8 +64,11 @@ class _on_stream:
 
 class PDEenv:
     def __init__(self, setup, B=1, dtype=torch.float32, device="cuda:0", y0=None, action0=None, stream=None, history=1,
-                 autoreset=None):
-        """autoreset (default: B > 1): a trajectory whose blow-up flag is raised by a step restarts from its initial
+                 autoreset=None, part_streams=None):
+        """part_streams: streams for the parts of the batch that the 2-D Keller-Segel and fluid environments step side by
+        side (`n_part_streams` tells how many the step uses), made by the caller back to back with its pipeline streams
+        (`make_streams`, include/pdeconv.h: pdec_stream_create) instead of by the library; kept alive by this object.
+        autoreset (default: B > 1): a trajectory whose blow-up flag is raised by a step restarts from its initial
         condition IN that step (y, state, action rows <- y0, featurize(y0), action0; pdec_env_autoreset), its terminal
         transition having been produced; the reference (B = 1) ends the whole episode instead (src/PDEenv.jl:226-240),
         which a lock-stepped batch cannot do for one trajectory -- without the reset the blown-up trajectory would feed
@@ -101,6 +104,9 @@ class PDEenv:
         self.stream = stream
         if stream is not None:
             _lib.check(self.lib.pdec_set_stream(self._h, _stream_ptr(stream)))
+        self.part_streams = None
+        if part_streams is not None:
+            self.set_part_streams(part_streams)
         ns, A = setup.state_shape
         self._yshape = (self.B,) + tuple(reversed(setup.y_shape)) + ((2,) if self.is_fluid else ())
         self._sshape = (self.B, A, ns)
@@ -136,6 +142,21 @@ class PDEenv:
         self.reset()
 
     # ---- helpers
+
+    @property
+    def n_part_streams(self):
+        """streams besides its own that a step of this environment uses for parts of the batch (0: none)"""
+        n = C.c_int(0)
+        _lib.check(self.lib.pdec_env_part_streams(self._h, C.byref(n)))
+        return n.value
+
+    def set_part_streams(self, streams):
+        """hands the caller's part streams to the environment (pdec_env_set_part_streams); same results bit for bit"""
+        streams = list(streams)
+        arr = (C.c_void_p * max(len(streams), 1))(*[s.cuda_stream for s in streams])
+        _lib.check(self.lib.pdec_env_set_part_streams(self._h, arr, len(streams)))
+        self.part_streams = streams
+
     def _to_mem(self, a):
         """Julia-shaped host array -> memory image (column-major == reversed axes); complex fields get a
         trailing (re, im) axis"""

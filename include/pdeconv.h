@@ -70,6 +70,22 @@ int pdec_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int pdec_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int pdec_memset(void* dptr, int value, size_t bytes);
 int pdec_set_stream(pdec_handle h, void* hip_stream);   /* hipStream_t; NULL = null stream */
+/* A non-blocking stream at an explicit priority LEVEL (-1 high, 0 normal, +1 low; clamped to the device's range), made together
+ * with its hardware queue.  Why a library call: on this GPU a process's hardware queues are spread over FOUR compute pipes in
+ * the order they are made, queue i on pipe i mod 4, and two BUSY queues on one pipe take turns instead of running side by
+ * side (tools/c4_stream_matrix.sh, 21 creation orders: config C4 runs at 75 k env-steps/s when the env, update and two
+ * part-batch streams sit on four pipes and at 40 - 46 k when two of them share one; HIP also lets at most four queues exist
+ * per level and maps further streams of that level onto those).  So the streams that work at the same time -- env stream,
+ * update stream, the part streams of pdec_env_set_part_streams -- are made BACK TO BACK by one caller, at most four of them,
+ * and kept for the life of the process (queues made after others were destroyed take over the freed slots in an order of
+ * their own: a fresh set per pipeline, the old one released, was measured worse than one set used again and again).  The
+ * first call also makes the null stream's queue if nothing has yet, so that it cannot land between the caller's later.  A
+ * framework's pooled streams give no such control (torch makes each pool stream at its first use).  hipGraph launches make
+ * queues of their own for parallel branches; with all four pipes taken by busy streams they share one (C2: graph replay 190 -
+ * 260 instead of 125 us per step -- eager issue, 110 us, is what the pipeline uses).  The reference has no counterpart
+ * (single stream). */
+int pdec_stream_create(void** hip_stream, int level);
+int pdec_stream_destroy(void* hip_stream);
 int pdec_sync(pdec_handle h);                           /* hipStreamSynchronize of h's stream */
 int pdec_destroy(pdec_handle h);                        /* any handle kind */
 
@@ -344,6 +360,14 @@ int pdec_env_set_simd_sharing(pdec_handle env, int on, int* effective);
  * (fp32; NULL switches it off), and pdec_ddpg_set_reward_partials hands them to the next critic pass, which adds them in a
  * fixed order. */
 int pdec_env_set_reward_partials_out(pdec_handle env, void* partial_sums, int* n_partials);
+/* Environments that run parts of their batch on streams of their own (2-D Keller-Segel: the RK4 sub-steps of C4 in three
+ * parts; fluid: child environments) make those streams themselves by default.  pdec_env_part_streams tells how many the step
+ * uses besides the environment's own; pdec_env_set_part_streams hands over the caller's instead (made back to back with its
+ * pipeline streams, see pdec_stream_create; the library's are released, the caller's are never destroyed by the library).
+ * Fewer than asked for: 2-D Keller-Segel runs that many parts + 1 (0: unsplit), fluid refuses (PDEC_E_INVALID).  Environments
+ * without parts accept and ignore the call.  Same results bit for bit either way. */
+int pdec_env_part_streams(pdec_handle env, int* n);
+int pdec_env_set_part_streams(pdec_handle env, void* const* hip_streams, int n);
 int pdec_ddpg_set_reward_partials(pdec_handle critic, const void* partial_sums, int n);
 int pdec_ddpg_set_reward_mean(pdec_handle critic, const void* mean_dev);
 

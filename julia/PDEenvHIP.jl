@@ -249,6 +249,23 @@ end
 #   RLBase.update!(p::CustomDDPGPolicy{<:CustomNeuralNetworkApproximator{PDEenvHIP.HipMLP}}, batch::NamedTuple{SARTS}) =
 #       PDEenvHIP.ddpg_update!(p, batch)
 
+# ---- streams (the reference runs on one; a two-stream caller makes its streams here, BACK TO BACK: env, update, then the part
+# streams an environment asks for -- hardware queues sit on the GPU's four compute pipes in the order they are made, see
+# include/pdeconv.h at pdec_stream_create) ---------------------------------------------------------------------------------
+function stream_create(level::Integer = 0)          # -1 high, 0 normal, +1 low; returns the hipStream_t
+    s = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pdec_stream_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), s, level))
+    s[]
+end
+stream_destroy(s::Ptr{Cvoid}) = check(ccall((:pdec_stream_destroy, LIB), Cint, (Ptr{Cvoid},), s))
+function env_part_streams(env::UInt64)
+    n = Ref{Cint}(0)
+    check(ccall((:pdec_env_part_streams, LIB), Cint, (UInt64, Ref{Cint}), env, n))
+    Int(n[])
+end
+env_set_part_streams(env::UInt64, streams::Vector{Ptr{Cvoid}}) =
+    check(ccall((:pdec_env_set_part_streams, LIB), Cint, (UInt64, Ptr{Ptr{Cvoid}}, Cint), env, streams, length(streams)))
+
 # ---- multi-GPU (one Julia process per GPU; the reference itself is single-process) -----------------------------------
 function comm_unique_id()
     id = zeros(UInt8, 128)

@@ -7,7 +7,7 @@ setup = pkg.KellerSegel2DSetup(nx=n, ny=n)
 rng = np.random.default_rng(0)
 y0 = np.ascontiguousarray(np.moveaxis(setup.generate_random_init(rng, B), 1, -1))
 for two in (True, False):
-    s_env = torch.cuda.Stream()
+    s_env = torch.cuda.Stream(priority=-1)
     s_upd = torch.cuda.Stream() if two else s_env
     env = pkg.PDEenv(setup, B=B, dtype=torch.float32, device="cuda:0", y0=y0, stream=s_env, autoreset=False)
     agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, device="cuda:0", stream=s_upd,

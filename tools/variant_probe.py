@@ -40,4 +40,6 @@ for s in seq:
         a = mk(config="C3", steps=20, warmup=10); a.no_overlap = True
         o = bench.bench_ks(a)
     print(s, round(o["value"]), round(o["ms_per_step"], 4), {k: v for k, v in o["kernels_ms_per_step"].items() if k.startswith("kseg") or k.startswith("ddpg2")}, file=sys.stderr, flush=True)
-    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    o = None
+    gc.collect(); torch.cuda.synchronize()
+    torch.cuda.empty_cache()
