@@ -30,7 +30,7 @@ class EnvCfg(C.Structure):
         ("reward_offset", C.c_double), ("reward_power", C.c_double), ("reward_denom", C.c_double),
         ("action_punish", C.c_double), ("delta_action_punish", C.c_double),
         ("ifpad", C.c_int), ("sensors_per_axis", C.c_int), ("nu", C.c_double),
-        ("Ny", C.c_int), ("integrator", C.c_int),
+        ("Ny", C.c_int), ("integrator", C.c_int), ("memory_size", C.c_int),
     ]
 
 
@@ -57,7 +57,7 @@ SIGNATURES = {
     "pdec_debug_split_available": [],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
-    "pdec_featurize": [Handle, _vp, _vp, _vp],
+    "pdec_featurize": [Handle, _vp, _vp, _vp], "pdec_featurize_action": [Handle, _vp, _vp, _vp, _vp], "pdec_mlp_set_noise_rows": [Handle, _i],
     "pdec_reward": [Handle, _vp, _vp, _vp, _vp],
     "pdec_env_step": [Handle] + [_vp] * 9,
     "pdec_rhs_eval": [Handle, _vp, _vp, _vp],

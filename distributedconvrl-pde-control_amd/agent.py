@@ -218,6 +218,10 @@ class CustomDDPGPolicy:
         cols = s.shape[0] * s.shape[1]
         actor = self._actor_for(env.dtype, cols)
         na = actor.dims[-1]
+        if self.memory_size and getattr(actor, "_noise_rows", None) != na - self.memory_size:
+            # action memory: noise on the driving rows only (src/PDEagent.jl:201: actions[1:end-memory_size, :] += ...)
+            _lib.check(self.lib.pdec_mlp_set_noise_rows(actor.handle, na - self.memory_size))
+            actor._noise_rows = na - self.memory_size
         if self._actions is None or self._actions.shape != (cols, na) or self._actions.dtype != env.dtype:
             # two buffers, alternated: the env may adopt the returned tensor without copying (PDEenv.__call__(adopt=True))
             self._action_ring = [torch.empty((cols, na), dtype=env.dtype, device=env.device) for _ in range(2)]

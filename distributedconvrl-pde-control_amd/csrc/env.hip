@@ -148,6 +148,33 @@ __device__ __forceinline__ void featurize_traj(const EnvDev<T>& e, const T* dots
   }
 }
 
+// featurize with action memory (cfg.memory_size > 0; KSSetup.jl:190-229 with :216 and :220-226): columns are
+// [fresh window rows | the previous state's rows minus its oldest block and its memory rows | memory rows], the memory rows =
+// rows 1.. of the action just applied (actg [A][na]; null = reset form, featurize(y0) without env: zeros).  Kept apart from
+// featurize_traj so that the fused step kernels stay what they were, instruction for instruction.
+template <class T>
+__device__ __forceinline__ void featurize_traj_mem(const EnvDev<T>& e, const T* dots, const T* prev, const T* actg, T* state,
+                                                   int tid, int nt) {
+  const int w = e.window / 2;
+  const int fresh = e.window * e.n_species, body = e.ns - e.mem;
+  for (int idx = tid; idx < e.A * e.ns; idx += nt) {
+    const int a = idx / e.ns, rr = idx - a * e.ns;
+    T v;
+    if (rr >= body) {
+      v = actg ? actg[(size_t)a * e.na + 1 + (rr - body)] : (T)0;
+    } else if (rr < fresh || prev == nullptr) {
+      const int r0 = rr % fresh;
+      const int sp = r0 / e.window, i = (r0 - sp * e.window) - w;
+      int sidx = (e.a2s[a] - i) % e.S;
+      if (sidx < 0) sidx += e.S;
+      v = dots[sp * e.S + sidx] * e.sensor_scale;
+    } else {
+      v = prev[(size_t)a * e.ns + (rr - fresh)];
+    }
+    state[idx] = v;
+  }
+}
+
 // reward + featurize of the TWO trajectories of a workgroup in one pass each (per-actuator agents, temporal_steps == 1): the
 // table loads (a2s, gsum, fmap) are shared and the two trajectories' load-to-use latencies overlap instead of following
 // each other (3.6 k + 2.2 k cycles of the C2 step as four separate loops).  Same arithmetic per element as reward_traj /
@@ -1960,10 +1987,10 @@ __global__ void sense_kernel(EnvDev<T> e, const T* __restrict__ y, const T* __re
   T* actp = act + e.A;
   T* dots = actp + e.A;
   T* part = dots + 2 * e.S;
-  if (MODE == 0 || MODE == 2) {
+  if (MODE == 0 || MODE == 2) {     // row 0 of every action column (KSSetup.jl:176,241: action[1, i]); na = 1 without action memory
     for (int a = tid; a < e.A; a += nt) {
-      act[a] = action[(size_t)b * e.A + a];
-      actp[a] = MODE == 2 ? action_prev[(size_t)b * e.A + a] : (T)0;
+      act[a] = action[((size_t)b * e.A + a) * e.na];
+      actp[a] = MODE == 2 ? action_prev[((size_t)b * e.A + a) * e.na] : (T)0;
     }
     __syncthreads();
   }
@@ -1983,11 +2010,22 @@ __global__ void sense_kernel(EnvDev<T> e, const T* __restrict__ y, const T* __re
   sense_dots<T>(e, [&](int r, int n) { return sy[r * N + n]; }, dots, part, tid, nt);
   if (MODE == 1) {
     const size_t sw = e.mono ? (size_t)e.S : (size_t)e.A * e.ns;
-    featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, out + b * sw, tid, nt);
+    if (e.mem > 0)
+      featurize_traj_mem<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, action ? action + (size_t)b * e.A * e.na : nullptr,
+                            out + b * sw, tid, nt);
+    else
+      featurize_traj<T>(e, dots, state_prev ? state_prev + b * sw : nullptr, out + b * sw, tid, nt);
   } else {
     const int rw = e.mono ? 1 : e.A;
     reward_traj<T>(e, dots, act, actp, out + (size_t)b * rw, tid, nt);
   }
+}
+
+// terminal flag per actuator column from the per-trajectory blow-up flags (composed env step; the fused kernels write it themselves)
+template <class T>
+__global__ void terminal_from_done_kernel(const int32_t* __restrict__ done, int B, int cpt, T* __restrict__ term) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * cpt) term[i] = (done[i / cpt] & 1) ? (T)1 : (T)0;
 }
 
 // ------------------------------------------------------------------ host side
@@ -1997,7 +2035,8 @@ static EnvDev<T> make_dev(const Env& E) {
   EnvDev<T> e;
   e.B = c.B; e.N = c.N; e.S = c.S; e.A = c.A; e.window = c.window; e.temporal = c.temporal_steps;
   e.mono = c.mono; e.K = c.K; e.check_max = c.check_max_value; e.n_species = c.n_species;
-  e.ns = c.mono ? c.S : c.window * c.n_species * c.temporal_steps;
+  e.mem = c.memory_size; e.na = 1 + c.memory_size;      // (action memory: stand-alone closures + the composed env step only)
+  e.ns = c.mono ? c.S : c.window * c.n_species * c.temporal_steps + c.memory_size;
   e.sensor_scale = (T)c.sensor_scale; e.agent_power = (T)c.agent_power;
   e.r_in_scale = (T)c.reward_in_scale; e.r_offset = (T)c.reward_offset; e.r_power = (T)c.reward_power;
   e.r_denom = (T)c.reward_denom; e.a_pun = (T)c.action_punish; e.da_pun = (T)c.delta_action_punish;
@@ -2241,6 +2280,31 @@ static int launch_sense(Env& E, int mode, const void* y, const void* action, con
   return PDEC_OK;
 }
 
+// (env::PDEenv)(action) with action memory (cfg.memory_size > 0): the closures one after the other on the environment's
+// stream -- prepare_action (row 0 of every action column), the integrator, reward (row 0), featurize (window rows, temporal
+// stack, memory rows = rows 1.. of the action).  No shipped script sets memory_size, so this reference surface is served by
+// four launches instead of one and the fused step kernels keep their register budgets.  src/PDEenv.jl:195-241.
+template <class T>
+static int env_step_composed(Env& E, const void* y_in, const void* action, const void* action_prev, const void* state_prev,
+                             void* y_out, void* p_out, void* state_out, void* reward_out, int32_t* done) {
+  const pdec_env_cfg& c = E.cfg;
+  const size_t need = (size_t)c.B * env_p_count(c) * sizeof(T) + (size_t)c.B * sizeof(int32_t) + 64;
+  if (E.mem_scratch.bytes < need) PDEC_HIP(E.mem_scratch.alloc(need));
+  void* p = p_out ? p_out : E.mem_scratch.p;
+  int32_t* flags = done ? done : reinterpret_cast<int32_t*>(E.mem_scratch.as<char>() + (size_t)c.B * env_p_count(c) * sizeof(T));
+  int rc;
+  if ((rc = launch_sense<T>(E, 0, nullptr, action, nullptr, nullptr, p))) return rc;
+  if ((rc = launch_step<T>(E, false, 1, y_in, p, nullptr, nullptr, nullptr, y_out, nullptr, nullptr, nullptr, flags))) return rc;
+  if ((rc = launch_sense<T>(E, 2, y_out, action, action_prev, nullptr, reward_out))) return rc;
+  if ((rc = launch_sense<T>(E, 1, y_out, action, nullptr, state_prev, state_out))) return rc;
+  if (E.term_out) {
+    const int n = c.B * c.A;
+    hipLaunchKernelGGL((terminal_from_done_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, E.stream, flags, c.B, c.A, (T*)E.term_out);
+    PDEC_HIP(hipGetLastError());
+  }
+  return PDEC_OK;
+}
+
 }  // namespace pdec
 
 using namespace pdec;
@@ -2259,6 +2323,10 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
   PDEC_REQUIRE(c.Lx > 0 && c.dt > 0, "pdec_env_create: Lx and dt must be positive");
   PDEC_REQUIRE(c.integrator == 0 || (c.integrator == 1 && (c.pde_kind == PDEC_PDE_KSEG_RK4 || c.pde_kind == PDEC_PDE_KS_RK4_FD)),
                "pdec_env_create: integrator %d is not available for pde_kind %d", c.integrator, c.pde_kind);
+  PDEC_REQUIRE(c.memory_size >= 0 && c.memory_size <= 64, "pdec_env_create: memory_size %d out of range", c.memory_size);
+  PDEC_REQUIRE(c.memory_size == 0 || (!c.mono && c.check_max_value != 2),
+               "pdec_env_create: action memory is built for the per-actuator environments with check_max_value 0 / 1 "
+               "(KSSetup.jl:216-226); the global-agent form and the reward-based blow-up test are not");
   for (int a = 0; a < c.A && !c.mono; ++a)
     PDEC_REQUIRE(a2s[a] >= 0 && a2s[a] < c.S, "pdec_env_create: a2s[%d]=%d out of range", a, a2s[a]);
   auto E = std::make_unique<Env>();
@@ -2387,7 +2455,7 @@ int pdec_env_create(pdec_handle* h, const pdec_env_cfg* cfg, const double* senso
   PDEC_HIP(hipMemcpy(E->an0.p, an0.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice));
   PDEC_HIP(E->a2s.alloc(sizeof(int32_t) * c.A));
   PDEC_HIP(hipMemcpy(E->a2s.p, a2s_h.data(), sizeof(int32_t) * c.A, hipMemcpyHostToDevice));
-  if (!c.mono && c.temporal_steps == 1) {
+  if (!c.mono && c.temporal_steps == 1 && c.memory_size == 0) {
     // featurize as one gather (KSSetup.jl:190-229 without temporal stacking): state[a][rr] = dots[sp][(a2s[a] - i) mod S]
     const int ns1 = c.window * c.n_species, w = c.window / 2;
     std::vector<int32_t> fm((size_t)c.A * ns1);
@@ -2432,7 +2500,7 @@ int pdec_env_set_reward_partials_out(pdec_handle h, void* partial_sums, int* n_p
   Env* E = lookup_as<Env>(h, Kind::Env);
   if (!E) { set_error("pdec_env_set_reward_partials_out: bad handle"); return PDEC_E_HANDLE; }
   const bool ks = E->cfg.pde_kind == PDEC_PDE_KS_CNAB2, ksfd = E->cfg.pde_kind == PDEC_PDE_KS_RK4_FD;
-  PDEC_REQUIRE(ks || ksfd || partial_sums == nullptr,
+  PDEC_REQUIRE(((ks || ksfd) && E->cfg.memory_size == 0) || partial_sums == nullptr,
                "pdec_env_set_reward_partials_out: provided by the fused KS steps only (use pdec_reward_mean elsewhere)");
   E->rsum_out = (float*)partial_sums;
   // CNAB2: one workgroup integrates two trajectories; RK4 + FD: one trajectory per workgroup
@@ -2473,6 +2541,15 @@ int pdec_featurize(pdec_handle h, const void* y, const void* prev_state, void* s
   if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4) return kseg2d_featurize(*E, y, prev_state, state_out);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 1, y, nullptr, nullptr, prev_state, state_out)
                                   : launch_sense<float>(*E, 1, y, nullptr, nullptr, prev_state, state_out);
+}
+
+int pdec_featurize_action(pdec_handle h, const void* y, const void* prev_state, const void* action, void* state_out) {
+  GET_ENV(E, h);
+  if (!action || E->cfg.memory_size == 0) return pdec_featurize(h, y, prev_state, state_out);
+  PDEC_REQUIRE(y && state_out, "pdec_featurize_action: null");
+  PDEC_REQUIRE(prev_state != state_out, "pdec_featurize_action: state_out must not alias prev_state");
+  return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 1, y, action, nullptr, prev_state, state_out)
+                                  : launch_sense<float>(*E, 1, y, action, nullptr, prev_state, state_out);
 }
 
 int pdec_reward(pdec_handle h, const void* y, const void* action, const void* action_prev, void* r_out) {
@@ -2517,6 +2594,10 @@ int pdec_env_step(pdec_handle h, const void* y_in, const void* action, const voi
     return fluid_env_step(*E, y_in, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
   if (E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4)
     return kseg2d_env_step(*E, y_in, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
+  if (E->cfg.memory_size > 0)
+    return E->cfg.dtype == PDEC_F64
+               ? env_step_composed<double>(*E, y_in, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done)
+               : env_step_composed<float>(*E, y_in, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
   return E->cfg.dtype == PDEC_F64
              ? launch_step<double>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done)
              : launch_step<float>(*E, true, 0, y_in, nullptr, action, action_prev, state_prev, y_out, p_out, state_out, reward_out, done);
@@ -2556,7 +2637,7 @@ int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, cons
   const pdec_env_cfg& c = E->cfg;
   const size_t ts = dtype_size(c.dtype);
   const int ns = env_ns(c);
-  const size_t ny = (size_t)c.B * env_y_count(c) * ts, np = (size_t)c.B * env_p_count(c) * ts, na = (size_t)c.B * c.A * ts;
+  const size_t ny = (size_t)c.B * env_y_count(c) * ts, np = (size_t)c.B * env_p_count(c) * ts, na = (size_t)c.B * c.A * env_na(c) * ts;
   const size_t nst = (size_t)c.B * (c.mono ? c.S : c.A * ns) * ts, nr = (size_t)c.B * (c.mono ? 1 : c.A) * ts;
   auto al = [](size_t x) { return (x + 63) / 64 * 64; };
   int rc = env_stage(E, 2 * al(ny) + al(np) + 2 * al(na) + 2 * al(nst) + al(nr) + al(c.B * sizeof(int32_t)));

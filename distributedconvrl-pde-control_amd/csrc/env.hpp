@@ -9,6 +9,7 @@ namespace pdec {
 template <class T>
 struct EnvDev {
   int B, N, S, A, ns, window, temporal, mono, K, check_max, n_species, rk2, prio;
+  int mem, na;           // action memory rows (cfg.memory_size) and rows per action column, na = 1 + mem: action [B][A][na]
   T sensor_scale, agent_power, r_in_scale, r_offset, r_power, r_denom, a_pun, da_pun, max_value;
   T dx, hstep, dist_mu;  // cell size, RK4 sub-step, KS disturbance amplitude (RK4-FD variant)
   // sensor / actuator kernels as circular BAND tables (exact: every non-zero entry of the dense
@@ -36,6 +37,7 @@ struct Env : Object {
   int Wd = 0, Cnt = 0;
   DevBuf stage;  // staging for the _host wrappers
   DevBuf roll;   // ping-pong buffers of pdec_rollout
+  DevBuf mem_scratch;   // forcing field + flags of the composed env step (cfg.memory_size > 0)
   void* term_out = nullptr;
   float* rsum_out = nullptr;
   bool share_simd = false;   // pdec_env_set_simd_sharing: launch the 64-VGPR form of the fused KS step
@@ -96,7 +98,8 @@ inline int env_ns(const pdec_env_cfg& c) {
   if (c.mono) return c.S;
   if (c.pde_kind == PDEC_PDE_FLUID_RK4) return c.window * c.window * c.temporal_steps;
   if (c.pde_kind == PDEC_PDE_KSEG2D_RK4) return 2 * c.window * c.window * c.temporal_steps;
-  return c.window * c.n_species * c.temporal_steps;
+  return c.window * c.n_species * c.temporal_steps + c.memory_size;
 }
+inline int env_na(const pdec_env_cfg& c) { return 1 + c.memory_size; }
 
 }  // namespace pdec

@@ -205,14 +205,15 @@ __global__ void cast_copy_kernel(TD* __restrict__ dst, const TS* __restrict__ sr
 }
 
 // actions[c][f] = clamp(H[f][c] + noise[c][f]*act_noise, +-lim)
+// (noise on the first nrows outputs only: the action-memory rows stay noise-free, src/PDEagent.jl:201)
 template <class T>
-__global__ void act_noise_clamp_kernel(const T* __restrict__ H, const T* __restrict__ noise, int cols, int n,
+__global__ void act_noise_clamp_kernel(const T* __restrict__ H, const T* __restrict__ noise, int cols, int n, int nrows,
                                        T act_noise, T lim, T* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   for (int f = 0; f < n; ++f) {
     T v = H[(size_t)f * cols + c];
-    if (noise) v += noise[(size_t)c * n + f] * act_noise;
+    if (noise && f < nrows) v += noise[(size_t)c * n + f] * act_noise;
     v = v < -lim ? -lim : (v > lim ? lim : v);
     out[(size_t)c * n + f] = v;
   }
@@ -712,15 +713,15 @@ int pdec_policy_act(pdec_handle actor, const void* state, const void* noise, int
   if (rc) return rc;
   rc = DISPATCH(M, M->forward<float>(cols), M->forward<double>(cols));
   if (rc) return rc;
-  const int no = M->dims[M->L];
+  const int no = M->dims[M->L], nrows = M->noise_rows < 0 ? no : M->noise_rows;
   dim3 grid(cdiv(cols, 256)), block(256);
   ProfScope ps(M, "act_noise_clamp");
   if (M->dtype == PDEC_F64)
     hipLaunchKernelGGL((act_noise_clamp_kernel<double>), grid, block, 0, M->stream, M->H[M->L].as<double>(), (const double*)noise,
-                       cols, no, act_noise, act_limit, (double*)actions_out);
+                       cols, no, nrows, act_noise, act_limit, (double*)actions_out);
   else
     hipLaunchKernelGGL((act_noise_clamp_kernel<float>), grid, block, 0, M->stream, M->H[M->L].as<float>(), (const float*)noise, cols,
-                       no, (float)act_noise, (float)act_limit, (float*)actions_out);
+                       no, nrows, (float)act_noise, (float)act_limit, (float*)actions_out);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
@@ -1005,6 +1006,13 @@ int pdec_policy_act_rng_dev(pdec_handle actor, const void* state, int cols, doub
                            c + (M->nc_sel ^ 1), inc);
   if (rc) return rc;
   flip(M->nc_sel);
+  return PDEC_OK;
+}
+
+int pdec_mlp_set_noise_rows(pdec_handle actor, int rows) {
+  GET_MLP(M, actor);
+  PDEC_REQUIRE(rows == -1 || (rows >= 1 && rows <= M->dims[M->L]), "pdec_mlp_set_noise_rows: %d of %d outputs", rows, M->dims[M->L]);
+  M->noise_rows = rows == M->dims[M->L] ? -1 : rows;
   return PDEC_OK;
 }
 

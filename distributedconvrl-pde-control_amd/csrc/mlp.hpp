@@ -25,6 +25,7 @@ struct Mlp : Object {
   const void* rbar_ext = nullptr;    // batch-mean reward reduced elsewhere (pdec_ddpg_set_reward_mean), consumed by the next critic pass
   DevBuf noise_ctr;                  // uint64 [2]: double-buffered exploration-noise counter of pdec_policy_act_rng_dev
   int nc_sel = 0;
+  int noise_rows = -1;   // pdec_mlp_set_noise_rows: exploration noise on the first rows of the output only (-1: all)
   std::vector<DevBuf> H;             // activations, feature-major [dims[l]][cols]
   DevBuf dz[2];                      // ping-pong dL/dz buffers [maxdim][cols]
   DevBuf dy;                         // dL/dy of the output layer [dims[L]][cols]

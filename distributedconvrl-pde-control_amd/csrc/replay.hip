@@ -284,7 +284,7 @@ int pdec_env_autoreset(pdec_handle henv, const int32_t* done, void* y, const voi
     g.row_bytes[1] = (long long)((c.mono ? (size_t)c.S : (size_t)c.A * env_ns(c)) * ts);
   }
   if (action && action0) {
-    g.dst[2] = (char*)action; g.src[2] = (const char*)action0; g.row_bytes[2] = (long long)((size_t)c.A * ts);
+    g.dst[2] = (char*)action; g.src[2] = (const char*)action0; g.row_bytes[2] = (long long)((size_t)c.A * env_na(c) * ts);
   }
   g.reward = reward; g.reward_len = c.mono ? 1 : c.A;
   ProfScope ps(E, "env_autoreset");

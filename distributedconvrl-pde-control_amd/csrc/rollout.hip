@@ -42,7 +42,7 @@ extern "C" int pdec_rollout(pdec_handle henv, pdec_handle hactor, int T, void* y
   PDEC_REQUIRE(A->stream == E->stream, "pdec_rollout: the actor and the environment must share one stream");
   const size_t ts = dtype_size(c.dtype);
   const int ns = env_ns(c), cols = c.B * (c.mono ? 1 : c.A), na = A->dims[A->L];
-  PDEC_REQUIRE(A->dims[0] == (c.mono ? c.S : ns) && cols * na == c.B * c.A,
+  PDEC_REQUIRE(A->dims[0] == (c.mono ? c.S : ns) && cols * na == c.B * c.A * env_na(c),
                "pdec_rollout: actor shape %d -> %d does not match the state/action matrices", A->dims[0], na);
   if (ks_rollout_supported(*E, *A)) {
     // KS: the whole loop in ONE persistent launch -- the trajectories stay in registers / LDS between steps and the actor is
@@ -53,7 +53,7 @@ extern "C" int pdec_rollout(pdec_handle henv, pdec_handle hactor, int T, void* y
   if (kseg_rollout_supported(*E, *A))     // 1-D Keller-Segel: likewise one launch (csrc/env.hip: kseg_rollout_kernel)
     return kseg_rollout_persistent(*E, *A, T, y, state, action, act_noise, act_limit, learning, seed, offset, reward_sum, log_y,
                                    log_p, log_action, log_reward, done_any, done_step);
-  const size_t ny = (size_t)c.B * env_y_count(c) * ts, np = (size_t)c.B * env_p_count(c) * ts, nact = (size_t)c.B * c.A * ts;
+  const size_t ny = (size_t)c.B * env_y_count(c) * ts, np = (size_t)c.B * env_p_count(c) * ts, nact = (size_t)c.B * c.A * env_na(c) * ts;
   const size_t nst = (size_t)c.B * (c.mono ? c.S : (size_t)c.A * ns) * ts, nr = (size_t)c.B * (c.mono ? 1 : c.A) * ts;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   // scratch: second y / state / action buffers, p, reward, done

@@ -240,10 +240,12 @@ class PDEenv:
             self.state.copy_(self._state0)
 
     # ---- stand-alone closures (each one launch)
-    def featurize(self, y=None, prev_state=None):
+    def featurize(self, y=None, prev_state=None, action=None):
+        """featurize(y0, t0) / featurize(; env) (KSSetup.jl:190-229).  `action` [B, A, 1 + memory_size]: the source of the
+        action-memory rows (memory_size > 0; None = the reset form, zeros)"""
         y = self.y if y is None else y
         out = torch.empty(self._sshape, dtype=self.dtype, device=self.device)
-        _lib.check(self.lib.pdec_featurize(self._h, _lib.ptr(y), _lib.ptr(prev_state), _lib.ptr(out)))
+        _lib.check(self.lib.pdec_featurize_action(self._h, _lib.ptr(y), _lib.ptr(prev_state), _lib.ptr(action), _lib.ptr(out)))
         return out
 
     def prepare_action(self, action=None):

@@ -38,7 +38,7 @@ class KellerSegelSetup:
         self.window_size, self.temporal_steps, self.memory_size, self.mono, self.n_species = \
             window_size, int(temporal_steps), int(memory_size), False, 2
         from .ks import _refuse_unbuilt_branches
-        _refuse_unbuilt_branches(self, "scripts/Keller-Segel/setup/KellerSegelSetup.jl:295-314")
+        _refuse_unbuilt_branches(self, "scripts/Keller-Segel/setup/KellerSegelSetup.jl:295-314", memory_built=True)
         self.nna_scale, self.nna_scale_critic, self.drop_middle_layer = nna_scale, nna_scale_critic, drop_middle_layer
         self.gamma, self.rho, self.batch_size = gamma, rho, batch_size
         self.start_steps, self.update_after, self.update_freq, self.update_loops = \
@@ -58,11 +58,11 @@ class KellerSegelSetup:
 
     @property
     def state_shape(self):
-        return (self.window_size * 2 * self.temporal_steps, self.n_actuators)
+        return (self.window_size * 2 * self.temporal_steps + self.memory_size, self.n_actuators)
 
     @property
     def action_shape(self):
-        return (1, self.n_actuators)
+        return (1 + self.memory_size, self.n_actuators)
 
     @property
     def reward_len(self):
@@ -95,6 +95,7 @@ class KellerSegelSetup:
         c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, self.temporal_steps, 0
         c.K = self.oversampling
         c.integrator = 1 if self.integrator == "midpoint" else 0
+        c.memory_size = self.memory_size
         c.check_max_value = {"y": 1, "reward": 2}.get(self.check_max_value, 0)
         c.Lx, c.dt, c.mu, c.max_value = self.Lx, self.dt, 0.0, self.max_value
         c.sensor_scale = 0.25                                      # KellerSegelSetup.jl:276

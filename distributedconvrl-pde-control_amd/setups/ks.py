@@ -26,12 +26,16 @@ def prepare_gaussians(nx, Lx, positions, sigma, norm_mode):
     return out
 
 
-def _refuse_unbuilt_branches(setup, where):
-    """memory_size > 0 (action memory: src/PDEagent.jl:201 + the featurize branch cited in `where`) and a temporal stack for
-    the mono / global agent are optional branches no shipped script sets; a caller who sets them gets an error, not silence"""
-    if setup.memory_size != 0:
+def _refuse_unbuilt_branches(setup, where, memory_built=False):
+    """memory_size > 0 (action memory: src/PDEagent.jl:201 + the featurize branch cited in `where`) is built for the 1-D
+    per-actuator environments (KS, Keller-Segel: the composed env step, csrc/env.hip env_step_composed); elsewhere -- the
+    global agent, the 2-D environments -- and a temporal stack for the mono / global agent are optional branches no shipped
+    script sets; a caller who sets them gets an error, not silence"""
+    if setup.memory_size < 0 or (setup.memory_size != 0 and not memory_built):
         raise _lib.PdecError(f"memory_size = {setup.memory_size}: the action-memory branch of featurize / the acting path "
-                             f"({where}, src/PDEagent.jl:201) is not built; only memory_size = 0 is supported")
+                             f"({where}, src/PDEagent.jl:201) is not built for this setup; only memory_size = 0 is supported")
+    if setup.memory_size != 0 and getattr(setup, "check_max_value", "y") == "reward":
+        raise _lib.PdecError("memory_size > 0 with check_max_value = 'reward' is not built (the composed env step tests 'y' only)")
     if setup.temporal_steps < 1 or (getattr(setup, "mono", False) and setup.temporal_steps != 1):
         raise _lib.PdecError(f"temporal_steps = {setup.temporal_steps} is not supported for this setup ({where})")
 
@@ -69,9 +73,9 @@ class KSSetup:
         self.act_limit, self.act_noise, self.trajectory_length = act_limit, act_noise, trajectory_length
         # featurize's optional branches (KSSetup.jl:209-226): temporal stacking runs in the step kernels' general
         # featurize path; the action-memory rows (memory_size > 0: extra actor outputs fed back as state rows,
-        # src/PDEagent.jl:201) are not built -- refused here rather than silently ignored
+        # src/PDEagent.jl:201) go through the composed env step (four launches; per-actuator agents only)
         self.temporal_steps, self.memory_size, self.n_species = int(temporal_steps), int(memory_size), 1
-        _refuse_unbuilt_branches(self, "scripts/KS/setup/KSSetup.jl:209-226")
+        _refuse_unbuilt_branches(self, "scripts/KS/setup/KSSetup.jl:209-226", memory_built=not mono)
         self.gaussians = prepare_gaussians(self.nx, self.Lx, self.sensor_positions, sigma_sensors, 1)
         if mono:   # KSglobalSetup.jl:99-102,125
             self.gaussians_actuators = prepare_gaussians(self.nx, self.Lx, self.actuator_positions, sigma_actuators, 2)
@@ -90,7 +94,7 @@ class KSSetup:
 
     @property
     def state_shape(self):          # size(state_space)
-        return (self.n_sensors, 1) if self.mono else (self.window_size * self.temporal_steps, self.n_actuators)
+        return (self.n_sensors, 1) if self.mono else (self.window_size * self.temporal_steps + self.memory_size, self.n_actuators)
 
     @property
     def action_shape(self):         # size(action_space)
@@ -125,6 +129,7 @@ class KSSetup:
         # "midpoint_fd" (the same right-hand side under PDEenv's built-in explicit-midpoint integrator, src/PDEenv.jl:208-214)
         kind = _lib.PDE_KS_RK4_FD if self.integrator in ("rk4_fd", "midpoint_fd") else _lib.PDE_KS_CNAB2
         c.integrator = 1 if self.integrator == "midpoint_fd" else 0
+        c.memory_size = self.memory_size
         c.pde_kind, c.dtype, c.B, c.N, c.n_species = kind, dtype_code, B, self.nx, 1
         c.S, c.A, c.window, c.temporal_steps, c.mono = self.n_sensors, self.n_actuators, self.window_size, self.temporal_steps, int(self.mono)
         c.K = self.oversampling

@@ -136,6 +136,11 @@ typedef struct pdec_env_cfg {
    * setups' do_step use), 1 = PDEenv's built-in explicit midpoint rule, K = `oversampling` sub-steps
    * (src/PDEenv.jl:208-214, taken when no do_step closure is supplied) */
   int integrator;
+  /* action memory (scripts/KS/setup/KSSetup.jl:39,48,216-226; src/PDEagent.jl:201; 0 in every shipped script): the actor has
+   * 1 + memory_size outputs per actuator; row 0 drives the PDE and the reward, rows 1.. come back as the LAST memory_size rows
+   * of the next state (zeros at a reset).  action arrays become [B][A][1 + memory_size], state columns grow by memory_size.
+   * 1-D per-actuator kinds only (KS CNAB2, KS RK4+FD, Keller-Segel); PDEC_E_INVALID for mono / 2-D environments. */
+  int memory_size;
 } pdec_env_cfg;
 
 /* sensor_kernels [S][N], actuator_kernels [A][N] (host, double, row = one kernel: the
@@ -182,6 +187,9 @@ int pdec_pde_step(pdec_handle h, const void* y_in, const void* p, void* y_out, i
 /* featurize(; env): state_out[B][A][ns] from y and the previous state (temporal_steps>1;
  * may be NULL = constructor/reset form, KSSetup.jl:190-229, KellerSegelSetup.jl:265-316) */
 int pdec_featurize(pdec_handle h, const void* y, const void* prev_state, void* state_out);
+/* the same with the action the environment holds (cfg.memory_size > 0: rows 1.. of `action` [B][A][1 + memory_size] become the
+ * last memory_size rows of every state column, KSSetup.jl:220-226; action NULL = pdec_featurize = the reset form: zeros) */
+int pdec_featurize_action(pdec_handle h, const void* y, const void* prev_state, const void* action, void* state_out);
 /* reward_function(env): r_out[B][A] (or [B][1] mono)      (KSSetup.jl:162-178) */
 int pdec_reward(pdec_handle h, const void* y, const void* action, const void* action_prev,
                 void* r_out);
@@ -287,6 +295,11 @@ int pdec_policy_act(pdec_handle actor, const void* state, const void* noise, int
 /* the same with the exploration noise drawn inside the kernel from the counter-based generator of
  * pdec_randn (identical numbers: element i of the stream (seed, offset) belongs to column i);
  * learning = 0 -> no noise (`learning=false`, src/PDEagent.jl:199).  One launch for 3-layer fp32 actors. */
+/* exploration noise on the first `rows` outputs of the actor only (-1 = all, the default): with action memory the reference
+ * adds noise to the driving row and leaves the memory rows as the actor produced them (src/PDEagent.jl:201:
+ * actions[1:end-memory_size, :] += randn * act_noise); the clamp applies to every row.  Philox element numbering unchanged
+ * (element = column * outputs + row; the memory rows' draws are skipped). */
+int pdec_mlp_set_noise_rows(pdec_handle actor, int rows);
 int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
                         int learning, uint64_t seed, uint64_t offset, void* actions_out);
 /* the same with the noise counter kept ON THE DEVICE (one per actor handle): the kernel reads the current counter and

@@ -49,16 +49,17 @@ struct EnvCfg
     nu::Cdouble
     Ny::Cint
     integrator::Cint
+    memory_size::Cint
 end
 
 # keyword constructor: every field by name, so that a field added to the C struct cannot silently shift the rest
 function EnvCfg(; pde_kind = KS_CNAB2, dtype = F64, B = 1, N, n_species = 1, S, A, window = 1, temporal_steps = 1,
                 mono = 0, K, check_max_value = 1, Lx, dt, mu = 0.0, max_value, sensor_scale, agent_power,
                 reward_in_scale, reward_offset = 0.0, reward_power, reward_denom, action_punish, delta_action_punish,
-                ifpad = 0, sensors_per_axis = 0, nu = 0.0, Ny = 0, integrator = 0)
+                ifpad = 0, sensors_per_axis = 0, nu = 0.0, Ny = 0, integrator = 0, memory_size = 0)
     EnvCfg(pde_kind, dtype, B, N, n_species, S, A, window, temporal_steps, mono, K, check_max_value, Lx, dt, mu,
            max_value, sensor_scale, agent_power, reward_in_scale, reward_offset, reward_power, reward_denom,
-           action_punish, delta_action_punish, ifpad, sensors_per_axis, nu, Ny, integrator)
+           action_punish, delta_action_punish, ifpad, sensors_per_axis, nu, Ny, integrator, memory_size)
 end
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:pdec_last_error, LIB), Cstring, ())))

@@ -98,9 +98,10 @@ def reward_function(cfg, y, action, delta_action):
     return r - cfg.action_punish * a ** 2 - cfg.delta_action_punish * da ** 2  # :257
 
 
-def featurize(cfg, y, prev_state=None):
-    """KellerSegelSetup.jl:265-316 (sees_action=false, memory_size=0).  prev_state=None is the
-    constructor/reset call (`isnothing(env)` branch: the fresh rows are repeated)."""
+def featurize(cfg, y, prev_state=None, action=None):
+    """KellerSegelSetup.jl:265-316 (sees_action=false).  prev_state=None is the
+    constructor/reset call (`isnothing(env)` branch: the fresh rows are repeated).  memory_size > 0 (cfg.memory_size, :303,
+    :307-313; 0 in the shipped script): the last rows are rows 2.. of env.action (`action`), zeros in the reset form."""
     s1 = cfg.gaussians @ y[0] / 4                                             # :276
     s2 = cfg.gaussians @ y[1] / 4                                             # :277
     w = int(np.floor(cfg.window_size / 2))
@@ -112,8 +113,14 @@ def featurize(cfg, y, prev_state=None):
         if prev_state is None:
             result = np.concatenate([result] * cfg.temporal_steps)           # :297-301
         else:
-            keep = prev_state.shape[0] - result.shape[0]
+            keep = prev_state.shape[0] - result.shape[0] - int(getattr(cfg, "memory_size", 0))
             result = np.concatenate([result, prev_state[:keep]])              # :303
+    m = int(getattr(cfg, "memory_size", 0))
+    if m > 0:                                                                 # :307
+        if action is None:
+            result = np.concatenate([result, np.zeros((m, result.shape[1]))])  # :309
+        else:
+            result = np.concatenate([result, np.asarray(action, dtype=np.float64)[-m:, :]])   # :311
     return result
 
 

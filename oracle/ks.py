@@ -161,11 +161,13 @@ def reward_function(cfg, y, action, delta_action):
     return r
 
 
-def featurize(cfg, y, prev_state=None):
-    """scripts/KS/setup/KSSetup.jl:190-229 with memory_size=0; mono variant KSglobalSetup.jl:211-249 returns the
+def featurize(cfg, y, prev_state=None, action=None):
+    """scripts/KS/setup/KSSetup.jl:190-229; mono variant KSglobalSetup.jl:211-249 returns the
     [S,1] column.  temporal_steps > 1 (:209-218; 1 in every shipped KS script): prev_state=None is the reference's
     `isnothing(env)` branch (the fresh rows repeated), otherwise the fresh rows stacked on the newest rows of the
-    previous state (`env.state[1:end-size(result)[1], :]`)."""
+    previous state (`env.state[1:end-size(result)[1]-memory_size, :]`).  memory_size > 0 (cfg.memory_size; 0 in every shipped
+    script; :220-226): the last memory_size rows are rows 2.. of env.action [1 + memory_size, A] -- `action` here -- or zeros
+    in the `isnothing(env)` form (action=None)."""
     sensors = sensor_dots(cfg, y) / cfg.max_value                             # :201
     if cfg.mono:
         return sensors.reshape(-1, 1)                                         # KSglobalSetup.jl:225-227
@@ -174,12 +176,18 @@ def featurize(cfg, y, prev_state=None):
     result = np.stack(rows)
     result = result[:, cfg.actuators_to_sensors - 1]                          # :207
     T = getattr(cfg, "temporal_steps", 1)
+    m = int(getattr(cfg, "memory_size", 0))
     if T > 1:                                                                 # :209
         if prev_state is None:
             result = np.concatenate([result] * T)                             # :211-214
         else:
             prev = np.asarray(prev_state, dtype=np.float64)
-            result = np.concatenate([result, prev[:prev.shape[0] - result.shape[0], :]])   # :216
+            result = np.concatenate([result, prev[:prev.shape[0] - result.shape[0] - m, :]])   # :216
+    if m > 0:                                                                 # :220
+        if action is None:
+            result = np.concatenate([result, np.zeros((m, result.shape[1]))])  # :222
+        else:
+            result = np.concatenate([result, np.asarray(action, dtype=np.float64)[-m:, :]])   # :224
     return result
 
 
@@ -213,7 +221,7 @@ def env_step(cfg, y, action_prev, action, time, prev_state=None):
     p = prepare_action(cfg, action)                                           # :199
     y_new = do_step(cfg, y, p)                                                # :217
     reward = reward_function(cfg, y_new, action, delta_action)                # :220
-    state = featurize(cfg, y_new, prev_state)                                 # :222
+    state = featurize(cfg, y_new, prev_state, action if getattr(cfg, "memory_size", 0) else None)   # :222
     time = time + cfg.dt                                                      # :225
     done = bool(time >= cfg.te or np.max(np.abs(y_new)) > cfg.max_value)      # :227
     return dict(y=y_new, p=p, reward=reward, state=state, done=done, time=time,

@@ -162,11 +162,13 @@ def ddpg_update(A, C, At, Ct, optA, optC, acts_a, acts_c, s, a, r, t, snext, gam
     return out
 
 
-def policy_act(A, acts_a, state, noise, act_noise, act_limit, learning=True):
-    """(policy::CustomDDPGPolicy)(env), src/PDEagent.jl:183-207, memory_size = 0.  The
-    reference promotes Float32 weights to the Float64 state (acting path is fp64)."""
+def policy_act(A, acts_a, state, noise, act_noise, act_limit, learning=True, memory_size=0):
+    """(policy::CustomDDPGPolicy)(env), src/PDEagent.jl:183-207.  The reference promotes Float32 weights to the Float64
+    state (acting path is fp64).  memory_size > 0: noise on actions[1:end-memory_size, :] only (:201)."""
     P = [p.astype(np.float64) for p in A]
     actions = forward(P, acts_a, np.asarray(state, dtype=np.float64))         # :189
     if learning:
-        actions = actions + noise * act_noise                                 # :201
+        actions = np.array(actions, dtype=np.float64)
+        k = actions.shape[0] - int(memory_size)
+        actions[:k] = actions[:k] + np.asarray(noise)[:k] * act_noise         # :201
     return np.clip(actions, -act_limit, act_limit)                            # :202-204

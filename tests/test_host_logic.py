@@ -45,14 +45,14 @@ def test_julia_glue_matches_the_c_abi(pkg):
     hdr, decls = _c_decls()
     body = re.search(r"typedef struct pdec_env_cfg \{(.*?)\} pdec_env_cfg;", hdr, flags=re.S).group(1)
     c_fields = re.findall(r"\b(int|double)\s+([A-Za-z_0-9]+)\s*;", body)
-    assert len(c_fields) == 29
+    assert len(c_fields) == 30
     jl = open(os.path.join(ROOT, "julia", "PDEenvHIP.jl")).read()
     jbody = re.search(r"^struct EnvCfg\n(.*?)^end", jl, flags=re.S | re.M).group(1)
     j_fields = re.findall(r"^\s*([A-Za-z_0-9]+)::(Cint|Cdouble)\s*$", jbody, flags=re.M)
     assert [(n, {"Cint": "int", "Cdouble": "double"}[t]) for n, t in j_fields] == [(n, t) for t, n in c_fields]
     py_fields = [(n, "int" if t is ctypes.c_int else "double") for n, t in pkg._lib.EnvCfg._fields_]
     assert py_fields == [(n, t) for t, n in c_fields]
-    assert ctypes.sizeof(pkg._lib.EnvCfg) == 12 * 4 + 12 * 8 + 2 * 4 + 8 + 2 * 4
+    assert ctypes.sizeof(pkg._lib.EnvCfg) == 12 * 4 + 12 * 8 + 2 * 4 + 8 + 3 * 4 + 4      # (+ 4 bytes of tail padding)
     # the keyword constructor forwards every field positionally in the struct's order
     ctor = re.search(r"function EnvCfg\(;.*?\n    EnvCfg\((.*?)\)\nend", jl, flags=re.S).group(1)
     assert [a.strip() for a in ctor.replace("\n", " ").split(",")] == [n for _, n in c_fields]
@@ -285,14 +285,28 @@ def test_jld2_writer_roundtrip_and_checksums(pkg, tmp_path):
 
 
 def test_optional_featurize_branches_are_refused_or_restated(pkg):
-    """memory_size > 0 (KSSetup.jl:220-226, PDEagent.jl:201) is refused at setup by every setup class --
-    an error, not silence; temporal_steps > 1 is accepted (the step kernels' general featurize path) and the oracle restates
-    both branches of KSSetup.jl:209-218"""
+    """memory_size > 0 (KSSetup.jl:220-226, PDEagent.jl:201): built for the 1-D per-actuator setups since round 4 (shapes
+    here, GPU parity in tests/test_gpu_memory.py), refused -- an error, not silence -- by the global agent, the 2-D setups and
+    together with the reward-based blow-up test; temporal_steps > 1 is accepted (the step kernels' general featurize path) and
+    the oracle restates both branches of KSSetup.jl:209-218 and the memory rows of :220-226"""
     from oracle import ks
-    for mk in (lambda **k: pkg.KSSetup.KS22(**k), lambda **k: pkg.FluidSetup(nx=32, sensors_per_axis=4, **k),
-               lambda **k: pkg.KellerSegelSetup(**k), lambda **k: pkg.KellerSegel2DSetup(**k)):
+    for mk in (lambda **k: pkg.KSSetup.KS22_global(**k), lambda **k: pkg.FluidSetup(nx=32, sensors_per_axis=4, **k),
+               lambda **k: pkg.KellerSegel2DSetup(**k), lambda **k: pkg.KSSetup.KS22(check_max_value="reward", **k),
+               lambda **k: pkg.KSSetup.KS22(**{**k, "memory_size": -1})):
         with pytest.raises(pkg.PdecError, match="memory_size"):
             mk(memory_size=2)
+    sm = pkg.KSSetup.KS22(window_size=3, temporal_steps=2, memory_size=2)
+    assert sm.state_shape == (8, 8) and sm.action_shape == (3, 8) and sm.env_cfg(1, 0).memory_size == 2
+    km = pkg.KellerSegelSetup(memory_size=1)
+    assert km.state_shape == (13, km.n_actuators) and km.action_shape == (2, km.n_actuators) and km.env_cfg(1, 0).memory_size == 1
+    cm = ks.KSConfig(192, 22.0, np.arange(1, 193, 24), sigma_sensors=0.7, sigma_actuators=0.7, window_size=3, temporal_steps=2)
+    cm.memory_size = 2
+    y_ = np.sin(np.arange(192) * 0.1)
+    act_ = np.arange(24.0).reshape(3, 8)
+    s0 = ks.featurize(cm, y_)                                   # reset form: fresh rows twice, zeros (:211-214, :222)
+    assert s0.shape == (8, 8) and np.array_equal(s0[:3], s0[3:6]) and not s0[6:].any()
+    s1 = ks.featurize(cm, 2 * y_, s0, act_)                     # env form: the newest block of s0 without its memory rows (:216, :224)
+    assert np.array_equal(s1[3:6], s0[:3]) and np.array_equal(s1[6:], act_[1:]) and np.allclose(s1[:3], 2 * s0[:3])
     with pytest.raises(pkg.PdecError, match="temporal_steps"):
         pkg.KSSetup.KS22_global(temporal_steps=2)
     s = pkg.KSSetup.KS22(window_size=3, temporal_steps=2)
