@@ -9,6 +9,8 @@ python bench.py --steps 200 --warmup 20 --no-cpu-baseline --integrator rk4_fd 2>
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob("gpurun_out/%s_*.json" % os.environ["TAG"])):
-    d=json.load(open(f)); r=d["roofline"]
+    d=json.load(open(f))
+    if "roofline" not in d: continue
+    r=d["roofline"]
     print(f.split("/")[-1], round(d["value"],1), round(d["ms_per_step"],4), r["kernel"], round(r["frac"],3), "traffic", r.get("traffic"))
 PY
