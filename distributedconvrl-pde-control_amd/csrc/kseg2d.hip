@@ -212,7 +212,11 @@ __global__ __launch_bounds__(K2Tile<T>::NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     if (!act[k] || sr[k] < H || sr[k] >= H + K2_TY || sc[k] < H || sc[k] >= H + K2_TX) continue;
-    const size_t g = fo + (size_t)(gy0 + sr[k]) * e.nx + (gx0 + sc[k]);
+    // the address is computed again from the strip's row: otherwise the compiler keeps the prologue's 64-bit offsets alive
+    // through the four stages (one spilled register with its reload in front of this store in the MODE 2 form)
+    int row = sr[k];
+    asm volatile("" : "+v"(row));
+    const size_t g = fo + (size_t)(gy0 + row) * e.nx + (gx0 + sc[k]);
     Quad<T> q;
     q.c[0] = mk<T>(u0[k][0].x, v0[k][0].x); q.c[1] = mk<T>(u0[k][0].y, v0[k][0].y);
     q.c[2] = mk<T>(u0[k][1].x, v0[k][1].x); q.c[3] = mk<T>(u0[k][1].y, v0[k][1].y);
