@@ -38,6 +38,8 @@ struct K2Dev {
   const int* sy;        // [Sy] 0-based centre rows
   const int* a2s;       // [A]
   const int* cell_act;  // [ny][nx] actuator whose box covers the cell, -1 = none (boxes do not overlap)
+  const int* ftab;      // [A * ns] featurize map: index into a trajectory's box sums [2][S]; bit 31 = a row of the temporal stack
+  const int* acnt;      // [A] cells in the actuator's sensor box (reward offset term)
   T* term_out;          // optional [B][A]
 };
 
@@ -241,63 +243,64 @@ __global__ void kseg2d_actuate_kernel(K2Dev<T> e, const T* __restrict__ action, 
   p[i] = a >= 0 ? e.agent_power * action[b * e.A + a] : (T)0;
 }
 
-// box sums of u and v for every sensor: sums [B][2][S]
+// box sums of u and v for every sensor: sums [B][2][S].  One wave per (trajectory, sensor row): the rows of that sensor row's
+// boxes are read once, whole and coalesced (four cells = 32 / 64 bytes per lane), into per-column sums in LDS, and each sensor
+// adds its own columns -- round 4; one thread per sensor walking its box cell by cell took 45 us at config C4 (67 MB: ~11 us).
+// Order of a box's additions: rows top to bottom inside a column, then the columns left to right.
 template <class T>
-__global__ void kseg2d_boxsum_kernel(K2Dev<T> e, const C2<T>* __restrict__ y, T* __restrict__ sums) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= e.B * e.S) return;
-  const int b = i / e.S, s = i - b * e.S, iy = s / e.Sx, ix = s - iy * e.Sx;
-  const int cy = e.sy[iy], cx = e.sx[ix];
-  const int r0 = max(cy - e.hw, 0), r1 = min(cy + e.hw, e.ny - 1), c0 = max(cx - e.hw, 0), c1 = min(cx + e.hw, e.nx - 1);
-  T su = 0, sv = 0;
+__global__ __launch_bounds__(64) void kseg2d_boxsum_kernel(K2Dev<T> e, const C2<T>* __restrict__ y, T* __restrict__ sums) {
+  extern __shared__ __align__(16) unsigned char k2bs_smem[];
+  T* cu = reinterpret_cast<T*>(k2bs_smem);          // [nx] column sums of u over the box rows
+  T* cv = cu + e.nx;                                // [nx] ... of v
+  const int b = blockIdx.x / e.Sy, iy = blockIdx.x - b * e.Sy, lane = threadIdx.x;
+  const int cy = e.sy[iy], r0 = max(cy - e.hw, 0), r1 = min(cy + e.hw, e.ny - 1);
   const C2<T>* yb = y + (size_t)b * e.ny * e.nx;
-  for (int r = r0; r <= r1; ++r)
-    for (int c = c0; c <= c1; ++c) {
-      const C2<T> v = yb[(size_t)r * e.nx + c];
-      su += v.x;
-      sv += v.y;
+  for (int c = 4 * lane; c < e.nx; c += 256) {      // nx is a multiple of 4
+    T su[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0};
+    for (int r = r0; r <= r1; ++r) {
+      const Quad<T> q = *reinterpret_cast<const Quad<T>*>(yb + (size_t)r * e.nx + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { su[i] += q.c[i].x; sv[i] += q.c[i].y; }
     }
-  sums[((size_t)b * 2 + 0) * e.S + s] = su;
-  sums[((size_t)b * 2 + 1) * e.S + s] = sv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cu[c + i] = su[i]; cv[c + i] = sv[i]; }
+  }
+  __syncthreads();
+  for (int ix = lane; ix < e.Sx; ix += 64) {
+    const int cx = e.sx[ix], c0 = max(cx - e.hw, 0), c1 = min(cx + e.hw, e.nx - 1);
+    T su = 0, sv = 0;
+    for (int c = c0; c <= c1; ++c) { su += cu[c]; sv += cv[c]; }
+    const int sidx = iy * e.Sx + ix;
+    sums[((size_t)b * 2 + 0) * e.S + sidx] = su;
+    sums[((size_t)b * 2 + 1) * e.S + sidx] = sv;
+  }
 }
 
 // reward (KellerSegelSetup.jl:241-257) and featurize (:265-316, 3x3 circular window in the
-// scripts/Fluid/setup/FluidSetup.jl:219-223 shift order): one thread per STATE ELEMENT (b, a, row), so consecutive
-// lanes write consecutive addresses; the row-0 thread of a column also evaluates its reward
+// scripts/Fluid/setup/FluidSetup.jl:219-223 shift order): one thread per STATE ELEMENT (a, row) of trajectory blockIdx.y, so
+// consecutive lanes write consecutive addresses; where an element comes from is a table made with the environment (ftab: the
+// per-element index arithmetic -- five divisions by run-time values -- took 73 - 125 us at config C4); the first A threads
+// of a trajectory also evaluate the rewards.
 template <class T>
 __global__ void kseg2d_feat_kernel(K2Dev<T> e, const T* __restrict__ sums, const T* __restrict__ action,
                                    const T* __restrict__ action_prev, const T* __restrict__ state_prev,
                                    T* __restrict__ state_out, T* __restrict__ reward_out, int32_t* __restrict__ done) {
-  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)e.B * e.A * e.ns;
-  if (gi >= total) return;
-  const int i = (int)(gi / e.ns), rr = (int)(gi - (size_t)i * e.ns);          // column, row
-  const int b = i / e.A, a = i - b * e.A, s = e.a2s[a], iy = s / e.Sx, ix = s - iy * e.Sx;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, per = e.A * e.ns, b = blockIdx.y;
+  if (idx >= per) return;
   const T* sb = sums + (size_t)b * 2 * e.S;
-  if (reward_out && rr == 0) {
-    const int cy = e.sy[iy], cx = e.sx[ix];
-    const int nr = min(cy + e.hw, e.ny - 1) - max(cy - e.hw, 0) + 1, nc = min(cx + e.hw, e.nx - 1) - max(cx - e.hw, 0) + 1;
-    const T d = e.r_in_scale * (sb[s] + e.r_offset * (T)(nr * nc));
+  if (reward_out && idx < e.A) {
+    const int i = b * e.A + idx;
+    const T d = e.r_in_scale * (sb[e.a2s[idx]] + e.r_offset * (T)e.acnt[idx]);
     const T av = action[i], da = av - action_prev[i];
     const T r = -k2_pow_abs<T>(d, e.r_power) / e.r_denom - e.a_pun * av * av - e.da_pun * da * da;
     reward_out[i] = r;
     if (done && e.check_max == 2 && !(fabs(r) <= e.max_value)) atomicOr(done + b, 1);
   }
   if (state_out) {
-    const int w = e.window / 2, ww = e.window * e.window, fresh = 2 * ww;
-    T v;
-    if (rr < fresh || state_prev == nullptr) {
-      const int r0 = rr % fresh, sp = r0 / ww, q = r0 - sp * ww;
-      const int di = q / e.window - w, dj = q - (q / e.window) * e.window - w;
-      // circshift(sensors, [di, dj])[iy, ix] = sensors[iy - di, ix - dj]
-      int jy = (iy - di) % e.Sy, jx = (ix - dj) % e.Sx;
-      if (jy < 0) jy += e.Sy;
-      if (jx < 0) jx += e.Sx;
-      v = sb[(size_t)sp * e.S + jy * e.Sx + jx] * e.sensor_scale;
-    } else {
-      v = state_prev[gi - fresh];
-    }
-    state_out[gi] = v;
+    const int t = e.ftab[idx];
+    const size_t gi = (size_t)b * per + idx;
+    // a row of the temporal stack: the previous state's row `fresh` places up (fresh = 2 window^2); reset form: the fresh value again
+    state_out[gi] = (t < 0 && state_prev) ? state_prev[gi - 2 * e.window * e.window] : sb[t & 0x7fffffff] * e.sensor_scale;
   }
 }
 
@@ -311,7 +314,7 @@ __global__ void kseg2d_terminal_kernel(K2Dev<T> e, const int32_t* __restrict__ d
 
 struct Kseg2dEnv : Env {
   int nx = 0, ny = 0, Sx = 0, Sy = 0, hw = 0, nsub = 1;
-  DevBuf sx, sy, a2s_d, cell_act, sums, pbuf, ytmp, done_tmp;
+  DevBuf sx, sy, a2s_d, cell_act, ftab, acnt, sums, pbuf, ytmp, done_tmp;
   size_t lds1 = 0, lds2 = 0;
   static constexpr int MAXPART = 4;       // parts of the batch on their own streams during the RK4 sub-steps (k2_integrate)
   hipStream_t pstream[MAXPART] = {nullptr, nullptr, nullptr, nullptr};        // [0] unused: part 0 runs on the environment's stream
@@ -343,6 +346,7 @@ static K2Dev<T> k2_dev(const Kseg2dEnv& E) {
   d.sensor_scale = (T)c.sensor_scale; d.agent_power = (T)c.agent_power; d.r_in_scale = (T)c.reward_in_scale;
   d.r_offset = (T)c.reward_offset; d.r_power = (T)c.reward_power; d.r_denom = (T)c.reward_denom;
   d.a_pun = (T)c.action_punish; d.da_pun = (T)c.delta_action_punish; d.max_value = (T)c.max_value;
+  d.ftab = E.ftab.as<int>(); d.acnt = E.acnt.as<int>();
   d.sx = E.sx.as<int>(); d.sy = E.sy.as<int>(); d.a2s = E.a2s_d.as<int>(); d.cell_act = E.cell_act.as<int>();
   d.term_out = (T*)E.term_out;
   return d;
@@ -486,12 +490,11 @@ static int k2_sense(Kseg2dEnv& E, const void* y, const void* action, const void*
                     void* state_out, void* reward_out, int32_t* done) {
   const size_t need = (size_t)E.cfg.B * 2 * E.cfg.S * sizeof(T);
   if (E.sums.bytes < need) PDEC_HIP(E.sums.alloc(need));
-  const int nS = E.cfg.B * E.cfg.S, nA = E.cfg.B * E.cfg.A;
-  hipLaunchKernelGGL(kseg2d_boxsum_kernel<T>, dim3((nS + 127) / 128), dim3(128), 0, E.stream, k2_dev<T>(E), (const C2<T>*)y,
-                     E.sums.as<T>());
+  hipLaunchKernelGGL(kseg2d_boxsum_kernel<T>, dim3(E.cfg.B * E.Sy), dim3(64), 2 * (size_t)E.nx * sizeof(T), E.stream, k2_dev<T>(E),
+                     (const C2<T>*)y, E.sums.as<T>());
   PDEC_HIP(hipGetLastError());
-  const size_t nel = (size_t)nA * (2 * E.cfg.window * E.cfg.window * E.cfg.temporal_steps);
-  hipLaunchKernelGGL(kseg2d_feat_kernel<T>, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, E.stream, k2_dev<T>(E), E.sums.as<T>(),
+  const int per = E.cfg.A * (2 * E.cfg.window * E.cfg.window * E.cfg.temporal_steps);
+  hipLaunchKernelGGL(kseg2d_feat_kernel<T>, dim3((per + 255) / 256, E.cfg.B), dim3(256), 0, E.stream, k2_dev<T>(E), E.sums.as<T>(),
                      (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)state_out, (T*)reward_out, done);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
@@ -609,6 +612,25 @@ extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, i
   if ((rc = up_i(E->sy, sensor_y, Sy))) return rc;
   if ((rc = up_i(E->a2s_d, a2s, c.A))) return rc;
   if ((rc = up_i(E->cell_act, ca.data(), ca.size()))) return rc;
+  {   // featurize map and box cell counts (kseg2d_feat_kernel)
+    const int w = c.window / 2, ww = c.window * c.window, fresh = 2 * ww, ns = fresh * c.temporal_steps;
+    std::vector<int32_t> ft((size_t)c.A * ns), cnt(c.A);
+    for (int a = 0; a < c.A; ++a) {
+      const int s = a2s[a], iy = s / Sx, ix = s % Sx;
+      const int cy = sensor_y[iy], cx = sensor_x[ix];
+      cnt[a] = (std::min(cy + half_window, ny - 1) - std::max(cy - half_window, 0) + 1) *
+               (std::min(cx + half_window, c.N - 1) - std::max(cx - half_window, 0) + 1);
+      for (int rr = 0; rr < ns; ++rr) {
+        const int r0 = rr % fresh, sp = r0 / ww, q = r0 - sp * ww;
+        const int di = q / c.window - w, dj = q % c.window - w;
+        // circshift(sensors, [di, dj])[iy, ix] = sensors[iy - di, ix - dj]
+        const int jy = (((iy - di) % Sy) + Sy) % Sy, jx = (((ix - dj) % Sx) + Sx) % Sx;
+        ft[(size_t)a * ns + rr] = (sp * c.S + jy * Sx + jx) | (rr >= fresh ? (int32_t)0x80000000 : 0);
+      }
+    }
+    if ((rc = up_i(E->ftab, ft.data(), ft.size()))) return rc;
+    if ((rc = up_i(E->acnt, cnt.data(), cnt.size()))) return rc;
+  }
   auto set_lds = [](const void* f, size_t bytes) -> int {
     PDEC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return PDEC_OK;
