@@ -2548,6 +2548,7 @@ int pdec_featurize_action(pdec_handle h, const void* y, const void* prev_state, 
   if (!action || E->cfg.memory_size == 0) return pdec_featurize(h, y, prev_state, state_out);
   PDEC_REQUIRE(y && state_out, "pdec_featurize_action: null");
   PDEC_REQUIRE(prev_state != state_out, "pdec_featurize_action: state_out must not alias prev_state");
+  if (E->cfg.pde_kind == PDEC_PDE_FLUID_RK4) return fluid_featurize(*E, y, prev_state, state_out, action);
   return E->cfg.dtype == PDEC_F64 ? launch_sense<double>(*E, 1, y, action, nullptr, prev_state, state_out)
                                   : launch_sense<float>(*E, 1, y, action, nullptr, prev_state, state_out);
 }

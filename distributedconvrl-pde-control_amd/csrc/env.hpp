@@ -71,7 +71,7 @@ int fluid_env_step(Env& E, const void* y_in, const void* action, const void* act
 int fluid_pde_step(Env& E, const void* y_in, const void* p, void* y_out, int32_t* done);
 int fluid_rhs_eval(Env& E, const void* y, const void* p, void* out);
 int fluid_actuate(Env& E, const void* action, void* p_out);
-int fluid_featurize(Env& E, const void* y, const void* state_prev, void* state_out);
+int fluid_featurize(Env& E, const void* y, const void* state_prev, void* state_out, const void* action = nullptr);
 int fluid_reward(Env& E, const void* y, const void* action, const void* action_prev, void* r_out);
 
 // kseg2d.hip: Keller-Segel on a 2-D grid (BASELINE.json configs[3]; the reference's 1-D rules along both axes)
@@ -96,7 +96,7 @@ inline size_t env_p_count(const pdec_env_cfg& c) {
 }
 inline int env_ns(const pdec_env_cfg& c) {
   if (c.mono) return c.S;
-  if (c.pde_kind == PDEC_PDE_FLUID_RK4) return c.window * c.window * c.temporal_steps;
+  if (c.pde_kind == PDEC_PDE_FLUID_RK4) return c.window * c.window * c.temporal_steps + c.memory_size;
   if (c.pde_kind == PDEC_PDE_KSEG2D_RK4) return 2 * c.window * c.window * c.temporal_steps;
   return c.window * c.n_species * c.temporal_steps + c.memory_size;
 }

@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void fluid_dots_kernel(int n, int S, int BH, i
 template <class T>
 struct FeatArgs {
   int S, A, spa, window, ns, check_max;
+  int mem, na;      // action memory (cfg.memory_size): the last mem rows of a state column = rows 1.. of the action [A][na]
   T sensor_scale, r_in_scale, r_power, r_denom, a_pun, da_pun, max_value;
   const int* a2s;
 };
@@ -416,7 +417,9 @@ __global__ __launch_bounds__(256) void fluid_feat_kernel(FeatArgs<T> g, const T*
     for (int idx = tid; idx < g.A * g.ns; idx += nt) {
       const int a = idx / g.ns, rr = idx - a * g.ns;
       T v;
-      if (rr < fresh || prev == nullptr) {
+      if (rr >= g.ns - g.mem) {          // FluidSetup.jl:236-241: env.action[end-(memory_size-1):end, :], zeros without env
+        v = action ? action[((size_t)b * g.A + a) * g.na + 1 + (rr - (g.ns - g.mem))] : (T)0;
+      } else if (rr < fresh || prev == nullptr) {
         const int r0 = rr % fresh, wi = r0 / g.window - w, wj = r0 % g.window - w;
         const int e = g.a2s[a];
         int row = (e / g.spa - wi) % g.spa, col = (e % g.spa - wj) % g.spa;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void fluid_feat_kernel(FeatArgs<T> g, const T*
     for (int a = tid; a < g.A; a += nt) {
       const T dd = fabs(g.r_in_scale * dt[g.a2s[a]]);
       const T pw = dd == 0 ? (T)0 : (T)pow((double)dd, (double)g.r_power);
-      const T ac = action[(size_t)b * g.A + a], da = ac - action_prev[(size_t)b * g.A + a];
+      const T ac = action[((size_t)b * g.A + a) * g.na], da = ac - action_prev[((size_t)b * g.A + a) * g.na];   // row 1 (:200)
       const T r = -fabs(pw / g.r_denom) - g.a_pun * ac * ac - g.da_pun * da * da;
       reward_out[(size_t)b * g.A + a] = r;
       if (g.check_max == 2 && !(fabs(r) <= g.max_value)) atomicOr(&flag, 1);
@@ -467,7 +470,7 @@ template <class T>
 __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH, int BW, int nb1,
                                                             const T* __restrict__ boxes, const int* __restrict__ origin,
                                                             const int* __restrict__ blk_ptr, const int* __restrict__ blk_idx,
-                                                            const T* __restrict__ action, T power, T* __restrict__ preal) {
+                                                            const T* __restrict__ action, int na, T power, T* __restrict__ preal) {
   const int blk = blockIdx.x, b = blockIdx.y;
   const int bj = blk / nb1, bi = blk - bj * nb1;
   const int di = threadIdx.x & 15, dj = threadIdx.x >> 4;
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256) void fluid_actuate_kernel(int n, int A, int BH
     int dj2 = j - origin[2 * a], di2 = i - origin[2 * a + 1];
     if (dj2 < 0) dj2 += n;
     if (di2 < 0) di2 += n;
-    if (dj2 < BW && di2 < BH) acc += (power * action[(size_t)b * A + a]) * boxes[((size_t)a * BW + dj2) * BH + di2];
+    if (dj2 < BW && di2 < BH) acc += (power * action[((size_t)b * A + a) * na]) * boxes[((size_t)a * BW + dj2) * BH + di2];
   }
   preal[((size_t)b * n + j) * n + i] = acc;
 }
@@ -1250,7 +1253,8 @@ static FeatArgs<double> feat_args(const FluidEnv& E) {
   const pdec_env_cfg& c = E.cfg;
   FeatArgs<double> g;
   g.S = c.S; g.A = c.A; g.spa = c.sensors_per_axis; g.window = c.window;
-  g.ns = c.window * c.window * c.temporal_steps; g.check_max = c.check_max_value;
+  g.ns = env_ns(c); g.check_max = c.check_max_value;
+  g.mem = c.memory_size; g.na = env_na(c);
   g.sensor_scale = c.sensor_scale; g.r_in_scale = c.reward_in_scale; g.r_power = c.reward_power;
   g.r_denom = c.reward_denom; g.a_pun = c.action_punish; g.da_pun = c.delta_action_punish; g.max_value = c.max_value;
   g.a2s = E.a2s_d.as<int>();
@@ -1278,7 +1282,7 @@ int fluid_actuate(Env& E0, const void* action, void* p_out) {
   ProfScope ps(&E, "fluid_actuate");
   hipLaunchKernelGGL(fluid_actuate_kernel<double>, dim3(E.nb1 * E.nb1, c.B), dim3(256), 0, E.stream, E.n, c.A, E.BH, E.BW,
                      E.nb1, E.abox.as<double>(), E.aorg.as<int>(), E.blkptr.as<int>(), E.blkidx.as<int>(),
-                     (const double*)action, c.agent_power, E.yreal.as<double>());
+                     (const double*)action, env_na(c), c.agent_power, E.yreal.as<double>());
   hipLaunchKernelGGL((fluid_fft_fast_kernel<double, -1, true>), dim3(gt, c.B), dim3(FL_NTH), E.lds_n, E.stream, d,
                      E.yreal.p, E.tmpc.as<Z>());
   hipLaunchKernelGGL((fluid_fft_slow_kernel<double, -1, false>), dim3(gt, c.B), dim3(FL_NTH), E.lds_n, E.stream, d,
@@ -1287,11 +1291,11 @@ int fluid_actuate(Env& E0, const void* action, void* p_out) {
   return PDEC_OK;
 }
 
-int fluid_featurize(Env& E0, const void* y, const void* state_prev, void* state_out) {
+int fluid_featurize(Env& E0, const void* y, const void* state_prev, void* state_out, const void* action) {
   FluidEnv& E = as_fluid(E0);
   int rc = fluid_dots(E, y);
   if (rc) return rc;
-  return fluid_feat_launch(E, nullptr, nullptr, state_prev, state_out, nullptr, nullptr);
+  return fluid_feat_launch(E, action, nullptr, state_prev, state_out, nullptr, nullptr);   // (action: the memory rows only)
 }
 
 int fluid_reward(Env& E0, const void* y, const void* action, const void* action_prev, void* r_out) {
@@ -1332,7 +1336,7 @@ int fluid_env_step(Env& E0, const void* y_in, const void* action, const void* ac
   if (E.nparts >= 2 && !E.prof) {
     // the parts of the batch side by side: every argument is batch-major, so a part is a pointer offset.  (Per-kernel
     // timing passes, pdec_prof_enable, take the whole batch on one stream.)
-    const size_t nn = (size_t)E.n * E.n, A = E.cfg.A, ns = (size_t)E.cfg.window * E.cfg.window * E.cfg.temporal_steps;
+    const size_t nn = (size_t)E.n * E.n, A = E.cfg.A, ns = (size_t)env_ns(E.cfg), na = (size_t)env_na(E.cfg);
     auto off = [](const void* p, size_t bytes) -> const void* { return p ? (const char*)p + bytes : nullptr; };
     auto offm = [](void* p, size_t bytes) -> void* { return p ? (char*)p + bytes : nullptr; };
     PDEC_HIP(hipEventRecord(E.ev_fork, E.stream));
@@ -1342,7 +1346,7 @@ int fluid_env_step(Env& E0, const void* y_in, const void* action, const void* ac
       H.stream = hh == 0 ? E.stream : E.pstream[hh];
       if (hh > 0) PDEC_HIP(hipStreamWaitEvent(H.stream, E.ev_fork, 0));
       H.term_out = E.term_out ? (char*)E.term_out + (size_t)b0 * A * 8 : nullptr;
-      const int rc = fluid_env_step(H, off(y_in, b0 * nn * 16), off(action, b0 * A * 8), off(action_prev, b0 * A * 8),
+      const int rc = fluid_env_step(H, off(y_in, b0 * nn * 16), off(action, b0 * A * na * 8), off(action_prev, b0 * A * na * 8),
                                     off(state_prev, b0 * A * ns * 8), offm(y_out, b0 * nn * 16), offm(p_out, b0 * nn * 16),
                                     offm(state_out, b0 * A * ns * 8), offm(reward_out, b0 * A * 8), done ? done + b0 : nullptr);
       if (rc) return rc;
@@ -1382,6 +1386,7 @@ static int fluid_make(std::unique_ptr<FluidEnv>& out, const pdec_env_cfg& c, int
   PDEC_REQUIRE(c.window >= 1 && (c.window & 1) && c.window <= c.sensors_per_axis && c.temporal_steps >= 1 && !c.mono,
                "pdec_fluid_env_create: window must be odd and <= sensors_per_axis; no mono variant");
   PDEC_REQUIRE(BH >= 1 && BW >= 1 && BH <= n && BW <= n, "pdec_fluid_env_create: bad box %dx%d", BH, BW);
+  PDEC_REQUIRE(c.memory_size >= 0 && c.memory_size <= 64, "pdec_fluid_env_create: memory_size %d out of range", c.memory_size);
   PDEC_REQUIRE(c.Lx > 0 && c.dt > 0, "pdec_fluid_env_create: Lx and dt must be positive");
   for (int a = 0; a < c.A; ++a) PDEC_REQUIRE(a2s[a] >= 0 && a2s[a] < c.S, "pdec_fluid_env_create: a2s[%d] out of range", a);
   for (int s = 0; s < c.S; ++s)

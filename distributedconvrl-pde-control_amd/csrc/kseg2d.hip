@@ -578,6 +578,7 @@ extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, i
   PDEC_REQUIRE(c.B >= 1 && c.B <= 65535 && c.N >= 4 && c.N % 4 == 0 && ny >= 1 && c.K >= 1,
                "pdec_kseg2d_env_create: bad sizes B=%d nx=%d (multiple of 4) ny=%d K=%d", c.B, c.N, ny, c.K);
   PDEC_REQUIRE(c.n_species == 2 && !c.mono, "Keller-Segel has two species and no mono variant");
+  PDEC_REQUIRE(c.memory_size == 0, "pdec_kseg2d_env_create: action memory is not built for the 2-D grid (a configuration of this build, not of the reference)");
   PDEC_REQUIRE(Sx >= 1 && Sy >= 1 && Sx * Sy == c.S && c.A >= 1 && half_window >= 0,
                "pdec_kseg2d_env_create: S must equal Sx*Sy");
   PDEC_REQUIRE(c.window >= 1 && (c.window & 1) && c.temporal_steps >= 1, "pdec_kseg2d_env_create: window must be odd >= 1");

@@ -84,7 +84,7 @@ class FluidSetup:
         self.window_size, self.temporal_steps, self.memory_size, self.mono, self.n_species = \
             window_size, int(temporal_steps), int(memory_size), False, 1
         from .ks import _refuse_unbuilt_branches
-        _refuse_unbuilt_branches(self, "scripts/Fluid/setup/FluidSetup.jl:229-241")
+        _refuse_unbuilt_branches(self, "scripts/Fluid/setup/FluidSetup.jl:229-241", memory_built=True, reward_check_with_memory=True)
         self.nna_scale, self.nna_scale_critic, self.drop_middle_layer = nna_scale, nna_scale_critic, drop_middle_layer
         self.gamma, self.rho, self.batch_size = gamma, rho, batch_size
         self.start_steps, self.update_after, self.update_freq, self.update_loops = \
@@ -168,7 +168,7 @@ class FluidSetup:
 
     @property
     def state_shape(self):
-        return (self.window_size ** 2 * self.temporal_steps, self.n_actuators)
+        return (self.window_size ** 2 * self.temporal_steps + self.memory_size, self.n_actuators)
 
     @property
     def action_shape(self):
@@ -220,6 +220,7 @@ class FluidSetup:
         c.reward_power, c.reward_denom = 1.1, 320.0                 # :197
         c.action_punish, c.delta_action_punish = self.action_punish, self.delta_action_punish
         c.ifpad, c.sensors_per_axis, c.nu = self.ifpad, self.sensors_per_axis, self.nu
+        c.memory_size = self.memory_size
         return c
 
     def box_tables(self):

@@ -26,15 +26,15 @@ def prepare_gaussians(nx, Lx, positions, sigma, norm_mode):
     return out
 
 
-def _refuse_unbuilt_branches(setup, where, memory_built=False):
+def _refuse_unbuilt_branches(setup, where, memory_built=False, reward_check_with_memory=False):
     """memory_size > 0 (action memory: src/PDEagent.jl:201 + the featurize branch cited in `where`) is built for the 1-D
-    per-actuator environments (KS, Keller-Segel: the composed env step, csrc/env.hip env_step_composed); elsewhere -- the
-    global agent, the 2-D environments -- and a temporal stack for the mono / global agent are optional branches no shipped
+    per-actuator environments (KS, Keller-Segel: the composed env step, csrc/env.hip env_step_composed) and the fluid (its
+    sensing kernels); elsewhere -- the global agent, the 2-D Keller-Segel grid -- and a temporal stack for the mono / global agent are optional branches no shipped
     script sets; a caller who sets them gets an error, not silence"""
     if setup.memory_size < 0 or (setup.memory_size != 0 and not memory_built):
         raise _lib.PdecError(f"memory_size = {setup.memory_size}: the action-memory branch of featurize / the acting path "
                              f"({where}, src/PDEagent.jl:201) is not built for this setup; only memory_size = 0 is supported")
-    if setup.memory_size != 0 and getattr(setup, "check_max_value", "y") == "reward":
+    if setup.memory_size != 0 and getattr(setup, "check_max_value", "y") == "reward" and not reward_check_with_memory:
         raise _lib.PdecError("memory_size > 0 with check_max_value = 'reward' is not built (the composed env step tests 'y' only)")
     if setup.temporal_steps < 1 or (getattr(setup, "mono", False) and setup.temporal_steps != 1):
         raise _lib.PdecError(f"temporal_steps = {setup.temporal_steps} is not supported for this setup ({where})")

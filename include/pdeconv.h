@@ -139,7 +139,8 @@ typedef struct pdec_env_cfg {
   /* action memory (scripts/KS/setup/KSSetup.jl:39,48,216-226; src/PDEagent.jl:201; 0 in every shipped script): the actor has
    * 1 + memory_size outputs per actuator; row 0 drives the PDE and the reward, rows 1.. come back as the LAST memory_size rows
    * of the next state (zeros at a reset).  action arrays become [B][A][1 + memory_size], state columns grow by memory_size.
-   * 1-D per-actuator kinds only (KS CNAB2, KS RK4+FD, Keller-Segel); PDEC_E_INVALID for mono / 2-D environments. */
+   * Per-actuator kinds of the reference (KS CNAB2, KS RK4+FD, Keller-Segel, fluid); PDEC_E_INVALID for the global agent
+ * (mono) and the 2-D Keller-Segel grid. */
   int memory_size;
 } pdec_env_cfg;
 

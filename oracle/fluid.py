@@ -171,10 +171,11 @@ def error_detection(yhat):
     return bool(y_x.max() > 10.0 or y_y.max() > 10.0)
 
 
-def featurize(cfg, yhat, prev_state=None):
-    """scripts/Fluid/setup/FluidSetup.jl:204-245 (memory_size=0).  temporal_steps > 1 (:229-237; 1 in the shipped scripts):
+def featurize(cfg, yhat, prev_state=None, action=None):
+    """scripts/Fluid/setup/FluidSetup.jl:204-245.  temporal_steps > 1 (:229-237; 1 in the shipped scripts):
     prev_state=None is the `isnothing(env)` branch (fresh rows repeated), otherwise the fresh rows are stacked on the newest
-    rows of the previous state."""
+    rows of the previous state (without its memory rows).  memory_size > 0 (cfg.memory_size, :238-244; 0 in the shipped script):
+    the last rows are rows 2.. of env.action (`action`), zeros in the `isnothing(env)` form."""
     y = np.real(np.fft.ifft2(yhat))
     spa = cfg.sensors_per_axis
     dots = np.tensordot(cfg.gaussians, y, axes=([1, 2], [0, 1])) / 70         # :216
@@ -193,7 +194,13 @@ def featurize(cfg, yhat, prev_state=None):
             result = np.concatenate([result] * T)                             # :231-234
         else:
             prev = np.asarray(prev_state, dtype=np.float64)
-            result = np.concatenate([result, prev[:prev.shape[0] - result.shape[0], :]])   # :236
+            result = np.concatenate([result, prev[:prev.shape[0] - result.shape[0] - int(getattr(cfg, "memory_size", 0)), :]])   # :236
+    m = int(getattr(cfg, "memory_size", 0))
+    if m > 0:                                                                 # :240
+        if action is None:
+            result = np.concatenate([result, np.zeros((m, result.shape[1]))])  # :242
+        else:
+            result = np.concatenate([result, np.asarray(action, dtype=np.float64)[-m:, :]])   # :244
     return result
 
 

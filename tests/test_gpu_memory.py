@@ -113,6 +113,58 @@ def test_keller_segel_env_step_with_action_memory_matches_oracle(pkg):
             yo[b], state[b], aprev[b] = yn, st, act[b]
 
 
+@pytest.mark.parametrize("n,B,T", [(32, 3, 1), (32, 3, 2), (512, 8, 1)])
+def test_fluid_env_step_with_action_memory_matches_oracle(pkg, n, B, T):
+    """fluid (FluidSetup.jl:229-244): 3 x 3 window x temporal stack + 2 memory rows; two control steps against the oracle's
+    closures on a 32 x 32 grid; on the 512 x 512 grid (B = 8: two half-batch children, the action rows sliced per child) the
+    state is checked through its structure -- memory rows = rows 2.. of the action, window rows = the memory-free environment's"""
+    from oracle import fluid
+    m = 2
+    if n == 32:
+        spa, K = 4, 2
+        setup = pkg.FluidSetup(nx=n, ifpad=1, sensors_per_axis=spa, variance=0.08, oversampling=K, temporal_steps=T, memory_size=m)
+        cfg = fluid.FluidConfig(nx=n, ifpad=1, sensors_per_axis=spa, variance=0.08, oversampling=K)
+        cfg.temporal_steps, cfg.memory_size = T, m
+        rng = np.random.default_rng(21)
+        y = np.stack([fluid.ic(cfg, 4, rng) for _ in range(B)])
+        A, na = spa * spa, 1 + m
+        assert setup.state_shape == (9 * T + m, A) and setup.action_shape == (na, A)
+        ymem = np.ascontiguousarray(np.stack([np.stack([y[b].T.real, y[b].T.imag], axis=-1) for b in range(B)]))
+        env = pkg.PDEenv(setup, B=B, dtype=F64, y0=ymem, autoreset=False)
+        state = [fluid.featurize(cfg, y[b], None, None) for b in range(B)]
+        for b in range(B):
+            assert np.abs(_col(env.state[b]) - state[b]).max() <= 1e-12 and not state[b][-m:].any()
+        yo, aprev = [y[b] for b in range(B)], [np.zeros((na, A)) for _ in range(B)]
+        for t in range(2):
+            act = rng.uniform(-1, 1, (B, na, A))
+            env(to_dev(np.swapaxes(act, 1, 2), F64))
+            for b in range(B):
+                p = fluid.prepare_action(cfg, act[b])
+                yn = fluid.do_step(cfg, yo[b], p, K)
+                r = fluid.reward_function(cfg, yn, act[b], act[b] - aprev[b])
+                st = fluid.featurize(cfg, yn, state[b], act[b])
+                got = env.y[b].cpu().numpy()
+                assert np.abs((got[..., 0] + 1j * got[..., 1]).T - yn).max() <= 1e-11 * np.abs(yn).max()
+                assert np.abs(env.reward[b].cpu().numpy() - r).max() <= 1e-11 * max(1.0, np.abs(r).max())
+                assert np.abs(_col(env.state[b]) - st).max() <= 1e-11 * max(1.0, np.abs(st).max())
+                yo[b], state[b], aprev[b] = yn, st, act[b]
+        return
+    setup_m = pkg.FluidSetup(nx=n, sensors_per_axis=16, variance=0.04, memory_size=m, oversampling=3)
+    setup_0 = pkg.FluidSetup(nx=n, sensors_per_axis=16, variance=0.04, oversampling=3)
+    em = pkg.PDEenv(setup_m, B=B, dtype=F64, autoreset=False)
+    e0 = pkg.PDEenv(setup_0, B=B, dtype=F64, autoreset=False)
+    assert em.n_part_streams == 1
+    y0 = setup_0.random_init_device(e0, np.random.default_rng(4))
+    em.set_y0(y0); e0.set_y0(y0)
+    A = setup_m.n_actuators
+    act = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, (B, A, 1 + m))).cuda()
+    em(act)
+    e0(act[..., :1].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(em.y, e0.y) and torch.equal(em.reward, e0.reward)
+    assert torch.equal(em.state[..., :9], e0.state) and torch.equal(em.state[..., 9:], act[..., 1:])
+
+
 def test_policy_noise_spares_the_memory_rows(pkg):
     """(policy)(env) with memory_size = 2 (src/PDEagent.jl:201): noise on row 1 only, clamp on every row; against the oracle
     with the device's own Philox draws, and the rows without noise equal the actor's clamped outputs exactly"""
@@ -168,7 +220,7 @@ def test_ddpg_update_with_memory_shaped_nets_matches_oracle(pkg):
 
 
 def test_memory_is_refused_where_it_is_not_built(pkg):
-    for mk in (lambda: pkg.KSSetup.bench_C2(256, memory_size=1, mono=True), lambda: pkg.FluidSetup(nx=64, memory_size=1),
+    for mk in (lambda: pkg.KSSetup.bench_C2(256, memory_size=1, mono=True),
                lambda: pkg.KellerSegel2DSetup(nx=32, ny=32, memory_size=1),
                lambda: pkg.KSSetup.bench_C2(256, memory_size=1, check_max_value="reward")):
         with pytest.raises(pkg.PdecError, match="memory_size"):

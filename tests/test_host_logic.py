@@ -285,18 +285,19 @@ def test_jld2_writer_roundtrip_and_checksums(pkg, tmp_path):
 
 
 def test_optional_featurize_branches_are_refused_or_restated(pkg):
-    """memory_size > 0 (KSSetup.jl:220-226, PDEagent.jl:201): built for the 1-D per-actuator setups since round 4 (shapes
-    here, GPU parity in tests/test_gpu_memory.py), refused -- an error, not silence -- by the global agent, the 2-D setups and
+    """memory_size > 0 (KSSetup.jl:220-226, PDEagent.jl:201): built for the per-actuator setups of the reference (KS, Keller-Segel, fluid) since round 4 (shapes
+    here, GPU parity in tests/test_gpu_memory.py), refused -- an error, not silence -- by the global agent, the 2-D Keller-Segel grid and
     together with the reward-based blow-up test; temporal_steps > 1 is accepted (the step kernels' general featurize path) and
     the oracle restates both branches of KSSetup.jl:209-218 and the memory rows of :220-226"""
     from oracle import ks
-    for mk in (lambda **k: pkg.KSSetup.KS22_global(**k), lambda **k: pkg.FluidSetup(nx=32, sensors_per_axis=4, **k),
-               lambda **k: pkg.KellerSegel2DSetup(**k), lambda **k: pkg.KSSetup.KS22(check_max_value="reward", **k),
+    for mk in (lambda **k: pkg.KSSetup.KS22_global(**k), lambda **k: pkg.KellerSegel2DSetup(**k), lambda **k: pkg.KSSetup.KS22(check_max_value="reward", **k),
                lambda **k: pkg.KSSetup.KS22(**{**k, "memory_size": -1})):
         with pytest.raises(pkg.PdecError, match="memory_size"):
             mk(memory_size=2)
     sm = pkg.KSSetup.KS22(window_size=3, temporal_steps=2, memory_size=2)
     assert sm.state_shape == (8, 8) and sm.action_shape == (3, 8) and sm.env_cfg(1, 0).memory_size == 2
+    fm = pkg.FluidSetup(nx=32, sensors_per_axis=4, memory_size=2)
+    assert fm.state_shape == (11, 16) and fm.action_shape == (3, 16) and fm.env_cfg(1, 1).memory_size == 2
     km = pkg.KellerSegelSetup(memory_size=1)
     assert km.state_shape == (13, km.n_actuators) and km.action_shape == (2, km.n_actuators) and km.env_cfg(1, 0).memory_size == 1
     cm = ks.KSConfig(192, 22.0, np.arange(1, 193, 24), sigma_sensors=0.7, sigma_actuators=0.7, window_size=3, temporal_steps=2)
