@@ -218,6 +218,9 @@ function Flux.params(m::HipMLP)
     unflatten(m, flat)
 end
 Base.copyto!(dst::HipMLP, src::HipMLP) = check(ccall((:pdec_mlp_copy, LIB), Cint, (UInt64, UInt64), dst.h, src.h))
+# memory_size > 0 (EnvCfg(memory_size = m); actions [1 + m, A]): exploration noise on the first `rows` actor outputs only,
+# as actions[1:end-memory_size, :] += randn * act_noise does (src/PDEagent.jl:201)
+set_noise_rows!(m::HipMLP, rows::Integer) = check(ccall((:pdec_mlp_set_noise_rows, LIB), Cint, (UInt64, Cint), m.h, rows))
 function Base.deepcopy(m::HipMLP)                       # PDEhook snapshots the actor (src/PDEhook.jl:37-38)
     h = Ref{UInt64}(0)
     check(ccall((:pdec_mlp_create, LIB), Cint, (Ref{UInt64}, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Cvoid}, Cint),
