@@ -196,6 +196,14 @@ class CustomDDPGPolicy:
         self._acting = {}                                 # dtype -> promoted acting copy of the actor
         self._noise = None
         self._actions = None
+        self._set_noise_rows(m)
+
+    def _set_noise_rows(self, model):
+        """action memory: exploration noise on the driving rows only (src/PDEagent.jl:201: actions[1:end-memory_size, :] += ...);
+        a property of the network object, so every caller of the acting kernels -- this policy, TrainPipeline, rollouts --
+        gets it"""
+        if self.memory_size:
+            _lib.check(self.lib.pdec_mlp_set_noise_rows(model.handle, model.dims[-1] - self.memory_size))
 
     # ---- acting (src/PDEagent.jl:175-209)
     def _actor_for(self, dtype, cols):
@@ -205,6 +213,7 @@ class CustomDDPGPolicy:
         key = (dtype, cols)
         if key not in self._acting:
             self._acting[key] = m.clone(dtype=dtype, max_cols=max(cols, 1))
+            self._set_noise_rows(self._acting[key])
         else:
             _lib.check(self.lib.pdec_mlp_copy(self._acting[key].handle, m.handle))
         return self._acting[key]
@@ -218,10 +227,6 @@ class CustomDDPGPolicy:
         cols = s.shape[0] * s.shape[1]
         actor = self._actor_for(env.dtype, cols)
         na = actor.dims[-1]
-        if self.memory_size and getattr(actor, "_noise_rows", None) != na - self.memory_size:
-            # action memory: noise on the driving rows only (src/PDEagent.jl:201: actions[1:end-memory_size, :] += ...)
-            _lib.check(self.lib.pdec_mlp_set_noise_rows(actor.handle, na - self.memory_size))
-            actor._noise_rows = na - self.memory_size
         if self._actions is None or self._actions.shape != (cols, na) or self._actions.dtype != env.dtype:
             # two buffers, alternated: the env may adopt the returned tensor without copying (PDEenv.__call__(adopt=True))
             self._action_ring = [torch.empty((cols, na), dtype=env.dtype, device=env.device) for _ in range(2)]

@@ -188,6 +188,16 @@ def test_policy_noise_spares_the_memory_rows(pkg):
     got = a.reshape(cols, 1 + m).cpu().numpy().T
     assert np.abs(got - want).max() <= 1e-12
     assert torch.equal(a[..., 1:], quiet[..., 1:]) and not torch.equal(a[..., 0], quiet[..., 0])
+    # the mask is a property of the network object (set at agent creation), so callers that enqueue the acting kernel
+    # themselves -- TrainPipeline: pdec_policy_act_rng_dev on the behaviour actor -- get it as well
+    m32 = pol.behavior_actor.model
+    s32 = env.state.reshape(cols, -1).float().contiguous()
+    out = [torch.empty((cols, 1 + m), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    for o, learning in zip(out, (1, 0)):
+        pkg._lib.check(pol.lib.pdec_policy_act_rng_dev(m32.handle, pkg._lib.ptr(s32), cols, 0.4, float(setup.act_limit), learning, 123,
+                                                       pkg._lib.ptr(o)))
+    torch.cuda.synchronize()
+    assert torch.equal(out[0][:, 1:], out[1][:, 1:]) and not torch.equal(out[0][:, 0], out[1][:, 0])
 
 
 def test_ddpg_update_with_memory_shaped_nets_matches_oracle(pkg):
