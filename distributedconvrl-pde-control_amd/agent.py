@@ -38,6 +38,45 @@ class RandomPolicy:
         return torch.as_tensor(self.rng.uniform(-1, 1, env._ashape), dtype=env.dtype, device=env.device)
 
 
+class NegatePolicy:
+    """scripts/Fluid/setup/FluidSetup.jl:277-299: the hand-written baseline controller of the fluid script -- after the start
+    steps, action[i] = clamp(-env.state[i], -1, 1) for the first length(action) entries of the state in Julia's column-major
+    order (state [ns, A], action [na, A]; the device arrays [B, A, ns] / [B, A, na] flatten in the same order per
+    trajectory).  No networks, nothing to train."""
+
+    def __init__(self, action_shape, start_steps=0, start_policy=None):
+        self.action_shape, self.start_steps = action_shape, start_steps
+        self.start_policy = start_policy or ZeroPolicy(action_shape)
+        self.update_step = 0
+        self.reset_stage = POST_EPISODE_STAGE
+
+    def __call__(self, env, learning=True, test=False):
+        self.update_step += 1
+        if self.update_step <= self.start_steps:
+            return self.start_policy(env)
+        B = env.state.shape[0]
+        n = int(np.prod(env._ashape[1:]))
+        return (-env.state.reshape(B, -1)[:, :n]).clamp(-1.0, 1.0).reshape(env._ashape).contiguous()
+
+
+class NegateAgent:
+    """create_agent_negate (FluidSetup.jl:301-322): the stage calls of RL.jl's run loop with a policy that is not trained --
+    POST_EPISODE resets the step counter (:293-299), everything else is a no-op"""
+
+    def __init__(self, policy):
+        self.policy, self.trajectory = policy, None
+
+    def __call__(self, *args):
+        if len(args) == 1:
+            return self.policy(args[0])
+        if args[0] == POST_EPISODE_STAGE:
+            self.policy.update_step = 0
+
+
+def create_agent_negate(*, setup, start_steps=0, start_policy=None):
+    return NegateAgent(NegatePolicy(setup.action_shape, start_steps, start_policy))
+
+
 class CircularArraySARTTrajectory:
     """Device-resident replay with the reference's trace layout (state/action one `stride`
     longer than reward/terminal; Float32, src/PDEagent.jl:112-117).  Unlike RLCore's buffer the

@@ -471,3 +471,30 @@ def test_native_communicator_bring_up_is_a_collective_protocol(tmp_path, scenari
         assert res[0]["destroyed"] == 1 and res[1]["destroyed"] == 0          # rank 0 had one and dropped it
     if scenario == "create_times_out_on_0":
         assert all("did not return within" in r["error"] for r in res) and res[1]["destroyed"] == 1
+
+
+def test_negate_policy_is_the_fluid_scripts_baseline_controller(pkg):
+    """scripts/Fluid/setup/FluidSetup.jl:277-322: result[i] = -env.state[i] over the first length(action) entries of the state in
+    column-major order, clamped to +-1, behind `start_steps` steps of the start policy; POST_EPISODE resets the counter"""
+    torch = pytest.importorskip("torch")
+
+    class Env:
+        pass
+
+    B, A, ns, na = 2, 5, 9, 1
+    env = Env()
+    env.state = torch.arange(B * A * ns, dtype=torch.float64).reshape(B, A, ns) / 7.0 - 3.0
+    env._ashape, env.dtype, env.device = (B, A, na), torch.float64, torch.device("cpu")
+
+    class Setup:
+        action_shape = (na, A)
+
+    agent = pkg.create_agent_negate(setup=Setup(), start_steps=2)
+    assert float(agent(env).abs().max()) == 0.0 and float(agent(env).abs().max()) == 0.0      # the start policy (zeros) twice
+    a = agent(env)
+    for b in range(B):
+        st_julia = env.state[b].numpy().T                          # [ns, A]
+        want = np.clip(-st_julia.reshape(-1, order="F")[:na * A], -1.0, 1.0).reshape((na, A), order="F")
+        assert np.array_equal(a[b].numpy().T, want)
+    agent(pkg.POST_EPISODE_STAGE, env)
+    assert agent.policy.update_step == 0 and float(agent(env).abs().max()) == 0.0
