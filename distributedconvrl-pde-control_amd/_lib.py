@@ -239,7 +239,8 @@ def make_stream(level=0, device=0):
 def make_streams(levels, device=0):
     """make_stream for each level, BACK TO BACK: hardware queues sit on the GPU's four compute pipes in the order they are
     made, and two busy queues on one pipe take turns -- so the (at most four) streams that work at the same time are made in
-    one go: e.g. `s_env, s_upd, *parts = make_streams((-1, 0, 1, 1))` for a pipeline whose environment runs three parts."""
+    one go: e.g. `s_env, s_upd, *parts = make_streams((-1, 0, -1, -1))` for a pipeline whose environment runs three parts (the part
+    streams at the env stream's level: part 0 runs on the env stream itself, and parts of one level advance evenly)."""
     levels = list(levels)
     if len(levels) > 4:
         raise PdecError("make_streams: more than four streams cannot sit on four different compute pipes")
