@@ -185,8 +185,9 @@ class CircularArraySARTTrajectory:
         inds = rng.integers(0, hi, batch_size)
         base = max(0, self.n_rt - self.capacity)          # logical index of the oldest entry
         lg = base + inds
-        return (lg % (self.capacity + self.stride), lg % self.capacity,
-                (lg + self.stride) % (self.capacity + self.stride))
+        ls = lg + self._rlcore_wrap_shift()
+        return (ls % (self.capacity + self.stride), lg % self.capacity,
+                (ls + self.stride) % (self.capacity + self.stride))
 
     def sample_slots_many(self, rng, batch_size, loops):
         """`loops` independent pde_sample draws in one vectorised call -> int array [3, loops, batch_size]
@@ -194,8 +195,23 @@ class CircularArraySARTTrajectory:
         hi = len(self) - self.stride
         inds = rng.integers(0, hi, (loops, batch_size))
         lg = max(0, self.n_rt - self.capacity) + inds
+        ls = lg + self._rlcore_wrap_shift()
         cap1 = self.capacity + self.stride
-        return np.stack([lg % cap1, lg % self.capacity, (lg + self.stride) % cap1])
+        return np.stack([ls % cap1, lg % self.capacity, (ls + self.stride) % cap1])
+
+    def _rlcore_wrap_shift(self):
+        """0 unless `emulate_rlcore_wrap` is set.  RLCore's CircularArraySARTTrajectory keeps capacity + 1 frames of state /
+        action and `capacity` frames of reward / terminal, and pde_sample (src/PDEagent.jl:317-340) uses ONE index for all four
+        traces.  Index i of a buffer that has seen G pushes and holds len = min(G, its capacity) frames is logical row
+        G - len + i, so once the traces have wrapped, (s, a, s') come from rows (G_s - len_s) - (G_r - len_r) later than (r, t):
+        A - 1 rows at the PRE_ACT update (the A state rows of this step are pushed, its rewards are not) -- the state and action
+        of the NEXT control step of the neighbouring actuator.  The product keeps the four traces aligned (shift 0); the
+        host-sampling path can emulate the reference's buffer to study its effect on the learning curve (KS200's buffer wraps
+        at episode 37; its reference curve relapses from episode 39)."""
+        if not getattr(self, "emulate_rlcore_wrap", False):
+            return 0
+        cap = self.capacity
+        return (self.n_sa - min(self.n_sa, cap + 1)) - (self.n_rt - min(self.n_rt, cap))
 
     def sample(self, rng, batch_size):
         """pde_sample / pde_fetch! (src/PDEagent.jl:317-340)"""
@@ -210,7 +226,7 @@ class CustomDDPGPolicy:
     def __init__(self, *, behavior_actor, behavior_critic, target_actor, target_critic, rng, gamma=0.99, rho=0.995,
                  batch_size=3, start_steps=6, start_policy=None, update_after=10, update_freq=1, update_loops=1,
                  reset_stage=POST_EPISODE_STAGE, act_limit=1.0, act_noise=1.2, memory_size=0, number_actuators=1,
-                 quirk_target_broadcast=True, noise_seed=0, reducer=None):
+                 quirk_target_broadcast=True, quirk_frozen_targets=True, noise_seed=0, reducer=None):
         self.behavior_actor, self.behavior_critic = behavior_actor, behavior_critic
         self.target_actor, self.target_critic = target_actor, target_critic
         self.rng = rng
@@ -220,6 +236,15 @@ class CustomDDPGPolicy:
         self.reset_stage, self.act_limit, self.act_noise, self.memory_size = reset_stage, act_limit, act_noise, memory_size
         self.number_actuators = number_actuators
         self.quirk = quirk_target_broadcast               # (1xBu) .+ (Bu) broadcast of r
+        # The reference's Polyak loop (src/PDEagent.jl:415-417) runs over zip(Flux.params([At, Ct]), Flux.params([A, C])), and
+        # both are EMPTY: src/custom_nna.jl:20 defines a `functor` of its own (not Functors.functor), so Flux sees a
+        # CustomNeuralNetworkApproximator inside a Vector as a leaf without parameters.  The loop body never runs and the target
+        # networks stay at their initial values for the whole training -- held by the reference's own artifact: the target actor
+        # and target critic in scripts/KS/KS22/saves/agent.jld2 have exactly-zero biases and glorot-range weights after 130 340
+        # updates (tests/test_replay_golden.py), and only with frozen targets does this path reproduce the reference's learning
+        # curve (tests/test_gpu_training.py).  True (default) = the reference as it runs: the kernels get rho = 1 (dest = 1 * dest
+        # + 0 * src); False = the loop as written (rho = self.p).
+        self.quirk_frozen_targets = bool(quirk_frozen_targets)
         self.update_step = 0
         self.actor_loss = self.critic_loss = 0.0
         self.reducer = reducer                            # data-parallel gradient all-reduce (or None)
@@ -243,6 +268,11 @@ class CustomDDPGPolicy:
         gets it"""
         if self.memory_size:
             _lib.check(self.lib.pdec_mlp_set_noise_rows(model.handle, model.dims[-1] - self.memory_size))
+
+    @property
+    def rho_effective(self):
+        """the Polyak factor the update kernels receive (see quirk_frozen_targets)"""
+        return 1.0 if self.quirk_frozen_targets else float(self.p)
 
     # ---- acting (src/PDEagent.jl:175-209)
     def _actor_for(self, dtype, cols):
@@ -300,22 +330,22 @@ class CustomDDPGPolicy:
             if before_actor_half is None:
                 _lib.check(self.lib.pdec_ddpg_update_async(
                     A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r), _lib.ptr(t),
-                    _lib.ptr(sn), Bu, float(self.y), float(self.p), int(self.quirk), float(oa.eta), float(oc.eta),
+                    _lib.ptr(sn), Bu, float(self.y), self.rho_effective, int(self.quirk), float(oa.eta), float(oc.eta),
                     C.c_void_p(L.data_ptr())))
                 return
             _lib.check(self.lib.pdec_ddpg_update_critic_async(
                 A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r), _lib.ptr(t),
-                _lib.ptr(sn), Bu, float(self.y), float(self.p), int(self.quirk), float(oc.eta), C.c_void_p(L.data_ptr())))
+                _lib.ptr(sn), Bu, float(self.y), self.rho_effective, int(self.quirk), float(oc.eta), C.c_void_p(L.data_ptr())))
             before_actor_half()
             _lib.check(self.lib.pdec_ddpg_update_actor_async(
-                A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), Bu, float(self.p), float(oa.eta),
+                A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), Bu, self.rho_effective, float(oa.eta),
                 C.c_void_p(L.data_ptr())))
             return
         if not self.reducer.reduce_critic:
             # policy-gradient-only exchange: the critic half is the local fused form (no all-reduce)
             _lib.check(self.lib.pdec_ddpg_update_critic_async(
                 A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r), _lib.ptr(t),
-                _lib.ptr(sn), Bu, float(self.y), float(self.p), int(self.quirk), float(oc.eta), C.c_void_p(L.data_ptr())))
+                _lib.ptr(sn), Bu, float(self.y), self.rho_effective, int(self.quirk), float(oc.eta), C.c_void_p(L.data_ptr())))
         else:
             _lib.check(self.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a),
                                                        _lib.ptr(r), _lib.ptr(t), _lib.ptr(sn), Bu, float(self.y),
@@ -323,14 +353,14 @@ class CustomDDPGPolicy:
             self.reducer.all_reduce(Cn)
             # update!(critic) :400 fused with the critic's Polyak step :415-417 (independent of the actor)
             _lib.check(self.lib.pdec_adam_polyak_step(Cn.handle, Ct.handle, float(oc.eta), oc.beta[0], oc.beta[1],
-                                                      oc.epsilon, float(self.p)))
+                                                      oc.epsilon, self.rho_effective))
         if before_actor_half is not None:
             before_actor_half()
         _lib.check(self.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, _lib.ptr(s), Bu, scale,
                                                   C.c_void_p(L.data_ptr() + L.element_size())))
         self.reducer.all_reduce(A)
         _lib.check(self.lib.pdec_adam_polyak_step(A.handle, At.handle, float(oa.eta), oa.beta[0], oa.beta[1],
-                                                  oa.epsilon, float(self.p)))                  # :412, :415-417
+                                                  oa.epsilon, self.rho_effective))                  # :412, :415-417
 
     def small_update_ok(self):
         A, Cn = self.behavior_actor.model, self.behavior_critic.model
@@ -348,7 +378,7 @@ class CustomDDPGPolicy:
         _lib.check(self.lib.pdec_ddpg_update_small(
             A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(tr.state), _lib.ptr(tr.action), _lib.ptr(tr.reward),
             _lib.ptr(tr.terminal), C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()), C.c_void_p(d[2].data_ptr()),
-            int(slots.shape[1]), int(slots.shape[2]), float(self.y), float(self.p), int(self.quirk), float(oa.eta),
+            int(slots.shape[1]), int(slots.shape[2]), float(self.y), self.rho_effective, int(self.quirk), float(oa.eta),
             float(oc.eta), C.c_void_p(L.data_ptr())))
         self._slots_keepalive = d
 
@@ -360,7 +390,7 @@ class CustomDDPGPolicy:
         _lib.check(self.lib.pdec_ddpg_update_small_rng(
             A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(tr.state), _lib.ptr(tr.action), _lib.ptr(tr.reward),
             _lib.ptr(tr.terminal), int(self.update_loops), int(self.batch_size), self._sample_seed, self._sample_off,
-            len(tr), tr.n_rt, tr.capacity, tr.stride, float(self.y), float(self.p), int(self.quirk), float(oa.eta),
+            len(tr), tr.n_rt, tr.capacity, tr.stride, float(self.y), self.rho_effective, int(self.quirk), float(oa.eta),
             float(oc.eta), C.c_void_p(self._losses.data_ptr())))
         self._sample_off += (self.update_loops * self.batch_size + 3) // 4
 
@@ -469,6 +499,7 @@ def create_agent(*, setup, B=1, rng=None, dtype=torch.float32, device="cuda:0", 
         act_limit=g("act_limit"), act_noise=g("act_noise"), memory_size=setup.memory_size,
         number_actuators=cols_per_env, reducer=reducer,
         quirk_target_broadcast=overrides.get("quirk_target_broadcast", True),
+        quirk_frozen_targets=overrides.get("quirk_frozen_targets", True),
         noise_seed=overrides.get("noise_seed", 0))
     trajectory = CircularArraySARTTrajectory(g("trajectory_length") * B, ns, na, stride, torch.device(device))
     trajectory.bind(behavior_critic.model)         # stage kernels on the networks' stream (row F1)

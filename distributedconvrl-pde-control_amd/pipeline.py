@@ -454,7 +454,7 @@ class TrainPipeline:
         """the per-step scalars that a recorded step / a captured graph holds as frozen launch arguments"""
         pol = self.policy
         return (float(pol.act_noise), float(pol.act_limit), float(pol.behavior_actor.optimizer.eta),
-                float(pol.behavior_critic.optimizer.eta), float(pol.y), float(pol.p), int(bool(pol.quirk)),
+                float(pol.behavior_critic.optimizer.eta), float(pol.y), float(pol.rho_effective), int(bool(pol.quirk)),
                 bool(self.kick_env_after_critic), int(self.noise_seed))
 
     def _check_key(self):

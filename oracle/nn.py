@@ -1,7 +1,14 @@
 """Weight-shared ("convolutional") actor/critic MLPs, DDPG update, ADAM, Polyak -- NumPy
-restatement.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED by any
-reference artifact; pinned by finite-difference checks and the committed torch-autograd
-golden (tests/golden/nn_torch_golden.npz, generator tests/golden/make_nn_golden.py).
+restatement.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Single operations are pinned by
+finite-difference checks and the committed torch-autograd golden (tests/golden/nn_torch_golden.npz,
+generator tests/golden/make_nn_golden.py); the update as a whole is pinned by the reference's own
+training artifacts (round 5): the ADAM step count / Float64 beta powers of agent.jld2 bit for bit and the
+learning curves of hook.jld2 in a band over seeds (tests/test_gpu_training.py), which is how the
+frozen-target behaviour below was found.
+
+The reference's Polyak loop (src/PDEagent.jl:415-417) never runs: Flux.params([At, Ct]) is empty because
+src/custom_nna.jl:20 defines a `functor` of its own.  Callers reproduce the reference as it runs by passing
+rho = 1 to ddpg_update / polyak (dest = 1 * dest + 0 * src), the loop as written with rho = 0.995.
 
 Layout follows Flux: W[out, in], b[out]; a batch is a matrix [features, columns] and a Dense
 layer applied to it shares weights across columns (src/PDEagent.jl:14-56)."""

@@ -13,9 +13,11 @@ import sys
 
 import numpy as np
 
+import importlib
+
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, HERE)
-from jld2_reader import JLD2File  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+JLD2File = importlib.import_module("distributedconvrl-pde-control_amd.jld2").JLD2File      # the package's reader (row F3)
 
 REF = os.environ.get("PDEC_REFERENCE", "/root/reference")
 
@@ -66,6 +68,41 @@ def ks(name, rel, nx, Lx, stride, sigma, mu=0.0, extra=None):
     save(name, **kw)
 
 
+def int64_hits(buf, val):
+    pat, pos, hits = np.int64(val).tobytes(), 0, []
+    while True:
+        pos = buf.find(pat, pos)
+        if pos < 0:
+            return hits
+        hits.append(pos)
+        pos += 1
+
+
+def agent_training(name, rel, A, full):
+    fa = JLD2File(os.path.join(REF, rel))
+    bp = np.stack([fa.array(o) for o in fa.numeric(1, 8) if o.dims and tuple(o.dims) == (2,)])
+    kw = dict(adam_beta_pow=bp, n_actuators=A, capacity=150000)
+    big = [fa.array(o).ravel() for o in fa.numeric(1, 4) if o.dims and fa.array(o).size >= 2000]
+    bools = [o for o in fa.objs.values() if o.cls == 4 and o.size == 1 and o.dims and o.data_off]
+    t = np.frombuffer(fa.buf[bools[0].data_off:bools[0].data_off + bools[0].data_size], dtype=np.uint8)
+    ep = 51 * A
+    if full:
+        # filled length: the terminal trace carries one flag per actuator on the 51st step of every episode for exactly
+        # n_rt rows (the rest of the Array{undef} is garbage), and the CircularArrayBuffers' nframes fields hold
+        # n_rt / n_rt + A as Int64
+        n_ep = 0
+        while (np.all(t[n_ep * ep:n_ep * ep + ep - A] == 0) and np.all(t[n_ep * ep + ep - A:(n_ep + 1) * ep] == 1)):
+            n_ep += 1
+        n_rt = n_ep * ep
+        assert len(int64_hits(fa.buf, n_rt)) == 2 and len(int64_hits(fa.buf, n_rt + A)) == 2, "nframes fields not found"
+        s, a, r = big
+        kw.update(n_rt=n_rt, n_sa=n_rt + A, state=s[:n_rt + A].copy(), action=a[:n_rt + A].copy(), reward=r[:n_rt].copy())
+    else:
+        # wrapped buffer (80 actuators x 6528 steps > capacity): only the frame counts
+        kw.update(nframes_rt=len(int64_hits(fa.buf, 150000)), nframes_sa=len(int64_hits(fa.buf, 150001)))
+    save(name, **kw)
+
+
 def main():
     ks("ks22_hook.npz", "scripts/KS/KS22/saves/hook.jld2", 192, 22.0, 24, 0.7)
     ks("ks200_hook.npz", "scripts/KS/KS200/saves/hook.jld2", 240, 200.0, 3, 1.0)
@@ -82,6 +119,8 @@ def main():
               y_t=y[idx], y_t1=y[idx + 1], reward_t1=reward[idx + 1], nx=100, Lx=10.0, dt=0.006)
     kw.update(weights_dict(f32))
     save("kseg_hook.npz", **kw)
+    # round 5: hook.rewards (53 episode returns of the reference's train() run, KellerSegelSetup.jl:390-406) in a file of its own
+    save("kseg_train.npz", episode_rewards=max((r for r in rew if r.ndim == 1 and r.size not in (16, 100)), key=lambda r: r.size))
 
     # Fluid: only actor weights and episode rewards are stored (collect_bestDF=false)
     for k in (8, 16, 32):
@@ -122,6 +161,12 @@ def main():
     kw["adam_eta"] = np.array(etas)
     kw["adam_beta_eps"] = np.array([0.9, 0.999, 1e-8])
     save("ks22_agent.npz", **kw)
+
+    # round 5: what the reference's agents hold about their own TRAINING RUN (train(), KSSetup.jl:304-319 -> run ->
+    # src/PDEagent.jl:342-361): the Float64 beta-power vectors of Flux's ADAM (one per parameter array, beta .^ (t + 1)
+    # after t steps) and, for KS22 whose buffer never wrapped, the filled part of the four replay traces
+    agent_training("ks22_agent_train.npz", "scripts/KS/KS22/saves/agent.jld2", 8, full=True)
+    agent_training("ks200_agent_train.npz", "scripts/KS/KS200/saves/agent.jld2", 80, full=False)
 
 
 if __name__ == "__main__":

@@ -14,8 +14,9 @@ def test_policy_update_matches_oracle_and_losses(pkg):
     from oracle import nn
     setup = pkg.KSSetup.bench_C2(256)
     B = 4
-    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(3))
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(3), quirk_frozen_targets=False)   # Polyak as written
     pol = agent.policy
+    assert pol.rho_effective == 0.995
     rng = np.random.default_rng(4)
     Bu = 256
     batch_np = dict(state=rng.standard_normal((Bu, 3)), action=rng.uniform(-1, 1, (Bu, 1)), reward=-rng.uniform(0, 1, Bu),

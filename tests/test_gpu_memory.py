@@ -223,7 +223,7 @@ def test_ddpg_update_with_memory_shaped_nets_matches_oracle(pkg):
     f32 = np.float32
     nn.ddpg_update(P[0], P[1], P[2], P[3], optA, optC, acts_a, acts_c, batch["state"].T.astype(f32), batch["action"].T.astype(f32),
                    batch["reward"].astype(f32), batch["terminal"].astype(f32), batch["next_state"].T.astype(f32),
-                   f32(pol.y), f32(pol.p), quirk=pol.quirk)
+                   f32(pol.y), f32(pol.rho_effective), quirk=pol.quirk)
     for n, want in zip(nets, P):
         for w, ref in zip(n.model.params(), want):
             assert np.abs(w - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())

@@ -134,3 +134,35 @@ def test_trajectory_glue_rebuilds_the_reference_buffer(pkg):
     assert np.array_equal(tr.reward[:n].numpy(), r[:n]) and np.array_equal(tr.terminal[:n].numpy(), t[:n])
     i_s, i_rt, i_sn = tr.sample_slots(np.random.default_rng(0), 256)
     assert np.array_equal(i_sn, i_s + A) and np.array_equal(i_rt, i_s) and i_s.max() < n - A
+
+
+def test_fixture_beta_powers_are_the_binary64_iterates_at_130340_steps():
+    """scripts/KS/{KS22,KS200}/saves/agent.jld2: Flux's ADAM keeps beta .^ (t + 1) per parameter array as Float64; iterating
+    p <- p * beta in binary64 gives the stored bits at exactly t = 130 340 = 20 x (128 x 51 - 11) steps (the GPU half:
+    tests/test_gpu_training.py)"""
+    for name in ("ks22_agent_train.npz", "ks200_agent_train.npz"):
+        g = load_golden(name)
+        bp = g["adam_beta_pow"]
+        assert bp.shape == (8, 2) and (bp == bp[0]).all()          # actor W1 b1 W2 b2, critic W1 b1 W2 b2: one step count
+        p = np.array([0.9, 0.999])
+        for _ in range(130340):
+            p = p * np.array([0.9, 0.999])
+        assert np.array_equal(p.view(np.uint64), bp[0].view(np.uint64))
+        assert bp[0, 0] == 5 * 2.0 ** -1074
+
+
+def test_reference_target_networks_never_moved():
+    """scripts/KS/KS22/saves/agent.jld2 after 130 340 updates: the TARGET actor and critic (the third and fourth network of
+    CustomDDPGPolicy, src/PDEagent.jl:121-158; arrays f32_24..31 in file order) still have exactly-zero biases and weights inside
+    the glorot-uniform range sqrt(6 / (in + out)) of their initialisation (src/PDEagent.jl:66), while the behaviour networks
+    (f32_00..03, f32_12..15) have left it: the Polyak loop of src/PDEagent.jl:415-417 iterates over Flux.params([At, Ct]), which
+    is empty because src/custom_nna.jl:20 defines a `functor` of its own instead of extending Functors.functor -- the reference's
+    target networks are frozen at their initial values.  (The product mirrors this with quirk_frozen_targets, agent.py.)"""
+    g = load_golden("ks22_agent.npz")
+    arr = lambda i: g[f"f32_{i:02d}"]
+    # behaviour actor / critic: trained
+    assert np.abs(arr(0)).max() > 5 and np.abs(arr(1)).max() > 0.1 and np.abs(arr(13)).max() > 0.1
+    # target actor 1 -> 6 -> 1, target critic 2 -> 140 -> 1: W inside the init range, b == 0 exactly
+    for iW, ib, fan in ((24, 25, 1 + 6), (26, 27, 6 + 1), (28, 29, 2 + 140), (30, 31, 140 + 1)):
+        assert (arr(ib) == 0).all()
+        assert np.abs(arr(iW)).max() <= np.sqrt(6.0 / fan) and np.abs(arr(iW)).max() > 0.9 * np.sqrt(6.0 / fan)
