@@ -254,7 +254,10 @@ int pdec_mlp_grad_buffer(pdec_handle h, void** dptr, int* n);
 int pdec_adam_step(pdec_handle h, double eta, double beta1, double beta2, double eps);
 int pdec_adam_get_state(pdec_handle h, void* m_host, void* v_host, double* beta_pow2);
 int pdec_adam_set_state(pdec_handle h, const void* m_host, const void* v_host, const double* beta_pow2);
-/* dest .= rho .* dest .+ (1-rho) .* src                          (src/PDEagent.jl:415-417) */
+/* dest .= rho .* dest .+ (1-rho) .* src                          (src/PDEagent.jl:415-417)
+ * Every `rho` of this header: the reference's loop runs over Flux.params([At, Ct]), which is empty (src/custom_nna.jl:20 defines a
+ * functor of its own), so its targets never move; a caller reproduces the reference AS IT RUNS with rho = 1 (dest = 1*dest +
+ * 0*src, exact) and the loop as written with rho = policy.p. */
 int pdec_polyak(pdec_handle dst, pdec_handle src, double rho);
 
 /* update!(app, gs) immediately followed by the Polyak step of the app's target network

@@ -233,8 +233,14 @@ end
 # RLBase.update!(policy, batch) -- Zygote cannot differentiate through ccall, so the method at src/PDEagent.jl:363 is
 # overridden with the fused call (same losses, ADAM, Polyak).  `CustomDDPGPolicy` / `CustomNeuralNetworkApproximator`
 # are the reference's own types (src/PDEagent.jl:121, src/custom_nna.jl:7), defined in Main before this file is included.
+# FROZEN_TARGETS: the reference's Polyak loop (src/PDEagent.jl:415-417) iterates over Flux.params([At, Ct]), which is EMPTY --
+# src/custom_nna.jl:20 defines a `functor` of its own instead of extending Functors.functor -- so its target networks never
+# move (scripts/KS/KS22/saves/agent.jld2: zero target biases after 130 340 updates).  true = the reference as it runs (the
+# kernels get rho = 1: dest = 1 * dest + 0 * src); false = the loop as written (rho = policy.p).
+const FROZEN_TARGETS = Ref(true)
 function ddpg_update!(policy, batch)
     s, a, r, t, snext = batch                            # Float32; s [ns,Bu], a [na,Bu], r [1,Bu], t [Bu]
+    rho = FROZEN_TARGETS[] ? 1.0 : Float64(policy.p)
     al = Ref{Cdouble}(0)
     cl = Ref{Cdouble}(0)
     Bu = size(s, 2)
@@ -243,7 +249,7 @@ function ddpg_update!(policy, batch)
                 (UInt64, UInt64, UInt64, UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint,
                  Cdouble, Cdouble, Cint, Cdouble, Cdouble, Ref{Cdouble}, Ref{Cdouble}),
                 policy.behavior_actor.model.h, policy.behavior_critic.model.h, policy.target_actor.model.h,
-                policy.target_critic.model.h, ds, da, dr, dt, dsn, Bu, policy.y, policy.p, 1,
+                policy.target_critic.model.h, ds, da, dr, dt, dsn, Bu, policy.y, rho, 1,
                 policy.behavior_actor.optimizer.eta, policy.behavior_critic.optimizer.eta, al, cl))
     foreach(device_free, (ds, da, dr, dt, dsn))
     policy.actor_loss = al[]

@@ -188,7 +188,7 @@ def test_env_step_at_the_benchmarked_size_matches_oracle(pkg):
     reach is the 16-tile XCD order, the part-stream split of a 128-trajectory batch and all 784 actuators / 2 704 sensors."""
     from oracle import keller_segel2d as k2
     setup = pkg.KellerSegel2DSetup()
-    assert (setup.nx, setup.ny, setup.substeps, setup.n_actuators) == (256, 256, 32, 784)
+    assert (setup.nx, setup.ny, setup.oversampling, setup.n_actuators) == (256, 256, 32, 784)
     cfg = k2.KSeg2DConfig(nx=256, ny=256, Lx=setup.Lx, sensor_x=setup.sensor_x, sensor_y=setup.sensor_y)
     B, dt = 128, torch.float32
     env = pkg.PDEenv(setup, B=B, dtype=dt)
