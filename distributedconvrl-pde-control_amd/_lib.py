@@ -54,7 +54,6 @@ SIGNATURES = {
     "pdec_fluid_ic": [Handle, _pd, _i, _vp],
     "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
     "pdec_debug_critic_stamps": [Handle, _i, _pd],
-    "pdec_debug_split_available": [],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
     "pdec_featurize": [Handle, _vp, _vp, _vp], "pdec_featurize_action": [Handle, _vp, _vp, _vp, _vp], "pdec_mlp_set_noise_rows": [Handle, _i],

@@ -1032,14 +1032,6 @@ int pdec_noise_counter_set(pdec_handle actor, uint64_t value) {
   return PDEC_OK;
 }
 
-int pdec_debug_split_available(void) {
-#ifdef PDEC_EXPERIMENTAL_SPLIT
-  return 1;
-#else
-  return 0;
-#endif
-}
-
 int pdec_debug_critic_stamps(pdec_handle critic, int arm, double* out13) {
   GET_MLP(M, critic);
   if (arm) { M->stamps_armed = true; return PDEC_OK; }

@@ -34,7 +34,6 @@ struct Mlp : Object {
   int kchunk = 512, nsplit_max = 0, dx_index = 0;
   DevBuf fw, fslab;                  // fused-path padded weight image / per-workgroup gradient slabs
   DevBuf stamps;                     // diagnostic phase stamps (PDEC_STAMPS=1)
-  bool split_stale = false;          // bf16-split blocks of `fw` lag the parameters (updated while PDEC_SPLIT was off)
   bool stamps_armed = false;         // pdec_debug_critic_stamps: the next critic pass on this net records its stamps ...
   double stamps_last[13] = {0};      // ... here: 10 phase means, total cycles, shader clock (GHz), workgroups
   DevBuf noise;                      // internal exploration-noise buffer (pdec_policy_act_rng fallback)

@@ -39,25 +39,7 @@ struct FNet {
   int K0, H, HP, LDW;
   int oW1, ob1, ob2, ow3, ob3, oW2, oW2T, total;
   int nsmall, nbig;   // padded block sizes (floats, multiples of 256)
-  int oS2, oS2T;      // bf16-split blocks of W2 / W2^T (HP = 144 only, else -1), see SPLIT below
 };
-// ---- bf16-split operand format of the 144-wide hidden layer (SPLIT forms of the passes: experimental, PDEC_SPLIT, off by
-// default -- see split_on()).  The f32-input MFMA runs at the
-// f32 VECTOR rate; v_mfma_f32_16x16x32_bf16 at 16x that.  W = Whi + Wmid (two bf16 images: 16 mantissa bits of every
-// weight), an activation X = Xhi + Xmid + Xlo (three bf16 splits made in registers: all 24 bits), and
-//     W X ~ Whi Xlo + Wmid Xmid + Wmid Xhi + Whi Xmid + Whi Xhi          (f32 accumulation)
-// five MFMAs of 16 cycles where the f32 form needs eight of 32 cycles; the dropped terms are below 2^-17 relative.
-// Block layout (bf16 elements): [split hi | mid][row 0..HP-1][SPL_RS]; the 8 consecutive elements at
-// row * SPL_RS + 32 t + 8 q + j (j = 0..7) hold W[row][k = 16 (2t + (j >> 2)) + 4 q + (j & 3)] -- the order in which the
-// two accumulator tiles 2t, 2t+1 of the activation sit in lane group q -- so one ds_read_b128 is a whole A fragment, and the
-// row stride of 352 B keeps those reads bank-conflict free.  Rows / k beyond H hold zero.
-#define SPL_KB 5               // 32-deep k blocks (160 >= 144)
-#define SPL_RS 176             // row stride in bf16 elements (352 B)
-#define SPL_HP 144
-__host__ __device__ constexpr int split_floats() { return 2 * SPL_HP * SPL_RS / 2; }       // 25 344 floats = 99 KiB
-__host__ __device__ constexpr int split_elem(int row, int k) {                               // bf16 index inside one split image
-  return row * SPL_RS + (k >> 5) * 32 + ((k & 15) >> 2) * 8 + ((k & 31) >> 4) * 4 + (k & 3);
-}
 __host__ __device__ constexpr int pad256(int n) { return (n + 255) / 256 * 256; }
 __host__ __device__ constexpr int small_floats(int HP) { return pad256(HP * LDW1 + 3 * HP + 4); }
 __host__ __device__ constexpr int big_floats(int HP) { return pad256(HP * (HP + LDWPAD)); }
@@ -76,15 +58,6 @@ static FNet make_fnet_layout(int K0, int H) {
   f.oW2 = f.nsmall;
   f.oW2T = f.oW2 + f.nbig;
   f.total = f.oW2T + f.nbig;
-  f.oS2 = f.oS2T = -1;
-#ifdef PDEC_EXPERIMENTAL_SPLIT      // the bf16-split image blocks exist in the experimental build only (see split_on())
-  if (f.HP == SPL_HP) {
-    static_assert(split_floats() % 256 == 0, "split blocks are copied in whole 1-KiB pieces");
-    f.oS2 = f.total;
-    f.oS2T = f.oS2 + split_floats();
-    f.total = f.oS2T + split_floats();
-  }
-#endif
   return f;
 }
 
@@ -101,22 +74,7 @@ __global__ void prep_fused_kernel(const float* __restrict__ p, float* __restrict
   else if (i < f.ob3) { const int r = i - f.ow3; if (r < H) v = p[pW3 + r]; }
   else if (i < f.oW2) { if (i == f.ob3) v = p[pb3]; }
   else if (i < f.oW2T) { const int r = (i - f.oW2) / f.LDW, c = (i - f.oW2) % f.LDW; if (r < H && c < H) v = p[pW2 + r * H + c]; }
-  else if (f.oS2 < 0 || i < f.oS2) { const int r = (i - f.oW2T) / f.LDW, c = (i - f.oW2T) % f.LDW; if (r < H && c < H) v = p[pW2 + c * H + r]; }
-  else {          // one float slot of a split block = two bf16 elements e, e + 1 of image (split s, transposed or not)
-    const bool tr = i >= f.oS2T;
-    const int e0 = 2 * (i - (tr ? f.oS2T : f.oS2)), sp = e0 / (SPL_HP * SPL_RS), e = e0 - sp * SPL_HP * SPL_RS;
-    const int row = e / SPL_RS, c0 = e - row * SPL_RS;
-    unsigned bits = 0;
-    for (int u = 0; u < 2; ++u) {
-      const int c = c0 + u, t = c >> 5, q = (c & 31) >> 3, j = c & 7, k = 16 * (2 * t + (j >> 2)) + 4 * q + (j & 3);
-      float wv = 0.f;
-      if (c < SPL_KB * 32 && row < H && k < H) wv = tr ? p[pW2 + k * H + row] : p[pW2 + row * H + k];
-      const __bf16 hi = (__bf16)wv;
-      const __bf16 val = sp == 0 ? hi : (__bf16)(wv - (float)hi);
-      bits |= (unsigned)__builtin_bit_cast(unsigned short, val) << (16 * u);
-    }
-    v = __builtin_bit_cast(float, bits);
-  }
+  else { const int r = (i - f.oW2T) / f.LDW, c = (i - f.oW2T) % f.LDW; if (r < H && c < H) v = p[pW2 + c * H + r]; }
   out[i] = v;
 }
 
@@ -131,9 +89,9 @@ __device__ __forceinline__ SmallLds carve_small(float* base, int HP) {
   return s;
 }
 // floats of the big region: the padded W2 image (in whole DMA pieces), or the staging images that later overlay it
-__host__ __device__ constexpr int wreg_floats(int MT, int MTA, bool split = false) {
+__host__ __device__ constexpr int wreg_floats(int MT, int MTA) {
   const int HP = 16 * MT, HPa = 16 * MTA;
-  int a = split ? split_floats() : big_floats(HP), b = 2 * HP * LDP, c = (32 + 4 * HPa) * 136;      // c: the actor's staging images, LDPA = 136
+  int a = big_floats(HP), b = 2 * HP * LDP, c = (32 + 4 * HPa) * 136;      // c: the actor's staging images, LDPA = 136
   int m = a > b ? a : b;
   return m > c ? m : c;
 }
@@ -249,79 +207,6 @@ __device__ __forceinline__ void layer_hh(f32x4 (&out)[MTO], const f32x4 (&in)[MT
   layer_hh_part<MTO, MTI, BIAS, 0, MTO>(out, in, W, ldw, bias, lr, q);
 }
 
-// ---- bf16-split hidden layer (see SPLIT at the image layout)
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // two f32 -> packed bf16 (round to nearest even), a in the low half
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
-}
-struct SplitB {                      // the three bf16 splits of an activation, one B fragment per 32-deep k block
-  s16x8 hi[SPL_KB], mid[SPL_KB], lo[SPL_KB];
-};
-// accumulator-layout tiles (MT of them, rows beyond 16 MT are zero) -> split B fragments: k block t = tiles 2t, 2t+1
-template <int MT>
-__device__ __forceinline__ void split_tiles(SplitB& b, const f32x4 (&x)[MT]) {
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-  for (int t = 0; t < SPL_KB; ++t) {
-    unsigned h[4], m[4], lw[4];
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-      const int tile = 2 * t + (pr >> 1), r0 = 2 * (pr & 1);
-      const float a = tile < MT ? x[tile < MT ? tile : 0][r0] : 0.f, c = tile < MT ? x[tile < MT ? tile : 0][r0 + 1] : 0.f;
-      h[pr] = pk_bf16(a, c);
-      const float ra = a - __builtin_bit_cast(float, h[pr] << 16), rc = c - __builtin_bit_cast(float, h[pr] & 0xffff0000u);
-      m[pr] = pk_bf16(ra, rc);
-      const float sa = ra - __builtin_bit_cast(float, m[pr] << 16), sc = rc - __builtin_bit_cast(float, m[pr] & 0xffff0000u);
-      lw[pr] = pk_bf16(sa, sc);
-    }
-    b.hi[t] = __builtin_bit_cast(s16x8, u4{h[0], h[1], h[2], h[3]});
-    b.mid[t] = __builtin_bit_cast(s16x8, u4{m[0], m[1], m[2], m[3]});
-    b.lo[t] = __builtin_bit_cast(s16x8, u4{lw[0], lw[1], lw[2], lw[3]});
-    __builtin_amdgcn_sched_barrier(0);     // one k block at a time: the pass is at its register budget here
-  }
-}
-__device__ __forceinline__ f32x4 mfma_bf(s16x8 a, s16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// out = W in (+ bias) for the 144-wide layer from the split image `img` ([hi | mid][row][SPL_RS] bf16 in LDS); the A
-// fragments of a k block are read one block ahead of the five MFMAs that use them; smallest products first
-template <int MT, bool BIAS>
-__device__ __forceinline__ void layer_split(f32x4 (&out)[MT], const SplitB& b, const float* img, const float* bias, int lr, int q) {
-  const __bf16* ahi = reinterpret_cast<const __bf16*>(img) + lr * SPL_RS + q * 8;
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int mo = 0; mo < MT; ++mo) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (BIAS) {
-      const float* bb = bias + 16 * mo + 4 * q;
-      acc = f32x4{bb[0], bb[1], bb[2], bb[3]};
-    }
-    const __bf16* a0 = ahi + 16 * mo * SPL_RS;
-    s16x8 ah = *reinterpret_cast<const s16x8*>(a0), am = *reinterpret_cast<const s16x8*>(a0 + SPL_HP * SPL_RS);
-#pragma unroll
-    for (int t = 0; t < SPL_KB; ++t) {
-      s16x8 ahn = ah, amn = am;
-      if (t + 1 < SPL_KB) {
-        ahn = *reinterpret_cast<const s16x8*>(a0 + 32 * (t + 1));
-        amn = *reinterpret_cast<const s16x8*>(a0 + SPL_HP * SPL_RS + 32 * (t + 1));
-      }
-      acc = mfma_bf(ah, b.lo[t], acc);
-      acc = mfma_bf(am, b.mid[t], acc);
-      acc = mfma_bf(am, b.hi[t], acc);
-      acc = mfma_bf(ah, b.mid[t], acc);
-      acc = mfma_bf(ah, b.hi[t], acc);
-      ah = ahn; am = amn;
-    }
-    out[mo] = acc;
-    // keep the scheduler from lifting the operand reads of later tiles over this one (the whole activation set and the
-    // 60 registers of B fragments are live here)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 struct FusedArgs {
   FNet A, C, At, Ct;          // A/At unused fields are ignored by the actor pass
   const float *s, *a, *r, *t, *sn;
@@ -371,20 +256,14 @@ __device__ __forceinline__ float block_sum_lds(float v, float* red, int tid) {
 // (dma_even) -- round 2 loaded the small blocks through registers, 3.5 k cycles per load_small with nothing to overlap --
 // and the behaviour critic's small block is copied during the target phase into its own region, so the phase switch is one
 // barrier + the issue of the next big copy.  Copies are waited for in issue order with literal vmcnt counts.
-// SPLIT (HP = 144): the two FORWARD 144 x 144 products (target critic, behaviour critic) run on bf16-split operands
-// (layer_split, see the image layout); W2^T dz2 and the weight-gradient products stay exact f32.  (The form with W2^T dz2 split
-// as well was built, measured -- 61 -> 47 us alone -- and taken out: HISTORY.md §3.2a.  This form keeps the tail of the pass,
-// dz1 onwards, instruction for instruction what the exact-f32 pass runs.)  224 VGPRs: see the actor pass.
-template <int MT, int MTA, bool SPLIT = false>
+template <int MT, int MTA>
 __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) void ddpg_critic_fused_kernel(FusedArgs g) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
   constexpr int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD, NW = FTHREADS / 64;
-  static_assert(!SPLIT || HP == SPL_HP, "the split form is built for the 144-wide layer");
   constexpr int NS = small_floats(HP), NSa = small_floats(HPa), NB = big_floats(HP), NBa = big_floats(HPa);
-  constexpr int NBF = SPLIT ? split_floats() : NB;      // size of a forward image ([hi | mid] pair or padded f32)
   float* Wreg = smem;                                   // [HP][LDW] big weight image / staging images
-  float* sc = Wreg + wreg_floats(MT, MTA, SPLIT);       // target critic's small block
+  float* sc = Wreg + wreg_floats(MT, MTA);              // target critic's small block
   float* sc2 = sc + NS;                                 // behaviour critic's small block
   float* sa = sc2 + NS;                                 // target actor's small block
   float* saW2 = sa + NSa;                               // target actor's W2 [HPa][LDWa]
@@ -444,7 +323,7 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]), "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(xq[3]),
                "+v"(rv), "+v"(tv), "+v"(rsum), "+v"(rbar_in));
   dma_wait();                                             // (the small copies; nothing else is outstanding)
-  dma_even<NBF, NW>(Wreg, g.Ct.w + (SPLIT ? g.Ct.oS2 : g.Ct.oW2), w, l);
+  dma_even<NB, NW>(Wreg, g.Ct.w + g.Ct.oW2, w, l);
   dma_even<NS, NW>(sc2, g.C.w, w, l);
   constexpr int N_SC = dma_count<NS, NW>();
   float rbar = block_sum_lds(rsum, red, tid) / (float)g.Bu;   // raw barriers inside (small blocks visible afterwards)
@@ -466,17 +345,9 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
       if (4 * t + q == ns) x[t] = valid ? an : 0.f;
     f32x4 h1[MT], h2[MT];
     layer_in<MT, 4>(h1, x, SCt, lr, q);
-    if constexpr (SPLIT) {
-      SplitB sb;
-      split_tiles<MT>(sb, h1);
-      dma_wait_but<N_SC>();                               // the target critic's W2 has landed
-      lds_barrier();
-      layer_split<MT, true>(h2, sb, Wreg, SCt.b2, lr, q);
-    } else {
-      dma_wait_but<N_SC>();                               // the target critic's W2 has landed
-      lds_barrier();
-      layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SCt.b2, lr, q);
-    }
+    dma_wait_but<N_SC>();                                 // the target critic's W2 has landed
+    lds_barrier();
+    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SCt.b2, lr, q);
     relu_<MT>(h2);
     const float qt = head<MT>(h2, SCt.w3, SCt.b3[0], q);
     tgt = g.gamma * (1.f - tv) * qt;
@@ -485,23 +356,15 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   lds_barrier();                                        // every wave is done with Wreg; sc2 visible
   STAMP(2);
   // ---- phase Q: behaviour critic forward; its W2 lands behind layer 1
-  dma_even<NBF, NW>(Wreg, g.C.w + (SPLIT ? g.C.oS2 : g.C.oW2), w, l);
+  dma_even<NB, NW>(Wreg, g.C.w + g.C.oW2, w, l);
   STAMP(3);
 #pragma unroll
   for (int t = 0; t < 4; ++t) x[t] = xq[t];
   f32x4 h1[MT], h2[MT];
   layer_in<MT, 4>(h1, x, SC, lr, q);
-  if constexpr (SPLIT) {
-    SplitB sb;
-    split_tiles<MT>(sb, h1);
-    dma_wait();
-    lds_barrier();
-    layer_split<MT, true>(h2, sb, Wreg, SC.b2, lr, q);
-  } else {
-    dma_wait();
-    lds_barrier();
-    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
-  }
+  dma_wait();
+  lds_barrier();
+  layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
   relu_<MT>(h2);
   const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
   const float c = valid ? tgt - qv : 0.f;
@@ -576,7 +439,7 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   STAMP(7);
   {
     constexpr int LDP128 = 136;                 // 8 mod 16 floats, like LDP: conflict-free ds_read_b128 operand reads
-    static_assert(16 * MT * LDP128 + 16 * LDP128 <= wreg_floats(MT, MTA, SPLIT), "pass C images do not fit the big LDS region");
+    static_assert(16 * MT * LDP128 + 16 * LDP128 <= wreg_floats(MT, MTA), "pass C images do not fit the big LDS region");
     float* Lc = Wreg;
     float* Rc = Wreg + HP * LDP128;
     const int cw128 = w * 16 + lr;
@@ -624,18 +487,16 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
 // W2^T where the forward had W2: its first 32 rows (two output tiles) are copied into X during the forward, the rest into
 // the big region at the switch, behind those two tiles -- round 2 waited for the whole 87.5 KB copy with nothing to do.
 #define AX_ROWS 32
-// SPLIT: bf16-split operands for the two 144 x 144 products (no X region then: the [hi | mid] images of W2^T are not
-// row-contiguous and the LDS left beside a co-resident PDE-step workgroup does not hold a second region of them)
-template <int MT, int MTA, bool SPLIT = false>
+template <int MT, int MTA>
 __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) void ddpg_actor_fused_kernel(FusedArgs g) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, q = l >> 4;
   constexpr int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD, LDWa = HPa + LDWPAD, NW = FTHREADS / 64;
-  constexpr int NS = small_floats(HP), NSa = small_floats(HPa), NB = SPLIT ? split_floats() : big_floats(HP), NBa = big_floats(HPa);
-  constexpr bool TWO = !SPLIT && HP > AX_ROWS && (AX_ROWS * LDW) % 256 == 0;     // W2^T in two parts (X + big region)
+  constexpr int NS = small_floats(HP), NSa = small_floats(HPa), NB = big_floats(HP), NBa = big_floats(HPa);
+  constexpr bool TWO = HP > AX_ROWS && (AX_ROWS * LDW) % 256 == 0;     // W2^T in two parts (X + big region)
   constexpr int NX = TWO ? AX_ROWS * LDW : 256;
   float* Wreg = smem;
-  float* sc = Wreg + wreg_floats(MT, MTA, SPLIT);
+  float* sc = Wreg + wreg_floats(MT, MTA);
   float* sa = sc + NS;
   float* saW2 = sa + NSa;
   float* saW2T = saW2 + NBa;
@@ -660,7 +521,7 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   }
   asm volatile("" : "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]), "+v"(xs[3]));
   dma_wait();
-  dma_even<NB, NW>(Wreg, g.C.w + (SPLIT ? g.C.oS2 : g.C.oW2), w, l);      // lands behind the actor forward and the critic's first layer
+  dma_even<NB, NW>(Wreg, g.C.w + g.C.oW2, w, l);      // lands behind the actor forward and the critic's first layer
   lds_barrier();
   f32x4 ha1[MTA], ha2[MTA];
   layer_in<MTA, 4>(ha1, xs, SA, lr, q);
@@ -677,18 +538,10 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) relu1 |= (unsigned long long)(h1[m][r] > 0.f) << (4 * m + r);
-  if constexpr (SPLIT) {
-    SplitB sb;
-    split_tiles<MT>(sb, h1);
-    dma_wait();
-    lds_barrier();
-    layer_split<MT, true>(h2, sb, Wreg, SC.b2, lr, q);
-  } else {
-    dma_wait();
-    lds_barrier();
-    if constexpr (TWO) dma_even<NX, NW>(X, g.C.w + g.C.oW2T, w, l);      // rows 0 .. 31 of W2^T, behind the forward
-    layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
-  }
+  dma_wait();
+  lds_barrier();
+  if constexpr (TWO) dma_even<NX, NW>(X, g.C.w + g.C.oW2T, w, l);      // rows 0 .. 31 of W2^T, behind the forward
+  layer_hh<MT, MT, true>(h2, h1, Wreg, LDW, SC.b2, lr, q);
   relu_<MT>(h2);
   const float qv = head<MT>(h2, SC.w3, SC.b3[0], q);
   float st0 = (valid && q == 0) ? qv : 0.f;
@@ -696,15 +549,7 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   f32x4 dz2[MT];
   head_bwd<MT>(dz2, h2, SC.w3, dq, q);
   f32x4 dz1[MT];
-  if constexpr (SPLIT) {
-    SplitB sb;
-    split_tiles<MT>(sb, dz2);
-    lds_barrier();                                       // every wave is done with the forward images
-    dma_even<NB, NW>(Wreg, g.C.w + g.C.oS2T, w, l);
-    dma_wait();
-    lds_barrier();
-    layer_split<MT, false>(dz1, sb, Wreg, nullptr, lr, q);
-  } else if constexpr (TWO) {
+  if constexpr (TWO) {
     dma_wait();
     lds_barrier();                                       // X visible; every wave is done with the big region
     dma_even<NB - NX, NW>(Wreg + NX, g.C.w + g.C.oW2T + NX, w, l);       // rows 32 .. of W2^T behind the first two tiles
@@ -745,7 +590,7 @@ __global__ __launch_bounds__(FTHREADS) __attribute__((amdgpu_num_vgpr(112))) voi
   // Columns are contracted in the same order as before, so the sums are bit-identical.
   const int nslab = gridDim.x;
   constexpr int LDPA = 136;               // 8 mod 16 floats: conflict-free ds_read_b128 operand reads
-  static_assert((32 + 4 * HPa) * LDPA <= wreg_floats(MT, MTA, SPLIT), "the actor's staging images do not fit the big LDS region");
+  static_assert((32 + 4 * HPa) * LDPA <= wreg_floats(MT, MTA), "the actor's staging images do not fit the big LDS region");
   static_assert(2 * MTA + MTA * MTA <= FTHREADS / 64, "one output tile per wave");
   float* I0 = Wreg;                       // DZ3 [16][LDPA]
   float* I1 = I0 + 16 * LDPA;             // HA2aug [HPa][LDPA]
@@ -846,31 +691,11 @@ __device__ __forceinline__ void finish_param(const FinishArgs& g, int i, float g
   else o1 = g.lay.ob3;
   if (g.fw) { g.fw[o1] = pn; if (o2 >= 0) g.fw[o2] = pn; }
   if (g.fwp) { g.fwp[o1] = pn; if (o2 >= 0) g.fwp[o2] = pn; }
-  // bf16-split copies of a W2 element (144-wide nets): W2 and W2^T of the updated net (the actor pass reads the behaviour
-  // critic's; targets and published copies have none)
-  const bool spl = o2 >= 0 && g.lay.oS2 >= 0;
-  int e1 = 0, e2 = 0;
-  if (spl) {
-    const int r = j / H, c = j - r * H;       // j = r * H + c inside W2 here
-    e1 = split_elem(r, c); e2 = split_elem(c, r);
-    if (g.fw) {
-      const __bf16 hi = (__bf16)pn, mid = (__bf16)(pn - (float)hi);
-      __bf16* b2 = reinterpret_cast<__bf16*>(g.fw + g.lay.oS2);
-      __bf16* b2t = reinterpret_cast<__bf16*>(g.fw + g.lay.oS2T);
-      b2[e1] = hi; b2[SPL_HP * SPL_RS + e1] = mid;
-      b2t[e2] = hi; b2t[SPL_HP * SPL_RS + e2] = mid;
-    }
-  }
   if (g.pt) {
     const float tn = g.rho * pt0 + g.omr * pn;
     g.pt[i] = tn;
     if (g.fwt) {
       g.fwt[o1] = tn; if (o2 >= 0) g.fwt[o2] = tn;
-      if (spl) {                                 // the target critic's forward image (critic pass, split form)
-        const __bf16 hi = (__bf16)tn, mid = (__bf16)(tn - (float)hi);
-        __bf16* b2 = reinterpret_cast<__bf16*>(g.fwt + g.lay.oS2);
-        b2[e1] = hi; b2[SPL_HP * SPL_RS + e1] = mid;
-      }
     }
   }
 }
@@ -1166,12 +991,8 @@ bool fused_supported(const Mlp* A, const Mlp* C) {
   return (mt == 9 || mt == 2) && (mta == 2 || mta == 1);
 }
 
-static bool split_on(int which);
 static int ensure_prepped(Mlp* M) {
   const FNet f = make_fnet_layout(M->dims[0], M->dims[1]);
-  // the bf16-split blocks are refreshed by the finish kernel only while a split form is selected (PDEC_SPLIT); a net that was
-  // updated without them gets its whole image rebuilt from the parameters before the first split pass reads it
-  if (M->split_stale && (split_on(1) || split_on(2))) M->fw_dirty = true;
   const size_t bytes = (size_t)f.total * 4;
   if (M->fw.bytes < bytes) {
     PDEC_HIP(M->fw.alloc(bytes));
@@ -1188,7 +1009,6 @@ static int ensure_prepped(Mlp* M) {
     PDEC_HIP(hipMemcpyAsync(M->fw_pub[0].p, M->fw.p, bytes, hipMemcpyDeviceToDevice, M->stream));
     PDEC_HIP(hipMemcpyAsync(M->fw_pub[1].p, M->fw.p, bytes, hipMemcpyDeviceToDevice, M->stream));
     M->fw_dirty = false;
-    M->split_stale = false;
   }
   return PDEC_OK;
 }
@@ -1200,12 +1020,12 @@ static FNet fnet_of(const Mlp* M) {
 }
 
 template <int MT, int MTA>
-static size_t lds_bytes(bool actor_pass, bool split = false) {
+static size_t lds_bytes(bool actor_pass) {
   const int HP = 16 * MT, HPa = 16 * MTA, LDW = HP + LDWPAD;
-  size_t f = (size_t)wreg_floats(MT, MTA, split) + small_floats(HPa) + 8;
+  size_t f = (size_t)wreg_floats(MT, MTA) + small_floats(HPa) + 8;
   if (actor_pass) {   // sc | sa | saW2 | saW2T | red [8] | X (the first rows of W2^T, see the kernel)
     f += small_floats(HP) + 2 * (size_t)big_floats(HPa);
-    if (!split && HP > AX_ROWS && (AX_ROWS * LDW) % 256 == 0) f += (size_t)AX_ROWS * LDW;
+    if (HP > AX_ROWS && (AX_ROWS * LDW) % 256 == 0) f += (size_t)AX_ROWS * LDW;
   } else {            // sc | sc2 | sa | saW2 | red [8] + [8][HP] pass A + [8][8] loss statistics
     f += 2 * (size_t)small_floats(HP) + big_floats(HPa) + 8 * HP + 64;
   }
@@ -1242,51 +1062,22 @@ static int dump_stamps(Mlp* C, unsigned long long* dev, int grid) {
   return PDEC_OK;
 }
 
-// bf16-split operands for the 144-wide layers (see SPLIT at the image layout): an EXPERIMENT, off by default.
-// PDEC_SPLIT: 0 = exact f32 everywhere (default), a = actor pass, c = the two forward products of the critic pass, 1 = both.
-// Alone the split passes are bit-stable and faster (actor 31 -> 22 us, critic 60 -> 51 us).  In the two-stream training
-// pipeline, though, runs with a split pass beside the PDE step were NOT bit-reproducible: in a few per cent of 30-step runs
-// the step's fields -- in some collections also the gradients -- differed between two runs that differ only in timing (never
-// with the exact-f32 passes, never with the streams on disjoint CU masks, never with the same products issued as two
-// v_mfma_f32_16x16x16_bf16 -- tools/det_probe5.py, HISTORY.md round 3).  This is an UNRESOLVED NONDETERMINISM, not an
-// established hardware fault: a timing-dependent race inside the split passes themselves (register overlay of the weight
-// image, literal vmcnt waits) has not been excluded; the product's exact-f32 passes share dma_even / lds_barrier / the literal
-// waits and are checked against timing -- free-running, drained, the round-2 finish kernel and the STAMPED form of the critic
-// pass -- bit for bit (tests/test_gpu_pipeline.py::test_results_do_not_depend_on_stream_timing).  TrainPipeline refuses the
-// split forms unless it runs serially.  which: 1 critic pass, 2 actor pass.
-// The PRODUCT library does not contain these kernels (round-2 verdict, item 3: "otherwise record the number and delete the
-// kernel"): they are compiled only with -DPDEC_EXPERIMENTAL_SPLIT (`make EXPERIMENTAL_SPLIT=1 OUT=...`), which is how the
-// measurements and the reproducer of HISTORY.md §3.2a were built; the product refuses PDEC_SPLIT != 0 with an error.
-#define PDEC_SPLIT_DEFAULT '0'
-static char split_request() {
-  const char* e = getenv("PDEC_SPLIT");
-  return (e && e[0]) ? e[0] : PDEC_SPLIT_DEFAULT;
-}
-static bool split_on(int which) {
-#ifdef PDEC_EXPERIMENTAL_SPLIT
-  const char c = split_request();
-  return c == '1' || (which == 1 && c == 'c') || (which == 2 && c == 'a');
-#else
-  (void)which;
-  return false;
-#endif
-}
-// product build: a request for a split form is an error, not a silent exact-f32 run
+// (Round 5: the bf16-split forms of the passes -- an experiment of rounds 2 - 4 whose results beside the PDE step were not
+// bit-reproducible and whose cause was never found -- are deleted; HISTORY.md §3.2a keeps the record and the numbers.  A process
+// that still sets PDEC_SPLIT gets an error, not a silent exact-f32 run.)
 static int split_refused() {
-#ifndef PDEC_EXPERIMENTAL_SPLIT
-  const char c = split_request();
-  if (c != '0') {
-    set_error("PDEC_SPLIT=%c: this libpdeconv.so was built without the experimental bf16-split passes (HISTORY.md §3.2a; "
-              "make -C csrc EXPERIMENTAL_SPLIT=1 OUT=<other file> builds them)", c);
+  const char* e = getenv("PDEC_SPLIT");
+  if (e && e[0] && e[0] != '0') {
+    set_error("PDEC_SPLIT=%s: the experimental bf16-split passes no longer exist (HISTORY.md §3.2a); the passes are exact f32", e);
     return PDEC_E_INVALID;
   }
-#endif
   return PDEC_OK;
 }
-template <int MT, int MTA, bool SPLIT>
-static int launch_critic_v(Mlp* C, const FusedArgs& g, int grid) {
-  const size_t lds = lds_bytes<MT, MTA>(false, SPLIT);
-  auto kern = ddpg_critic_fused_kernel<MT, MTA, SPLIT>;
+template <int MT, int MTA>
+static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
+  if (int rc = split_refused()) return rc;
+  const size_t lds = lds_bytes<MT, MTA>(false);
+  auto kern = ddpg_critic_fused_kernel<MT, MTA>;
   static bool attr_set = false;
   if (!attr_set) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1315,19 +1106,10 @@ static int launch_critic_v(Mlp* C, const FusedArgs& g, int grid) {
   return PDEC_OK;
 }
 template <int MT, int MTA>
-static int launch_critic(Mlp* C, const FusedArgs& g, int grid) {
+static int launch_actor(Mlp* C, const FusedArgs& g, int grid) {
   if (int rc = split_refused()) return rc;
-#ifdef PDEC_EXPERIMENTAL_SPLIT
-  if constexpr (16 * MT == SPL_HP) {
-    if (split_on(1)) return launch_critic_v<MT, MTA, true>(C, g, grid);
-  }
-#endif
-  return launch_critic_v<MT, MTA, false>(C, g, grid);
-}
-template <int MT, int MTA, bool SPLIT>
-static int launch_actor_v(Mlp* C, const FusedArgs& g, int grid) {
-  const size_t lds = lds_bytes<MT, MTA>(true, SPLIT);
-  auto kern = ddpg_actor_fused_kernel<MT, MTA, SPLIT>;
+  const size_t lds = lds_bytes<MT, MTA>(true);
+  auto kern = ddpg_actor_fused_kernel<MT, MTA>;
   static bool attr_set = false;
   if (!attr_set) {
     PDEC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1342,17 +1124,6 @@ static int launch_actor_v(Mlp* C, const FusedArgs& g, int grid) {
   }
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
-}
-
-template <int MT, int MTA>
-static int launch_actor(Mlp* C, const FusedArgs& g, int grid) {
-  if (int rc = split_refused()) return rc;
-#ifdef PDEC_EXPERIMENTAL_SPLIT
-  if constexpr (16 * MT == SPL_HP) {
-    if (split_on(2)) return launch_actor_v<MT, MTA, true>(C, g, grid);
-  }
-#endif
-  return launch_actor_v<MT, MTA, false>(C, g, grid);
 }
 
 static int ensure_slab(Mlp* M, size_t floats) {
@@ -1377,11 +1148,6 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
     g.fw = M->fw.as<float>();
     g.fwp = M->fw_pub[M->pub ^ 1].as<float>();       // written now, read by acting kernels enqueued after this launch
     g.lay = make_fnet_layout(M->dims[0], M->dims[1]);
-    if (g.lay.oS2 >= 0 && !(split_on(1) || split_on(2))) {     // exact-f32 passes (default): no bf16-split copies to keep current
-      g.lay.oS2 = g.lay.oS2T = -1;
-      M->split_stale = true;
-      if (Mt) Mt->split_stale = true;
-    }
     g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps;
     if (Mt) {
       g.pt = Mt->params.as<float>(); g.fwt = Mt->fw.as<float>();

@@ -170,13 +170,6 @@ class TrainPipeline:
             eff = C.c_int()
             _lib.check(self.lib.pdec_env_set_simd_sharing(env.handle, 1, C.byref(eff)))
             self.simd_sharing = bool(eff.value)
-        # the experimental bf16-split forms of the fused passes (PDEC_SPLIT=a|c|1, csrc/mlp_mfma.hip) are bit-stable alone but
-        # NOT beside the PDE step: a few per cent of 30-step runs differed from a run with other timing (an unresolved
-        # nondeterminism, not root-caused: tools/det_probe5.py; HISTORY.md round 3).  Two streams refuse them.
-        if not self.serial and os.environ.get("PDEC_SPLIT", "0")[:1] not in ("", "0") and os.environ.get("PDEC_SPLIT_UNSAFE") != "1":
-            raise _lib.PdecError("PDEC_SPLIT=%s: the bf16-split passes are not bit-stable beside the PDE step of a two-stream "
-                                 "pipeline; run the pipeline on one stream, or unset PDEC_SPLIT (PDEC_SPLIT_UNSAFE=1 overrides "
-                                 "for measurements)" % os.environ["PDEC_SPLIT"])
         self._sp_env, self._sp_upd = C.c_void_p(self.s_env.cuda_stream), C.c_void_p(self.s_upd.cuda_stream)
         self.graphs = {}          # (chunk, pos) -> graph handle
         self._progs = {}          # ring phase -> recorded library calls of an interior eager step

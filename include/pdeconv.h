@@ -225,10 +225,6 @@ int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, int nlines, 
  * workgroup, their sum, the shader clock in GHz (d s_memtime / d s_memrealtime x 100 MHz) and the workgroup count.
  * Synchronises the stream of the pass. */
 int pdec_debug_critic_stamps(pdec_handle critic, int arm, double* out13);
-/* 1 when this library was built with the experimental bf16-split forms of the fused passes (-DPDEC_EXPERIMENTAL_SPLIT:
- * PDEC_SPLIT=a|c|1 then selects them), 0 in the product build (PDEC_SPLIT != 0 is then refused by the passes).  Not a status
- * code.  The reference has no counterpart (its update is src/PDEagent.jl:363-418 in Float32 throughout). */
-int pdec_debug_split_available(void);
 
 /* ---------------------------------------------------------------- networks ----------- */
 /* Chain(Dense...) with weights shared across columns (src/PDEagent.jl:14-56).

@@ -296,19 +296,11 @@ def test_small_update_all_loops_in_one_launch(pkg, quirk, ns, na, sa, sc, drop, 
     assert abs(bp[0] - 0.9 ** (loops + 1)) <= 1e-12
 
 
-def _need_split(pkg):
-    """the bf16-split passes exist only in the experimental build of the library (make -C csrc EXPERIMENTAL_SPLIT=1
-    OBJDIR=../../build_exp OUT=../../build_exp/libpdeconv_split.so; run these tests with PDEC_LIB_PATH pointing at it)"""
-    if not pkg._lib.load().pdec_debug_split_available():
-        pytest.skip("product build of libpdeconv.so: no bf16-split passes (HISTORY.md §3.2a)")
-
-
-def test_product_build_refuses_a_split_request(pkg, monkeypatch):
-    """PDEC_SPLIT != 0 with the product library is an error of the fused passes, never a silent exact-f32 run"""
+def test_library_refuses_a_split_request(pkg, monkeypatch):
+    """PDEC_SPLIT != 0 (the deleted bf16-split experiment, HISTORY.md §3.2a) is an error of the fused passes, never a silent
+    exact-f32 run"""
     import ctypes as C
     from oracle import nn
-    if pkg._lib.load().pdec_debug_split_available():
-        pytest.skip("experimental build: the split passes exist")
     rng = np.random.default_rng(2)
     da, aa = nn.layer_sizes(3, 1, 1.6, True, False)
     dc, ac = nn.layer_sizes(3, 1, 7.0, False, False)
@@ -317,97 +309,10 @@ def test_product_build_refuses_a_split_request(pkg, monkeypatch):
     s = to_dev(rng.standard_normal((256, 3)), torch.float32)
     L = torch.zeros(2, dtype=torch.float32, device="cuda:0")
     monkeypatch.setenv("PDEC_SPLIT", "a")
-    with pytest.raises(pkg.PdecError, match="without the experimental"):
+    with pytest.raises(pkg.PdecError, match="no longer exist"):
         pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, pkg._lib.ptr(s), 256, 1.0, C.c_void_p(L.data_ptr() + 4)))
     monkeypatch.setenv("PDEC_SPLIT", "0")
     pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, pkg._lib.ptr(s), 256, 1.0, C.c_void_p(L.data_ptr() + 4)))
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("split", ["a", "c", "1"])
-@pytest.mark.parametrize("quirk", [1, 0])
-@pytest.mark.parametrize("Bu", [4096, 77])
-def test_ddpg_update_with_bf16_split_passes_matches_oracle(pkg, monkeypatch, quirk, Bu, split):
-    """EXPERIMENTAL forms of the fused passes (PDEC_SPLIT, off by default; csrc/mlp_mfma.hip SPLIT): the 144 x 144 products on
-    v_mfma_f32_16x16x32_bf16 with W2 as a bf16 pair and the activation as three bf16 splits, five products accumulated in f32 --
-    a: both products of the actor pass, c: the two forward products of the critic pass, 1: both.  Same oracle, same tolerance
-    as the exact-f32 default (src/PDEagent.jl:363-418, 2e-4 relative on losses and all four networks after one and two updates)."""
-    _need_split(pkg)
-    monkeypatch.setenv("PDEC_SPLIT", split)
-    test_ddpg_update_matches_oracle(pkg, quirk, "f32", Bu)
-
-
-def test_bf16_split_gradients_track_the_exact_f32_form(pkg, monkeypatch):
-    """the gradients of one update (pdec_ddpg_critic_grads / pdec_ddpg_actor_grads, flat buffers) with split operands against the
-    exact-f32 MFMA form on the same inputs: <= 2e-5 of the largest gradient entry (16 mantissa bits of W2 in the split
-    products, all 24 bits of the activations); the pass a switch value does not name stays bit-identical"""
-    _need_split(pkg)
-    import ctypes as C
-    from oracle import nn
-    rng = np.random.default_rng(5)
-    ns, na, Bu = 3, 1, 8192
-    da, aa = nn.layer_sizes(ns, na, 1.6, True, False)
-    dc, ac = nn.layer_sizes(ns, na, 7.0, False, False)
-    s = to_dev(rng.standard_normal((Bu, ns)), torch.float32); sn = to_dev(rng.standard_normal((Bu, ns)), torch.float32)
-    a = to_dev(rng.uniform(-1, 1, (Bu, na)), torch.float32); r = to_dev(-rng.uniform(0, 1, Bu), torch.float32)
-    t = to_dev((rng.uniform(0, 1, Bu) < 0.1).astype(np.float64), torch.float32)
-    grads = {}
-    for split in ("0", "a", "c"):
-        monkeypatch.setenv("PDEC_SPLIT", split)
-        r2 = np.random.default_rng(9)
-        A, _ = make_net(pkg, r2, da, aa, torch.float32, Bu)
-        Cn, _ = make_net(pkg, r2, dc, ac, torch.float32, Bu)
-        At, _ = make_net(pkg, r2, da, aa, torch.float32, Bu)
-        Ct, _ = make_net(pkg, r2, dc, ac, torch.float32, Bu)
-        L = torch.zeros(2, dtype=torch.float32, device="cuda:0")
-        P = pkg._lib.ptr
-        pkg._lib.check(A.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, P(s), P(a), P(r), P(t), P(sn), Bu, 0.99, 1,
-                                                    1.0, C.c_void_p(L.data_ptr())))
-        pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, P(s), Bu, 1.0, C.c_void_p(L.data_ptr() + 4)))
-        torch.cuda.synchronize()
-        red = pkg.distributed.GradReducer()
-        grads[split] = (red._view(Cn).cpu().numpy().copy(), red._view(A).cpu().numpy().copy(), L.cpu().numpy().copy())
-    for split, other, mine in (("a", 0, 1), ("c", 1, 0)):
-        assert np.array_equal(grads["0"][other], grads[split][other])       # the pass the switch does not name: same kernel
-        g0, g1 = grads["0"][mine], grads[split][mine]
-        assert np.isfinite(g1).all() and np.abs(g1 - g0).max() <= 2e-5 * np.abs(g0).max(), (split, np.abs(g1 - g0).max(), np.abs(g0).max())
-        assert not np.array_equal(g0, g1)                                   # the switch really selected another kernel
-        assert np.abs(grads[split][2] - grads["0"][2]).max() <= 1e-5 * max(1.0, np.abs(grads["0"][2]).max())
-
-
-def test_bf16_split_images_are_rebuilt_after_updates_without_them(pkg, monkeypatch):
-    """The finish kernel refreshes the bf16-split blocks of the weight images only while a split form is selected.  Networks that
-    took ten updates with the default exact-f32 passes and are then read by a split pass must first get their images rebuilt
-    from the parameters (csrc/mlp_mfma.hip: split_stale): the split actor gradient still tracks the exact one to 2e-5 of its
-    largest entry (stale images -- ten ADAM steps at 1e-3 behind -- would be off by per cents)."""
-    _need_split(pkg)
-    import ctypes as C
-    from oracle import nn
-    monkeypatch.setenv("PDEC_SPLIT", "0")
-    rng = np.random.default_rng(11)
-    ns, na, Bu = 3, 1, 4096
-    da, aa = nn.layer_sizes(ns, na, 1.6, True, False)
-    dc, ac = nn.layer_sizes(ns, na, 7.0, False, False)
-    s = to_dev(rng.standard_normal((Bu, ns)), torch.float32); sn = to_dev(rng.standard_normal((Bu, ns)), torch.float32)
-    a = to_dev(rng.uniform(-1, 1, (Bu, na)), torch.float32); r = to_dev(-rng.uniform(0, 1, Bu), torch.float32)
-    t = to_dev((rng.uniform(0, 1, Bu) < 0.1).astype(np.float64), torch.float32)
-    A, _ = make_net(pkg, rng, da, aa, torch.float32, Bu)
-    Cn, _ = make_net(pkg, rng, dc, ac, torch.float32, Bu)
-    At, _ = make_net(pkg, rng, da, aa, torch.float32, Bu)
-    Ct, _ = make_net(pkg, rng, dc, ac, torch.float32, Bu)
-    P = pkg._lib.ptr
-    al, cl = C.c_double(), C.c_double()
-    for _ in range(10):
-        pkg._lib.check(A.lib.pdec_ddpg_update(A.handle, Cn.handle, At.handle, Ct.handle, P(s), P(a), P(r), P(t), P(sn), Bu, 0.99, 0.995, 1,
-                                             1e-3, 1e-3, C.byref(al), C.byref(cl)))
-    L = torch.zeros(2, dtype=torch.float32, device="cuda:0")
-    red = pkg.distributed.GradReducer()
-    grads = {}
-    for split in ("0", "a", "0"):
-        monkeypatch.setenv("PDEC_SPLIT", split)
-        pkg._lib.check(A.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, P(s), Bu, 1.0, C.c_void_p(L.data_ptr() + 4)))
-        torch.cuda.synchronize()
-        grads.setdefault(split, []).append(red._view(A).cpu().numpy().copy())
-    g0, g1 = grads["0"][0], grads["a"][0]
-    assert np.array_equal(grads["0"][0], grads["0"][1])
-    assert not np.array_equal(g0, g1) and np.abs(g1 - g0).max() <= 2e-5 * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())

@@ -332,9 +332,8 @@ def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
     """Two pipelines with the same seeds that differ only in TIMING must agree bit for bit: one issues its n control steps in
     one call (two streams, env step kicked behind the critic half, recorded-call replay), one is drained after every step, one
     reduces with the slower round-2 finish kernel.  Fields, action / reward rings, both flat gradient buffers and all four
-    networks.  (This is the check the experimental bf16-split passes FAILED beside the PDE step -- a few per cent of such runs,
-    one step wave wrong, tools/det_probe5.py -- which is why they are off by default and refused by a two-stream pipeline.)"""
-    monkeypatch.delenv("PDEC_SPLIT", raising=False)
+    networks.  (The check the bf16-split passes of rounds 2 - 4 failed beside the PDE step, HISTORY.md §3.2a; they were deleted
+    in round 5, the exact-f32 passes share their DMA / barrier helpers and pass it.)"""
     runs = []
     for mode in ("free", "drained", "finish_ref", "stamped"):
         if mode == "finish_ref":
@@ -361,14 +360,9 @@ def test_results_do_not_depend_on_stream_timing(pkg, monkeypatch, n):
         assert len(other) == len(runs[0]) and all(torch.equal(x, y) for x, y in zip(runs[0], other))
 
 
-def test_two_stream_pipeline_refuses_the_bf16_split_passes(pkg, monkeypatch):
-    """PDEC_SPLIT=a|c|1 selects the experimental bf16-split forms of the fused passes; beside the PDE step they are not
-    bit-stable (HISTORY.md §3.2a), so a two-stream TrainPipeline raises instead of training on silently wrong fields; on one
-    stream (nothing runs beside the passes) it is accepted -- by the experimental build of the library; the product build
-    does not contain those passes and refuses the request itself."""
-    monkeypatch.setenv("PDEC_SPLIT", "a")
-    with pytest.raises(pkg.PdecError, match="PDEC_SPLIT"):
-        _make(pkg, False, B=8, E=11)
+def test_a_request_for_the_deleted_bf16_split_passes_is_an_error(pkg, monkeypatch):
+    """PDEC_SPLIT=a|c|1 used to select the experimental bf16-split forms of the fused passes (deleted in round 5, HISTORY.md
+    §3.2a): the passes refuse the request instead of silently running exact f32"""
     setup = pkg.KSSetup.bench_C2(256)
     st = torch.cuda.Stream()
     y0 = setup.generate_random_init(np.random.default_rng(0), 8) * 0.15
@@ -376,12 +370,8 @@ def test_two_stream_pipeline_refuses_the_bf16_split_passes(pkg, monkeypatch):
     agent = pkg.create_agent(setup=setup, B=8, rng=np.random.default_rng(1), dtype=torch.float32, stream=st, start_steps=-1,
                              noise_seed=7, trajectory_length=1)
     p = pkg.TrainPipeline(env, agent, lag=2, episode_steps=11, stream_env=st, stream_upd=st, use_graphs=False, noise_seed=99)
-    assert p.serial
-    if pkg._lib.load().pdec_debug_split_available():      # experimental build of the library: the split passes run
-        p.run(6); p.sync()
-        assert bool(torch.isfinite(p.y).all())
-    else:                                                 # product build: the passes themselves refuse the request
-        with pytest.raises(pkg.PdecError, match="without the experimental"):
-            p.run(6)
-        monkeypatch.setenv("PDEC_SPLIT", "0")
+    monkeypatch.setenv("PDEC_SPLIT", "a")
+    with pytest.raises(pkg.PdecError, match="no longer exist"):
+        p.run(6)
+    monkeypatch.setenv("PDEC_SPLIT", "0")
     p.close()

@@ -74,4 +74,4 @@ for it in range(n):
                 rows = torch.nonzero(d.amax(dim=1)).flatten().tolist()
                 print(f"   iteration {it}: {int((d > 0).sum())} differing cells, max {float(d.max()):.3e}, trajectories {rows[:8]}")
 torch.cuda.synchronize()
-print(f"SPLIT={os.environ.get('PDEC_SPLIT')} SHARE={int(share)} BURN={os.environ.get('BURN', 'critic')}: {bad} of {n // int(os.environ.get('EVERY', '8'))} checked repetitions differ in the PDE fields, {badg} in the gradient of the pass")
+print(f"SHARE={int(share)} BURN={os.environ.get('BURN', 'critic')}: {bad} of {n // int(os.environ.get('EVERY', '8'))} checked repetitions differ in the PDE fields, {badg} in the gradient of the pass")

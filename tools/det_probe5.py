@@ -74,7 +74,7 @@ def one(n, side):
     p.close()
     return s
 
-tag = f"SPLIT={os.environ.get('PDEC_SPLIT')} CUMASK={os.environ.get('CUMASK')} B={B} base {BASE} A: {SIDES[0]} | B: {SIDES[1]}"
+tag = f"CUMASK={os.environ.get('CUMASK')} B={B} base {BASE} A: {SIDES[0]} | B: {SIDES[1]}"
 N = int(os.environ.get("N", "30"))
 nbad = 0
 for n in range(1, N + 1):
