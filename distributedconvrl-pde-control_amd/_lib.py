@@ -229,7 +229,10 @@ def make_stream(level=0, device=0):
     import torch
     lib = init(device)
     out = _vp()
-    check(lib.pdec_stream_create(C.byref(out), int(level)))
+    # pdec_stream_create makes the stream on the CURRENT HIP device: make `device` current for the call, so that the wrapper
+    # below names the device the stream really lives on
+    with torch.cuda.device(int(device)):
+        check(lib.pdec_stream_create(C.byref(out), int(level)))
     s = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", int(device)))
     _streams[out.value] = s
     return s
@@ -249,6 +252,7 @@ def make_streams(levels, device=0):
 def destroy_stream(s):
     """Releases a stream made by make_stream (the caller guarantees that no library object is still set to it)."""
     addr = int(s.cuda_stream)
-    if _streams.pop(addr, None) is None:
+    if addr not in _streams:
         raise PdecError("destroy_stream: not a stream of make_stream")
-    check(load().pdec_stream_destroy(_vp(addr)))
+    check(load().pdec_stream_destroy(_vp(addr)))       # (forgotten only once the library has released it)
+    _streams.pop(addr, None)

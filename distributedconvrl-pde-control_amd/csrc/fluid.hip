@@ -960,12 +960,13 @@ struct FluidEnv : Env {
   // round 4: two child environments of B/2 trajectories each (own work arrays, own stream) that fluid_env_step runs side by
   // side -- trajectories are independent, and the kernels of a right-hand side differ in what bounds them (K1 / K2: fp64
   // issue, K3: HBM), so one half's K3 hides under the other half's transforms (n = 512, B = 16: 96.4 -> 100.8 env-steps/s)
-  static constexpr int MAXPART = 4;
+  static constexpr int MAXPART = PartStreams::MAX;
   int nparts = 0;
   std::unique_ptr<FluidEnv> half[MAXPART];
-  hipStream_t pstream[MAXPART] = {nullptr, nullptr, nullptr, nullptr};      // [0] unused: part 0 runs on the environment's stream
-  bool own_ps[MAXPART] = {false, false, false, false};                     // made by the library (else the caller's)
-  hipEvent_t ev_fork = nullptr, ev_join[MAXPART] = {nullptr, nullptr, nullptr, nullptr};
+  // round 5: the children's streams through the helper both split environments share (common.hpp PartStreams):
+  // library-made streams are created at the first split step at the priority level of the environment's stream, as the 2-D
+  // Keller-Segel environment does -- not at creation time at the lowest level, before pdec_set_stream had named that stream
+  PartStreams ps;
   int part_streams() const override { return nparts >= 2 ? nparts - 1 : 0; }
   // the children exist since pdec_fluid_env_create: the caller's streams replace the library's one for one (all of them, or
   // PDEC_E_INVALID -- a child without a stream of its own would serialise behind another)
@@ -973,20 +974,11 @@ struct FluidEnv : Env {
     if (nparts < 2) return PDEC_OK;
     PDEC_REQUIRE(n >= nparts - 1, "pdec_env_set_part_streams: this environment runs %d parts and needs %d streams, got %d", nparts,
                  nparts - 1, n);
-    for (int i = 1; i < nparts; ++i) {
-      if (pstream[i] && own_ps[i]) PDEC_HIP(hipStreamDestroy(pstream[i]));
-      own_ps[i] = false;
-      pstream[i] = s[i - 1];
-    }
+    PDEC_HIP(ps.give(s, nparts - 1));
     return PDEC_OK;
   }
   ~FluidEnv() override {
-    for (int i = 0; i < MAXPART; ++i) {
-      half[i].reset();
-      if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-      if (pstream[i] && own_ps[i]) (void)hipStreamDestroy(pstream[i]);
-    }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (int i = 0; i < MAXPART; ++i) half[i].reset();
   }
 };
 
@@ -1339,23 +1331,27 @@ int fluid_env_step(Env& E0, const void* y_in, const void* action, const void* ac
     const size_t nn = (size_t)E.n * E.n, A = E.cfg.A, ns = (size_t)env_ns(E.cfg), na = (size_t)env_na(E.cfg);
     auto off = [](const void* p, size_t bytes) -> const void* { return p ? (const char*)p + bytes : nullptr; };
     auto offm = [](void* p, size_t bytes) -> void* { return p ? (char*)p + bytes : nullptr; };
-    PDEC_HIP(hipEventRecord(E.ev_fork, E.stream));
-    int b0 = 0;
+    {
+      bool refused = false;
+      PDEC_HIP(E.ps.ensure(E.stream, E.nparts, &refused));
+      PDEC_REQUIRE(!refused, "fluid step: its %d part streams do not exist yet and cannot be made while the environment's stream is "
+                   "being captured; run one step (or pdec_env_set_part_streams) before the capture, or PDEC_FLUID_SPLIT=0", E.nparts - 1);
+    }
+    PDEC_HIP(E.ps.fork(E.stream, E.nparts));
+    int b0 = 0, rc_part = PDEC_OK;
     for (int hh = 0; hh < E.nparts; ++hh) {
       FluidEnv& H = *E.half[hh];
-      H.stream = hh == 0 ? E.stream : E.pstream[hh];
-      if (hh > 0) PDEC_HIP(hipStreamWaitEvent(H.stream, E.ev_fork, 0));
+      H.stream = hh == 0 ? E.stream : E.ps.st[hh];
       H.term_out = E.term_out ? (char*)E.term_out + (size_t)b0 * A * 8 : nullptr;
       const int rc = fluid_env_step(H, off(y_in, b0 * nn * 16), off(action, b0 * A * na * 8), off(action_prev, b0 * A * na * 8),
                                     off(state_prev, b0 * A * ns * 8), offm(y_out, b0 * nn * 16), offm(p_out, b0 * nn * 16),
                                     offm(state_out, b0 * A * ns * 8), offm(reward_out, b0 * A * 8), done ? done + b0 : nullptr);
-      if (rc) return rc;
+      if (rc) { rc_part = rc; break; }              // (the part streams are joined below on this path too)
       b0 += H.cfg.B;
     }
-    for (int hh = 1; hh < E.nparts; ++hh) {
-      PDEC_HIP(hipEventRecord(E.ev_join[hh], E.pstream[hh]));
-      PDEC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[hh], 0));
-    }
+    const hipError_t ej = E.ps.join(E.stream, E.nparts);
+    if (rc_part) return rc_part;
+    PDEC_HIP(ej);
     return PDEC_OK;
   }
   void* ph = p_out ? p_out : E.phat.p;
@@ -1493,14 +1489,8 @@ extern "C" int pdec_fluid_env_create(pdec_handle* h, const pdec_env_cfg* cfg, in
       ch.B = left / (np - i);
       left -= ch.B;
       if ((rc = fluid_make(E->half[i], ch, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s))) return rc;
-      if (i > 0) {
-        PDEC_HIP(create_part_stream(&E->pstream[i]));
-        E->own_ps[i] = true;
-        PDEC_HIP(hipEventCreateWithFlags(&E->ev_join[i], hipEventDisableTiming));
-      }
     }
-    PDEC_HIP(hipEventCreateWithFlags(&E->ev_fork, hipEventDisableTiming));
-    E->nparts = np;
+    E->nparts = np;                                    // (streams and events: PartStreams::ensure at the first split step)
   }
   *h = register_object(std::move(E));
   return PDEC_OK;

@@ -316,22 +316,10 @@ struct Kseg2dEnv : Env {
   int nx = 0, ny = 0, Sx = 0, Sy = 0, hw = 0, nsub = 1;
   DevBuf sx, sy, a2s_d, cell_act, ftab, acnt, sums, pbuf, ytmp, done_tmp;
   size_t lds1 = 0, lds2 = 0;
-  static constexpr int MAXPART = 4;       // parts of the batch on their own streams during the RK4 sub-steps (k2_integrate)
-  hipStream_t pstream[MAXPART] = {nullptr, nullptr, nullptr, nullptr};        // [0] unused: part 0 runs on the environment's stream
-  bool own_ps[MAXPART] = {false, false, false, false};                       // made by the library (else the caller's)
-  int given_ps = -1;                                                           // >= 0: the caller handed over that many
-  int own_level = 0;                                                           // priority level of the library-made part streams
-  void* level_of = (void*)-1;                                                  // ... read from this environment stream
-  hipEvent_t ev_fork = nullptr, ev_join[MAXPART] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int MAXPART = PartStreams::MAX;   // parts of the batch on their own streams during the RK4 sub-steps (k2_integrate)
+  PartStreams ps;                                    // common.hpp: the caller's or library-made streams, fork / join events
   int part_streams() const override;
   int set_part_streams(const hipStream_t* s, int n) override;
-  ~Kseg2dEnv() override {
-    for (int i = 0; i < MAXPART; ++i) {
-      if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-      if (pstream[i] && own_ps[i]) (void)hipStreamDestroy(pstream[i]);
-    }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-  }
 };
 
 static Kseg2dEnv& as_k2(Env& E) { return static_cast<Kseg2dEnv&>(E); }
@@ -377,41 +365,23 @@ static int k2_launch_rk4(Kseg2dEnv& E, const void* y_in, const void* p, void* y_
 // Parts of the batch that the RK4 sub-steps run on streams of their own (fp32, one sub-step per launch).  Only when each part
 // still fills the chip (>= 512 tiles); PDEC_KSEG2D_SPLIT=0 off, 1 / 2 halves, 3 / 4 that many parts.  Default: three parts
 // (C4: 43 / 43 / 42 trajectories, 75.2 k env-steps/s against 72.1 k with halves and 71.1 k unsplit; FOUR parts -- with the
-// update's five busy streams on the four compute pipes, see create_part_stream -- fall to 65 k).
+// update's five busy streams on the four compute pipes, see PartStreams in common.hpp -- fall to 65 k).
 static int k2_parts(const Kseg2dEnv& E) {
   static const char* split_env = getenv("PDEC_KSEG2D_SPLIT");
   const int tiles_all = ((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2Tile<float>::TY - 1) / K2Tile<float>::TY) * E.cfg.B;
   int np = split_env ? atoi(split_env) : (tiles_all >= 1536 ? 3 : (tiles_all >= 1024 ? 2 : 0));
   if (np == 1) np = 2;
   np = std::min(std::min(np, (int)Kseg2dEnv::MAXPART), E.cfg.B);
-  if (E.given_ps >= 0) np = std::min(np, E.given_ps + 1);     // the caller's part streams: no more parts than it handed over
+  if (E.ps.given >= 0) np = std::min(np, E.ps.given + 1);     // the caller's part streams: no more parts than it handed over
   return np >= 2 ? np : 0;
 }
 
+// the part streams / events of a split step (PartStreams::ensure); refuses under stream capture when they do not exist yet
 static int k2_make_part_streams(Kseg2dEnv& E, int np) {
-  if (!E.ev_fork) PDEC_HIP(hipEventCreateWithFlags(&E.ev_fork, hipEventDisableTiming));
-  // the library's own part streams take the priority level of the environment's stream: part 0 runs on that stream itself, and
-  // parts of one level advance evenly (C4: 77-78 k env-steps/s against 74 k with the part streams one level below); the level
-  // is read when the environment's stream changes (PDEC_PART_LEVEL pins it)
-  static const char* pinned = getenv("PDEC_PART_LEVEL");
-  int level = 0;
-  if (!pinned && E.level_of != (void*)E.stream) {
-    if (E.stream) PDEC_HIP(hipStreamGetPriority(E.stream, &level));      // (the null stream: normal level)
-    E.level_of = (void*)E.stream;
-    if (level != E.own_level) {
-      for (int i = 1; i < Kseg2dEnv::MAXPART; ++i)
-        if (E.pstream[i] && E.own_ps[i]) { PDEC_HIP(hipStreamDestroy(E.pstream[i])); E.pstream[i] = nullptr; E.own_ps[i] = false; }
-      E.own_level = level;
-    }
-  }
-  for (int i = 1; i < np; ++i)
-    if (!E.pstream[i]) {
-      if (pinned) PDEC_HIP(create_part_stream(&E.pstream[i]));
-      else PDEC_HIP(hipStreamCreateWithPriority(&E.pstream[i], hipStreamNonBlocking, E.own_level));
-      E.own_ps[i] = true;
-    }
-  for (int i = 1; i < np; ++i)
-    if (!E.ev_join[i]) PDEC_HIP(hipEventCreateWithFlags(&E.ev_join[i], hipEventDisableTiming));
+  bool refused = false;
+  PDEC_HIP(E.ps.ensure(E.stream, np, &refused));
+  PDEC_REQUIRE(!refused, "2-D Keller-Segel step: its %d part streams do not exist yet and cannot be made while the environment's "
+               "stream is being captured; run one step (or pdec_env_set_part_streams) before the capture, or PDEC_KSEG2D_SPLIT=0", np - 1);
   return PDEC_OK;
 }
 
@@ -422,12 +392,7 @@ int Kseg2dEnv::part_streams() const {
 }
 
 int Kseg2dEnv::set_part_streams(const hipStream_t* s, int n) {
-  for (int i = 1; i < MAXPART; ++i) {
-    if (pstream[i] && own_ps[i]) PDEC_HIP(hipStreamDestroy(pstream[i]));
-    own_ps[i] = false;
-    pstream[i] = i - 1 < n ? s[i - 1] : nullptr;
-  }
-  given_ps = std::min(n, MAXPART - 1);
+  PDEC_HIP(ps.give(s, n));
   return PDEC_OK;
 }
 
@@ -451,28 +416,27 @@ static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, const voi
   const int np = sizeof(T) == 4 && ns == 1 && !E.prof ? k2_parts(E) : 0;
   if (np >= 2) {
     { const int rc = k2_make_part_streams(E, np); if (rc) return rc; }
-    PDEC_HIP(hipEventRecord(E.ev_fork, E.stream));
-    for (int i = 1; i < np; ++i) PDEC_HIP(hipStreamWaitEvent(E.pstream[i], E.ev_fork, 0));
-    for (int l = 0; l < launches; ++l) {
+    PDEC_HIP(E.ps.fork(E.stream, np));
+    int rc_launch = PDEC_OK;
+    for (int l = 0; l < launches && !rc_launch; ++l) {
       void* dst = ((launches - 1 - l) & 1) ? E.ytmp.p : y_out;
       const int last = l == launches - 1;
       if constexpr (sizeof(T) == 4) {
         int b0 = 0, left_b = E.cfg.B;
         for (int i = 0; i < np; ++i) {
           const int nb = left_b / (np - i);
-          hipStream_t st = i == 0 ? E.stream : E.pstream[i];
+          hipStream_t st = i == 0 ? E.stream : E.ps.st[i];
           const int rc = action ? k2_launch_rk4<T, 1, 2>(E, src, f, dst, done, last, b0, nb, st) : k2_launch_rk4<T, 1, 0>(E, src, f, dst, done, last, b0, nb, st);
-          if (rc) return rc;
+          if (rc) { rc_launch = rc; break; }          // (the part streams are joined below on this path too)
           b0 += nb;
           left_b -= nb;
         }
       }
       src = dst;
     }
-    for (int i = 1; i < np; ++i) {
-      PDEC_HIP(hipEventRecord(E.ev_join[i], E.pstream[i]));
-      PDEC_HIP(hipStreamWaitEvent(E.stream, E.ev_join[i], 0));
-    }
+    const hipError_t ej = E.ps.join(E.stream, np);
+    if (rc_launch) return rc_launch;
+    PDEC_HIP(ej);
     return PDEC_OK;
   }
   for (int l = 0; l < launches; ++l) {

@@ -76,12 +76,17 @@ class NativeGradReducer:
 
     Construction is a COLLECTIVE protocol in which every rank makes the same calls whatever fails:
       1. rank 0 creates the 128-byte ncclUniqueId and ALWAYS broadcasts (ok, id, error text) -- over torch.distributed's object
-         broadcast when a process group exists (any backend), or through `exchange` (a callable: rank 0 passes the tuple, every
-         rank gets it back, e.g. over a pipe); if rank 0 failed, every rank raises here, before anyone enters the rendezvous;
+         broadcast when a process group exists (any backend), or through `exchange` (a callable `exchange(payload, op)`:
+         op "broadcast" -- rank 0 passes the tuple, every rank gets it back, e.g. over a pipe; op "gather" -- every rank passes
+         its own payload and gets the list of all ranks' payloads in rank order); if rank 0 failed, every rank raises here,
+         before anyone enters the rendezvous;
       2. every rank enters RCCL's rendezvous with a bounded wait (`timeout_s`; a rank stuck without its peers comes back with
          an error instead of blocking for ever);
-      3. the ranks all-gather whether they hold a communicator; unless all do, every rank drops its own and raises.
-    So after the constructor either every rank has a working communicator or every rank got a PdecError."""
+      3. the ranks all-gather whether they hold a communicator -- through the process group or `exchange(..., "gather")` --;
+         unless all do, every rank drops its own and raises.
+    So after the constructor either every rank has a working communicator or every rank got a PdecError.  (with an
+    `exchange` that could only broadcast, step 3 was skipped and a peer of a failed rank kept a communicator whose first
+    all-reduce would never return; such a callable is now refused before anything collective starts.)"""
 
     native = True
 
@@ -102,9 +107,20 @@ class NativeGradReducer:
         if self.rank == 0:
             rc = lib.pdec_comm_unique_id(C.cast(buf, C.c_void_p))
             msg = (rc == 0, bytes(buf.raw), "" if rc == 0 else lib.pdec_last_error().decode(errors="replace"))
+        if self.world_size > 1 and exchange is not None:
+            import inspect
+            try:
+                n_par = len([q for q in inspect.signature(exchange).parameters.values()
+                             if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
+                var = any(q.kind == q.VAR_POSITIONAL for q in inspect.signature(exchange).parameters.values())
+            except (TypeError, ValueError):
+                n_par, var = 2, False
+            if n_par < 2 and not var:
+                raise _lib.PdecError("NativeGradReducer: `exchange` must be exchange(payload, op) with op 'broadcast' and 'gather' -- "
+                                     "without a gather the ranks cannot agree on whether every one of them holds a communicator")
         if self.world_size > 1:
             if exchange is not None:
-                msg = exchange(msg if self.rank == 0 else None)
+                msg = exchange(msg if self.rank == 0 else None, "broadcast")
             else:
                 box = [msg if self.rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
@@ -119,9 +135,14 @@ class NativeGradReducer:
         mine = rc == 0
         err = "" if mine else lib.pdec_last_error().decode(errors="replace")
         flags = [(mine, err)]
-        if self.world_size > 1 and exchange is None:
-            flags = [None] * self.world_size
-            dist.all_gather_object(flags, (mine, err))
+        if self.world_size > 1:
+            if exchange is not None:
+                flags = list(exchange((mine, err), "gather"))
+                if len(flags) != self.world_size:
+                    flags = flags + [(False, "exchange(..., 'gather') returned %d of %d verdicts" % (len(flags), self.world_size))]
+            else:
+                flags = [None] * self.world_size
+                dist.all_gather_object(flags, (mine, err))
         if not all(f[0] for f in flags):
             if mine:
                 lib.pdec_destroy(comm)

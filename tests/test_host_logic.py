@@ -524,3 +524,58 @@ def test_rlcore_wrap_shift_is_zero_until_the_traces_wrap(pkg):
     assert seen == [0] * 8 + [A - 1] * 12
     tr.emulate_rlcore_wrap = False
     assert tr._rlcore_wrap_shift() == 0
+
+
+def test_native_reducer_agrees_on_failure_through_an_exchange_callable(pkg):
+    """NativeGradReducer with `exchange` (no process group) must run the agreement step too -- two threads as ranks,
+    a fake library whose rendezvous fails on rank 1: BOTH constructors raise and rank 0 drops its communicator; an exchange
+    that cannot gather is refused before anything collective starts"""
+    import threading
+    from importlib import import_module
+    D = import_module("distributedconvrl-pde-control_amd.distributed")
+    L = import_module("distributedconvrl-pde-control_amd._lib")
+
+    class FakeLib:
+        def __init__(self, rank, fail):
+            self.rank, self.fail, self.destroyed = rank, fail, 0
+        def pdec_comm_unique_id(self, buf):
+            return 0
+        def pdec_comm_create_timeout(self, comm, n, rank, buf, ms):
+            return -1 if self.fail else 0
+        def pdec_last_error(self):
+            return b"rendezvous timed out (fake)"
+        def pdec_destroy(self, comm):
+            self.destroyed += 1
+            return 0
+
+    class Exchange:                                   # a 2-party board: broadcast from rank 0, gather in rank order
+        def __init__(self):
+            self.cv, self.box, self.round = threading.Condition(), {}, {}
+        def make(self, rank, n=2):
+            def ex(payload, op):
+                with self.cv:
+                    k = self.round.get(rank, 0)
+                    self.round[rank] = k + 1
+                    self.box.setdefault(k, {})[rank] = payload
+                    self.cv.notify_all()
+                    self.cv.wait_for(lambda: len(self.box[k]) == n, timeout=20)
+                    got = [self.box[k][r] for r in range(n)]
+                return got[0] if op == "broadcast" else got
+            return ex
+
+    for fail1 in (True, False):
+        board, libs, errs, reds = Exchange(), [FakeLib(0, False), FakeLib(1, fail1)], [None, None], [None, None]
+        def work(r):
+            try:
+                reds[r] = D.NativeGradReducer(libs[r], rank=r, world_size=2, exchange=board.make(r), timeout_s=1.0)
+            except L.PdecError as e:
+                errs[r] = str(e)
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        [t.start() for t in th]; [t.join(30) for t in th]
+        if fail1:
+            assert all(e and "rank(s) 1" in e for e in errs), errs
+            assert libs[0].destroyed == 1 and libs[1].destroyed == 0 and reds == [None, None]
+        else:
+            assert errs == [None, None] and all(r is not None and r.comm is not None for r in reds)
+    with pytest.raises(L.PdecError, match="gather"):
+        D.NativeGradReducer(FakeLib(0, False), rank=0, world_size=2, exchange=lambda payload: payload)
