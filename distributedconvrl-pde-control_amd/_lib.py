@@ -54,6 +54,7 @@ SIGNATURES = {
     "pdec_fluid_ic": [Handle, _pd, _i, _vp],
     "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
     "pdec_debug_critic_stamps": [Handle, _i, _pd],
+    "pdec_debug_kseg2d_probe": [Handle, _i, _i, _i, _pd],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
     "pdec_featurize": [Handle, _vp, _vp, _vp], "pdec_featurize_action": [Handle, _vp, _vp, _vp, _vp], "pdec_mlp_set_noise_rows": [Handle, _i],

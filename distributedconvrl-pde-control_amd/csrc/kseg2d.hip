@@ -93,7 +93,9 @@ struct alignas(16) QuadT {  // four consecutive scalars of one plane = two cell 
 // MODE 0: integrate NSUB sub-steps, 1: right-hand side only (KATs), 2: integrate with the forcing synthesised from the
 // action table (p_in = action [B][A]; p = agent_power * action[cell_act]: the [ny][nx] int table is shared by all
 // trajectories and stays in L2, so the per-sub-step HBM reads drop from 3 to 2 scalars per cell)
-template <class T, int NSUB, int MODE>
+// PROBE (pdec_debug_kseg2d_probe only): the sub-step loop runs `last` times on the tile held in registers -- the instruction mix
+// of a time-resident kernel without its halo exchange (the halo of the later repetitions is not refreshed: timing only)
+template <class T, int NSUB, int MODE, bool PROBE = false>
 __global__ __launch_bounds__(K2Tile<T>::NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 2) void kseg2d_rk4_kernel(K2Dev<T> e, const C2<T>* __restrict__ y_in,
                                                            const T* __restrict__ p_in, C2<T>* __restrict__ y_out,
                                                            int32_t* __restrict__ done, int last) {
@@ -153,7 +155,12 @@ __global__ __launch_bounds__(K2Tile<T>::NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 
     for (int i = 0; i < 2; ++i) { cu[k][i] = u0[k][i]; cv[k][i] = v0[k][i]; }
   }
   const T h = e.hstep;
-  for (int sub = 0; sub < NSUB; ++sub) {
+  const int nrep = PROBE ? last : NSUB;
+  for (int sub = 0; sub < nrep; ++sub) {
+    if (PROBE) {      // keep the compiler from hoisting the strips' LDS offsets out of the runtime loop (42 spilled registers otherwise)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) asm volatile("" : "+v"(sr[k]), "+v"(sc[k]));
+    }
 #pragma unroll
     for (int stage = 0; stage < 4; ++stage) {
       // publish the stage values
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(K2Tile<T>::NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 
       bad |= !(fabs(q.c[i].x) <= e.max_value && fabs(q.c[i].y) <= e.max_value);
     *reinterpret_cast<Quad<T>*>(y_out + g) = q;
   }
-  if (MODE != 1 && last && done && e.check_max == 1) {
+  if (MODE != 1 && !PROBE && last && done && e.check_max == 1) {
     if (__any(bad) && (tid & 63) == 0) atomicOr(done + b, 1);
   }
 }
@@ -481,6 +488,37 @@ static int k2_sense(Kseg2dEnv& E, const void* y, const void* action, const void*
   return PDEC_OK;
 }
 
+// Timing probe for the time-resident design question (HISTORY.md round 5): the fp32 tile kernel on `nb` trajectories with
+// `reps` sub-steps per launch, `iters` launches between two events on the environment's stream -> microseconds per launch.
+static int k2_probe(Kseg2dEnv& E, int nb, int reps, int iters, double* us) {
+  PDEC_REQUIRE(E.cfg.dtype == PDEC_F32 && nb >= 1 && nb <= E.cfg.B && reps >= 1 && iters >= 1, "pdec_debug_kseg2d_probe: fp32 environments, 1 <= nb <= B");
+  const size_t bytes = (size_t)E.cfg.B * E.ny * E.nx * 2 * sizeof(float);
+  if (E.ytmp.bytes < bytes) PDEC_HIP(E.ytmp.alloc(bytes));
+  DevBuf src, act;
+  PDEC_HIP(src.alloc(bytes));
+  PDEC_HIP(act.alloc((size_t)E.cfg.B * E.cfg.A * sizeof(float)));
+  PDEC_HIP(hipMemsetAsync(src.p, 0, bytes, E.stream));
+  PDEC_HIP(hipMemsetAsync(act.p, 0, (size_t)E.cfg.B * E.cfg.A * sizeof(float), E.stream));
+  constexpr int K2_TY = K2Tile<float>::TY, K2_NT = K2Tile<float>::NT;
+  const dim3 grid(((E.nx + K2_TX - 1) / K2_TX) * ((E.ny + K2_TY - 1) / K2_TY) * nb);
+  hipEvent_t e0, e1;
+  PDEC_HIP(hipEventCreate(&e0));
+  PDEC_HIP(hipEventCreate(&e1));
+  for (int it = -2; it < iters; ++it) {
+    if (it == 0) PDEC_HIP(hipEventRecord(e0, E.stream));
+    hipLaunchKernelGGL((kseg2d_rk4_kernel<float, 1, 2, true>), grid, dim3(K2_NT), k2_lds<1>(2 * sizeof(float)), E.stream, k2_dev<float>(E),
+                       src.as<C2<float>>(), act.as<float>(), E.ytmp.as<C2<float>>(), (int32_t*)nullptr, reps);
+  }
+  PDEC_HIP(hipEventRecord(e1, E.stream));
+  PDEC_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  PDEC_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *us = (double)ms * 1e3 / iters;
+  return PDEC_OK;
+}
+
 #define K2_DISPATCH(fn, ...) (E.cfg.dtype == PDEC_F64 ? fn<double>(E, __VA_ARGS__) : fn<float>(E, __VA_ARGS__))
 
 int kseg2d_actuate(Env& E0, const void* action, void* p_out) {
@@ -629,4 +667,11 @@ extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, i
   // -- whose priority level they take -- is known, and a caller that cares about where their queues land hands over its own)
   *h = register_object(std::move(E));
   return PDEC_OK;
+}
+
+// measurement aid (tools/kseg2d_resident_probe.py; not part of the reference's surface): see k2_probe
+extern "C" int pdec_debug_kseg2d_probe(pdec_handle h, int nb, int reps, int iters, double* us_per_launch) {
+  Env* E = lookup_as<Env>(h, Kind::Env);
+  PDEC_REQUIRE(E && E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4 && us_per_launch, "pdec_debug_kseg2d_probe: a 2-D Keller-Segel environment handle");
+  return k2_probe(as_k2(*E), nb, reps, iters, us_per_launch);
 }

@@ -225,6 +225,10 @@ int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, int nlines, 
  * workgroup, their sum, the shader clock in GHz (d s_memtime / d s_memrealtime x 100 MHz) and the workgroup count.
  * Synchronises the stream of the pass. */
 int pdec_debug_critic_stamps(pdec_handle critic, int arm, double* out13);
+/* Measurement aid (no counterpart in the reference): the fp32 2-D Keller-Segel tile kernel on `nb` trajectories with `reps` RK4
+ * sub-steps per launch on the tile held in registers (no halo refresh: timing only), `iters` launches between two events ->
+ * microseconds per launch.  What a time-resident form of KellerSegelSetup.jl:213-239 x 32 could at best cost (HISTORY.md round 5). */
+int pdec_debug_kseg2d_probe(pdec_handle env, int nb, int reps, int iters, double* us_per_launch);
 
 /* ---------------------------------------------------------------- networks ----------- */
 /* Chain(Dense...) with weights shared across columns (src/PDEagent.jl:14-56).

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Keller-Segel over the reference's whole train() (13 loops x >= 5000 steps): how often does a seed of this path hold the
+controller the way the reference's saved run does (episodes 5-35 between -1 and -3.4)?  Variants of the switches whose reference
+behaviour is uncertain for the Julia-1.9.4 artifacts (HISTORY.md round 5).
+    python tools/kseg_longrun_sweep.py n_seeds variant[,variant...]      variants: moving | moving_wrap | moving_diag | frozen"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("distributedconvrl-pde-control_amd")
+from util import load_golden, train  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1])
+    variants = sys.argv[2].split(",")
+    ref = load_golden("kseg_train.npz")["episode_rewards"]
+    np.set_printoptions(linewidth=220, precision=1, suppress=True)
+    stat = lambda r: (np.median(r[4:35]), float((r[4:35] < -9).mean()), r[4:35].max())
+    print("reference: median(5-35) %.2f, frac < -9: %.2f, best %.2f" % stat(ref))
+    setup = pkg.KellerSegelSetup()
+    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+    for v in variants:
+        good = 0
+        for seed in range(n):
+            env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
+            agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(700 + seed), noise_seed=1700 + seed, stream=s_upd,
+                                     quirk_frozen_targets=(v == "frozen"), quirk_target_broadcast=(v != "moving_diag"))
+            if v == "moving_wrap":
+                agent.policy.sampling = "host"
+                agent.trajectory.emulate_rlcore_wrap = True
+            hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, init_seed=2700 + seed, init_rng=np.random.default_rng(seed))
+            t = time.time()
+            train(pkg, agent, env, hook, loops=13, no_steps=5000, decay=0.6)
+            torch.cuda.synchronize()
+            r = np.asarray(hook.rewards)
+            med, bad, best = stat(r)
+            ok = med >= -3.5 and bad <= 0.2
+            good += ok
+            print(f"{v:12s} seed {seed:2d} ({time.time() - t:4.0f} s, {len(r)} ep): median(5-35) {med:7.2f}  frac<-9 {bad:.2f}  best {best:6.2f}  "
+                  f"{'LIKE REF' if ok else ''}  first 12: {r[:12]}", flush=True)
+        print(f"== {v}: {good} of {n} seeds hold the controller over episodes 5-35 like the reference's run", flush=True)
+
+
+if __name__ == "__main__":
+    main()
