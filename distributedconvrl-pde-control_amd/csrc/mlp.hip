@@ -690,6 +690,9 @@ int pdec_polyak(pdec_handle dst, pdec_handle src, double rho) {
   Mlp* S = lookup_as<Mlp>(src, Kind::Mlp);
   if (!S) { set_error("pdec_polyak: bad src"); return PDEC_E_HANDLE; }
   PDEC_REQUIRE(D->dims == S->dims && D->dtype == S->dtype, "pdec_polyak: shape/dtype mismatch");
+  // rho == 1: dest = 1 * dest + 0 * src -- the reference as it runs (its loop body never executes, include/pdeconv.h at this
+  // entry point): the target is left untouched, also where src holds an Inf / NaN that 0 * src would turn into NaN
+  if ((float)rho == 1.0f) return PDEC_OK;
   const int n = D->nparams;
   dim3 grid(cdiv(n, 256)), block(256);
   ProfScope ps(D, "polyak");

@@ -1149,7 +1149,10 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
     g.fwp = M->fw_pub[M->pub ^ 1].as<float>();       // written now, read by acting kernels enqueued after this launch
     g.lay = make_fnet_layout(M->dims[0], M->dims[1]);
     g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps;
-    if (Mt) {
+    // rho == 1 (the reference as it runs: its Polyak loop iterates over an empty parameter list, src/PDEagent.jl:415-417 with
+    // src/custom_nna.jl:20 -- agent.py quirk_frozen_targets): the target network is not touched at all, as in the reference
+    // (dest = 1 * dest + 0 * src would rewrite it with its own bits, and turn an Inf in src into a NaN in dest)
+    if (Mt && (float)ap->rho != 1.0f) {
       g.pt = Mt->params.as<float>(); g.fwt = Mt->fw.as<float>();
       const float r = (float)ap->rho;   // the reference holds p = 0.995f0 and computes (1 - p) in Float32
       g.rho = r; g.omr = 1.0f - r;

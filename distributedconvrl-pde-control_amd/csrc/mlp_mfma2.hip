@@ -808,6 +808,7 @@ static int launch_finish2(Mlp* M, Mlp* Mt, int nslab, int MT, int nR, double gra
     if (rcb) return rcb;
     g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
     g.eta = ap->eta; g.b1 = ap->b1; g.b2 = ap->b2; g.eps = ap->eps;
+    if (Mt && (float)ap->rho == 1.0f) Mt = nullptr;      // frozen targets (the reference as it runs): not touched, see mlp_mfma.hip launch_finish
     if (Mt) {
       g.pt = Mt->params.as<float>();
       const float r = (float)ap->rho;
@@ -862,6 +863,7 @@ int fused2_adam_polyak(Mlp* M, Mlp* Mt, const AdamPolyak& ap) {
   if (rcb) return rcb;
   g.p = M->params.as<float>(); g.m = M->m.as<float>(); g.v = M->v.as<float>();
   g.eta = ap.eta; g.b1 = ap.b1; g.b2 = ap.b2; g.eps = ap.eps;
+  if (Mt && (float)ap.rho == 1.0f) Mt = nullptr;        // frozen targets: not touched
   if (Mt) {
     g.pt = Mt->params.as<float>();
     const float r = (float)ap.rho;
