@@ -453,7 +453,9 @@ class Agent:
             return
         if p.update_step % p.update_freq != 0:                # :355
             return
-        on_device = p.sampling == "device" and getattr(tr, "_h", None) is not None
+        # (the emulation of RLCore's wrapped, misaligned traces lives in the host-sampling path only: _rlcore_wrap_shift)
+        on_device = (p.sampling == "device" and getattr(tr, "_h", None) is not None
+                     and not getattr(tr, "emulate_rlcore_wrap", False))
         if p.small_update_ok():
             # all update_loops minibatch updates in ONE launch; the slots of every loop (pde_sample,
             # src/PDEagent.jl:317-321) are drawn inside the kernel from the Philox stream, or here from the host rng

@@ -92,13 +92,16 @@ def test_training_run_reproduces_the_update_count_of_the_reference_agent(pkg, wh
 #   * Fluid_8 and the first training loop of Keller-Segel (artifacts written by Julia 1.9.4 -- another session of the authors):
 #     reproduced only with MOVING targets (rho = 0.995); frozen targets leave Keller-Segel at the saturated-actor return of
 #     -30 in 24 of 24 seeds.  Those runs evidently did not go through the committed custom_nna.jl.
-def _curves(pkg, setup, seeds, frozen, loops, no_steps, decay, hook_kw=None):
+def _curves(pkg, setup, seeds, frozen, loops, no_steps, decay, hook_kw=None, rlcore_wrap=False):
     out = []
     s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
     for seed in seeds:
         env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
         agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(100 + seed), noise_seed=1000 + seed, stream=s_upd,
                                  quirk_frozen_targets=frozen)
+        if rlcore_wrap:                      # RLCore's misaligned traces after wrap-around (agent.py: _rlcore_wrap_shift), host sampling
+            agent.policy.sampling = "host"
+            agent.trajectory.emulate_rlcore_wrap = True
         hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, init_seed=2000 + seed, init_rng=np.random.default_rng(seed),
                            **(hook_kw or {}))
         train(pkg, agent, env, hook, loops=loops, no_steps=no_steps, decay=decay)
@@ -139,6 +142,12 @@ def test_ks200_learning_curve_before_the_buffer_wraps(pkg):
     assert sum(all(band(r)) for r, _ in runs) >= 2, [np.round(r[:36], 1) for r, _ in runs]
     # aligned traces: no relapse after the wrap (the reference's worst episode after 36 is -26.2)
     assert np.median([r[36:].min() for r, _ in runs]) > -8.0
+    # ... and with RLCore's buffer emulated -- (s, a, s') taken A - 1 rows later than (r, t) once the traces have wrapped -- this path
+    # relapses after episode 37 like the reference's run (probe: 4 of 4 seeds, worst episodes -13 ... -21)
+    assert ref[36:].min() < -20.0 and ref[:36].min() > -21.0
+    wrapped = _curves(pkg, pkg.KSSetup.KS200(), range(3), True, 8, 800, 0.2, rlcore_wrap=True)
+    assert sum(all(band(r)) for r, _ in wrapped) >= 2                      # before the wrap: the same curve
+    assert np.median([r[36:].min() for r, _ in wrapped]) < -8.0, [np.round(r[36:].min(), 1) for r, _ in wrapped]
 
 
 def test_fluid8_learning_curve_needs_moving_targets(pkg):
