@@ -26,6 +26,10 @@ def make(which):
         return pkg.KellerSegelSetup(), dict(loops=13, no_steps=5000, decay=0.6), load_golden("kseg_train.npz")["episode_rewards"]
     if which == "fluid8":
         return pkg.FluidSetup.Fluid_8(), dict(loops=10, no_steps=580, decay=0.6), load_golden("fluid8_hook.npz")["episode_rewards"]
+    if which == "fluid16":
+        return pkg.FluidSetup.Fluid_16(), dict(loops=6, no_steps=580, decay=0.6), load_golden("fluid16_hook.npz")["episode_rewards"]
+    if which == "fluid32":
+        return pkg.FluidSetup.Fluid_32(), dict(loops=5, no_steps=580, decay=0.6), load_golden("fluid32_hook.npz")["episode_rewards"]
     raise SystemExit(which)
 
 
