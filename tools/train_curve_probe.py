@@ -26,6 +26,8 @@ def make(which):
         return pkg.KellerSegelSetup(), dict(loops=13, no_steps=5000, decay=0.6), load_golden("kseg_train.npz")["episode_rewards"]
     if which == "fluid8":
         return pkg.FluidSetup.Fluid_8(), dict(loops=10, no_steps=580, decay=0.6), load_golden("fluid8_hook.npz")["episode_rewards"]
+    if which == "ks22_global":       # KSglobalSetup.jl:330-345: 8 loops x >= 8000 steps (157 episodes each), noise x 0.2
+        return pkg.KSSetup.KS22_global(), dict(loops=8, no_steps=8000, decay=0.2), load_golden("ks22_global_hook.npz")["episode_rewards"]
     if which == "fluid16":
         return pkg.FluidSetup.Fluid_16(), dict(loops=6, no_steps=580, decay=0.6), load_golden("fluid16_hook.npz")["episode_rewards"]
     if which == "fluid32":
@@ -41,7 +43,8 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     setup, kw, ref = make(which)
     np.set_printoptions(linewidth=200, precision=2, suppress=True)
-    print("reference:", np.asarray(ref))
+    ref = np.asarray(ref)
+    print("reference:", ref if len(ref) <= 200 else np.array([np.median(ref[i:i + 50]) for i in range(0, len(ref), 50)]))
     for seed in range(n):
         s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
         env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
@@ -56,7 +59,7 @@ def main():
         torch.cuda.synchronize()
         r = np.asarray(hook.rewards)
         print(f"seed {seed}: {time.time() - t:.1f} s, {len(r)} episodes, best {hook.bestreward:.3f}")
-        print(r)
+        print(r if len(r) <= 200 else np.array([np.median(r[i:i + 50]) for i in range(0, len(r), 50)]))
 
 
 if __name__ == "__main__":
