@@ -109,3 +109,46 @@ def test_fluid_children_on_the_callers_stream_bit_identical(pkg):
     assert bool(torch.isfinite(e0.y).all())
     del e0, e1
     _release(pkg, s)
+
+
+def test_part_streams_are_not_made_under_stream_capture(pkg):
+    """ADVICE r4: the library's part streams / fork-join events of a split 2-D Keller-Segel step are made at the first split step;
+    while the environment's stream is being captured into a HIP graph that is illegal (it would invalidate the capture), so the
+    step refuses with an error -- and the same capture succeeds once one eager step has made them."""
+    import ctypes as C
+    L = pkg._lib
+    setup = pkg.KellerSegel2DSetup(substeps=2)
+    st = torch.cuda.Stream()
+    B = 64                                              # 1 024 tiles: two batch parts
+    lib = L.load()
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float32, stream=st)
+    assert env.n_part_streams == 1
+    y = torch.ones((B, 256, 256, 2), dtype=torch.float32, device="cuda:0")
+    p = torch.zeros((B, 256, 256), dtype=torch.float32, device="cuda:0")
+    out, want = torch.zeros_like(y), torch.zeros_like(y)
+    flags = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    step = lambda dst: lib.pdec_pde_step(env.handle, L.ptr(y), L.ptr(p), L.ptr(dst), L.ptr(flags))
+    torch.cuda.synchronize()
+    L.check(lib.pdec_capture_begin(env.handle))
+    try:
+        with pytest.raises(pkg.PdecError, match="captured"):
+            L.check(step(out))
+    finally:
+        h = L.Handle()
+        if lib.pdec_capture_end(env.handle, C.byref(h)) == 0:
+            lib.pdec_destroy(h)
+    torch.cuda.synchronize()
+    L.check(step(want))                                 # eager: makes the streams
+    torch.cuda.synchronize()
+    L.check(lib.pdec_capture_begin(env.handle))
+    try:
+        L.check(step(out))                              # now capturable: nothing left to create
+    finally:
+        h = L.Handle()
+        L.check(lib.pdec_capture_end(env.handle, C.byref(h)))
+    out.zero_()
+    torch.cuda.synchronize()
+    L.check(lib.pdec_graph_launch(h, None))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(want).all()) and torch.equal(out, want)
+    lib.pdec_destroy(h)
