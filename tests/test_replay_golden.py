@@ -166,3 +166,25 @@ def test_reference_target_networks_never_moved():
     for iW, ib, fan in ((24, 25, 1 + 6), (26, 27, 6 + 1), (28, 29, 2 + 140), (30, 31, 140 + 1)):
         assert (arr(ib) == 0).all()
         assert np.abs(arr(iW)).max() <= np.sqrt(6.0 / fan) and np.abs(arr(iW)).max() > 0.9 * np.sqrt(6.0 / fan)
+
+
+def test_last_logged_action_is_the_saved_actor_on_the_last_state():
+    """A20 against reference-held data: in the last training loop the exploration noise is 1.2 * 0.2^7 = 1.5e-5, so the action of the
+    very last control step (row 52 216 ... 52 223 of the action trace) is clamp(actor(state)) of the behaviour actor at that moment,
+    and the saved behaviour actor (f32_00..03) is that actor plus the 20 minibatch updates of that one step: the oracle's forward
+    (Dense(1, 6, relu) -> Dense(6, 1, tanh), W[out, in] layout, src/PDEagent.jl:18-30, 183-204) reproduces the stored actions to
+    2e-2 on all 8 actuators (measured 1.1e-2; the activations in the wrong order miss by 8e-2; a step earlier the actor was still
+    0.2 away -- the bang-bang policy moves fast)."""
+    from oracle import nn
+    g, w = load_golden("ks22_agent_train.npz"), load_golden("ks22_agent.npz")
+    n = int(g["n_rt"])
+    s_last, a_last = g["state"][n - A:n].astype(np.float64), g["action"][n - A:n].astype(np.float64)
+    P = [w[f"f32_{i:02d}"] for i in range(4)]
+    assert [p.shape for p in P] == [(6, 1), (6,), (1, 6), (1,)]
+    _, acts = nn.layer_sizes(1, 1, 0.6, True, True)
+    out = nn.policy_act(P, acts, s_last[None, :], None, 0.0, 1.0, learning=False)
+    assert np.abs(out[0] - a_last).max() <= 2e-2
+    # the controls: tanh before relu, or the transposed layout, miss by far more
+    W1, b1, W2, b2 = (p.astype(np.float64) for p in P)
+    wrong = np.maximum(W2 @ np.tanh(W1 @ s_last[None, :] + b1[:, None]) + b2[:, None], 0)[0]
+    assert np.abs(np.clip(wrong, -1, 1) - a_last).max() > 0.06
