@@ -188,3 +188,101 @@ def test_last_logged_action_is_the_saved_actor_on_the_last_state():
     W1, b1, W2, b2 = (p.astype(np.float64) for p in P)
     wrong = np.maximum(W2 @ np.tanh(W1 @ s_last[None, :] + b1[:, None]) + b2[:, None], 0)[0]
     assert np.abs(np.clip(wrong, -1, 1) - a_last).max() > 0.06
+
+
+def test_saved_critic_regresses_on_the_batch_mean_reward():
+    """The reward-broadcast quirk (`qnext = r .+ y .* (1 .- t) .* q_t` at src/PDEagent.jl:388 makes a Bu x Bu matrix, so
+    the critic's target for sample i is the BATCH-MEAN reward + gamma (1 - t_i) q_t,i) confirmed from reference-held data instead of
+    by reading: with batch_size = 3 the trained critic must satisfy
+        C(s, a) - gamma (1 - t) C_t(s', A_t(s'))  ~  (1/3) r(s, a) + (2/3) E[r]
+    over the replay buffer.  Everything on both sides is in scripts/KS/KS22/saves/agent.jld2: the behaviour critic (f32_12..15), the
+    frozen target networks (f32_24..31), the 52 224 transitions.  Fitted slope 0.32, correlation 0.98, intercept -0.029 = (2/3) x
+    mean reward; a diagonal TD loss would give slope 1.  The same numbers pin the oracle's forward (W[out, in], relu -> identity,
+    input rows [s; a]), the +A next-state indexing and the terminal mask."""
+    from oracle import nn
+    g, w = load_golden("ks22_agent_train.npz"), load_golden("ks22_agent.npz")
+    n = int(g["n_rt"])
+    s, a, r = (g[k].astype(np.float32) for k in ("state", "action", "reward"))
+    P = lambda ids: [w[f"f32_{i:02d}"] for i in ids]
+    critic, target_actor, target_critic = P((12, 13, 14, 15)), P((24, 25, 26, 27)), P((28, 29, 30, 31))
+    _, acts_a = nn.layer_sizes(1, 1, 0.6, True, True)
+    _, acts_c = nn.layer_sizes(1, 1, 7.0, False, True)
+    t = np.zeros(n, np.float32)
+    t.reshape(-1, 51, A)[:, 50, :] = 1.0
+    idx = np.arange(n - A)
+    q = nn.forward(critic, acts_c, np.stack([s[idx], a[idx]]))[0]
+    sn = s[idx + A][None]
+    qt = nn.forward(target_critic, acts_c, np.concatenate([sn, nn.forward(target_actor, acts_a, sn)]))[0]
+    assert np.abs(qt).max() < 5e-3                                   # the frozen initial critic on these states: ~ 0
+    y = (q - np.float32(0.99) * (1 - t[idx]) * qt).astype(np.float64)
+    x = r[idx].astype(np.float64)
+    slope, intercept = np.polyfit(x, y, 1)
+    assert 0.29 <= slope <= 0.37, slope                              # 1 / batch_size, not 1
+    assert np.corrcoef(x, y)[0, 1] > 0.97
+    assert abs(intercept - (2.0 / 3.0) * x.mean()) < 0.01, (intercept, x.mean())
+
+
+def test_saved_actor_sits_at_the_maximum_of_the_saved_critic():
+    """The actor half of the update (loss = -mean(C([s; A(s)])), src/PDEagent.jl:402-412: ascent on Q through the updated critic) from
+    reference-held data: on the states of the last 16 episodes of the KS22 buffer the saved behaviour actor's action is a maximum of
+    the saved behaviour critic along a -- moving it by +-0.5 lowers Q on average (by 1.8e-3 and 5.8e-3), the slope dQ/da is ~ 0
+    inside (-1, 1) and points outward wherever tanh has saturated (100 % of those columns).  A descent on Q (wrong sign) would
+    leave the actor at a minimum."""
+    from oracle import nn
+    g, w = load_golden("ks22_agent_train.npz"), load_golden("ks22_agent.npz")
+    n = int(g["n_rt"])
+    S = g["state"][n - 16 * 51 * A:n].astype(np.float32)[None]
+    P = lambda ids: [w[f"f32_{i:02d}"] for i in ids]
+    actor, critic = P((0, 1, 2, 3)), P((12, 13, 14, 15))
+    _, acts_a = nn.layer_sizes(1, 1, 0.6, True, True)
+    _, acts_c = nn.layer_sizes(1, 1, 7.0, False, True)
+    Q = lambda a: nn.forward(critic, acts_c, np.concatenate([S, a.astype(np.float32)]))[0].astype(np.float64)
+    a0 = nn.forward(actor, acts_a, S)
+    q0 = Q(a0)
+    for d in (-0.5, 0.5):
+        assert (Q(np.clip(a0 + d, -1, 1)) - q0).mean() < -1e-3
+    grad = (Q(np.clip(a0 + 1e-3, -1, 1)) - Q(np.clip(a0 - 1e-3, -1, 1))) / 2e-3
+    sat = np.abs(a0[0]) > 0.98
+    assert sat.sum() > 100 and (np.sign(grad[sat]) == np.sign(a0[0][sat])).mean() > 0.95
+    assert np.abs(grad[~sat]).mean() < 2e-3
+
+
+def test_saved_adam_second_moments_have_the_scale_of_the_quirk_gradient():
+    """The SCALE of the critic gradient from reference-held data.  Flux's ADAM keeps v = EMA(g^2) (beta2 = 0.999: the last ~1000
+    minibatch updates) beside every parameter; at the end of the KS22 run the networks barely move (noise 1.5e-5), minibatches are
+    drawn uniformly from the whole buffer, so the saved v of the behaviour critic (agent.jld2: the (140, 2) / (140,) / (1, 140) / (1,)
+    arrays behind the critic's parameters) must be close to E[g^2] over random 3-sample minibatches of the saved buffer under the
+    saved networks.  With the oracle's gradient of the reference's loss as it is evaluated -- mean over the Bu x Bu broadcast, frozen
+    targets -- the ratio is 0.7 ... 0.9 on every live parameter (most hidden units are dead: relu); with the diagonal TD loss it is
+    5 ... 17 (the reward term is not averaged over the batch), except for the output bias whose gradient is the same sum in both."""
+    from oracle import nn
+    g, w = load_golden("ks22_agent_train.npz"), load_golden("ks22_agent.npz")
+    n = int(g["n_rt"])
+    s, a, r = (g[k].astype(np.float32) for k in ("state", "action", "reward"))
+    t = np.zeros(n, np.float32)
+    t.reshape(-1, 51, A)[:, 50, :] = 1.0
+    P = lambda ids: [w[f"f32_{i:02d}"] for i in ids]
+    actor, critic, At, Ct = P((0, 1, 2, 3)), P((12, 13, 14, 15)), P((24, 25, 26, 27)), P((28, 29, 30, 31))
+    v_ref = [w["f32_23"], w["f32_19"], w["f32_17"], w["f32_21"]]                 # v of W1, b1, W2, b2 (shapes checked below)
+    assert [x.shape for x in v_ref] == [p.shape for p in critic] and all((x >= 0).all() for x in v_ref)
+    _, acts_a = nn.layer_sizes(1, 1, 0.6, True, True)
+    _, acts_c = nn.layer_sizes(1, 1, 7.0, False, True)
+    rng = np.random.default_rng(0)
+
+    def second_moment(quirk, N):
+        acc = [np.zeros(p.shape, np.float64) for p in critic]
+        for _ in range(N):
+            i = rng.integers(0, n - A, 3)                                        # pde_sample: 1:length(t) - A
+            out = nn.ddpg_losses_and_grads(actor, critic, At, Ct, acts_a, acts_c, s[i][None], a[i][None], r[i], t[i], s[i + A][None],
+                                           np.float32(0.99), quirk)
+            for k, gk in enumerate(out["gC"]):
+                acc[k] += gk.astype(np.float64) ** 2
+        return [x / N for x in acc]
+
+    live = v_ref[0] > 1e-12
+    assert 4 <= live.sum() <= 40                                                 # a handful of live hidden units
+    for quirk, N, lo, hi in ((True, 2500, 0.5, 1.6), (False, 1200, 3.0, 60.0)):
+        v = second_moment(quirk, N)
+        ratio_w1 = np.median(v[0][live] / v_ref[0][live])
+        assert lo <= ratio_w1 <= hi, (quirk, ratio_w1)
+        assert 0.6 <= float(v[3][0] / v_ref[3][0]) <= 1.5                        # output bias: same in both forms
