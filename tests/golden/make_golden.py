@@ -98,8 +98,20 @@ def agent_training(name, rel, A, full):
         s, a, r = big
         kw.update(n_rt=n_rt, n_sa=n_rt + A, state=s[:n_rt + A].copy(), action=a[:n_rt + A].copy(), reward=r[:n_rt].copy())
     else:
-        # wrapped buffer (80 actuators x 6528 steps > capacity): only the frame counts
+        # wrapped buffer (80 actuators x 6528 steps > capacity): the frame counts ...
         kw.update(nframes_rt=len(int64_hits(fa.buf, 150000)), nframes_sa=len(int64_hits(fa.buf, 150001)))
+        # ... and the oldest 6 000 frames of every trace in LOGICAL order.  A CircularArrayBuffer is serialised as (buffer, first,
+        # nframes, step_size): the Int64 in front of nframes is `first`, the 1-based physical position of the oldest frame.
+        def first_of(nframes):
+            pos = int64_hits(fa.buf, nframes)[0]
+            first, nf, step = np.frombuffer(fa.buf[pos - 8:pos + 16], "<i8")
+            assert nf == nframes and step == 1 and 1 <= first <= nframes
+            return int(first)
+        first_sa, first_rt = first_of(150001), first_of(150000)
+        s, a, r = big
+        head = lambda x, first: np.roll(x, -(first - 1))[:6000].copy()
+        kw.update(first_sa=first_sa, first_rt=first_rt, state_head=head(s, first_sa), action_head=head(a, first_sa),
+                  reward_head=head(r, first_rt), terminal_head=head(t, first_rt))
     save(name, **kw)
 
 
