@@ -294,7 +294,7 @@ def test_rlcore_traces_are_misaligned_after_wrap_around_in_the_reference_buffer(
     150 000 from 72 241 -- exactly (pushes mod capacity) + 1 for 522 320 and 522 240 pushes.  In LOGICAL order (what `pde_fetch!` indexes
     with ONE index for all four traces, src/PDEagent.jl:323-340) the reward at index i is the reward function of the state / action
     at index i - 79 (KSSetup.jl:162-178 through the sensor value 30 s': residual 2e-9), NOT of those at index i (residual 3e-3): once
-    the traces have wrapped, a sampled (s, a, s') lies A - 1 = 79 rows behind its (r, t).  The product keeps its traces aligned;
+    the traces have wrapped, a sampled (s, a, s') comes from A - 1 = 79 rows LATER than the transition its (r, t) belong to.  The product keeps its traces aligned;
     `_rlcore_wrap_shift` (agent.py) is this offset, for the study of its effect on the learning curve (tests/test_gpu_training.py)."""
     g = load_golden("ks200_agent_train.npz")
     A2, cap = int(g["n_actuators"]), int(g["capacity"])
