@@ -112,6 +112,9 @@ def agent_training(name, rel, A, full):
         head = lambda x, first: np.roll(x, -(first - 1))[:6000].copy()
         kw.update(first_sa=first_sa, first_rt=first_rt, state_head=head(s, first_sa), action_head=head(a, first_sa),
                   reward_head=head(r, first_rt), terminal_head=head(t, first_rt))
+        # the four networks and their ADAM moments (file order as in ks22_agent.npz: f32_00 ...)
+        for i, arr in enumerate(x for x in (fa.array(o) for o in fa.numeric(1, 4) if o.dims) if x.size < 2000):
+            kw[f"f32_{i:02d}"] = np.ascontiguousarray(arr)
     save(name, **kw)
 
 

@@ -158,14 +158,16 @@ def test_reference_target_networks_never_moved():
     (f32_00..03, f32_12..15) have left it: the Polyak loop of src/PDEagent.jl:415-417 iterates over Flux.params([At, Ct]), which
     is empty because src/custom_nna.jl:20 defines a `functor` of its own instead of extending Functors.functor -- the reference's
     target networks are frozen at their initial values.  (The product mirrors this with quirk_frozen_targets, agent.py.)"""
-    g = load_golden("ks22_agent.npz")
-    arr = lambda i: g[f"f32_{i:02d}"]
-    # behaviour actor / critic: trained
-    assert np.abs(arr(0)).max() > 5 and np.abs(arr(1)).max() > 0.1 and np.abs(arr(13)).max() > 0.1
-    # target actor 1 -> 6 -> 1, target critic 2 -> 140 -> 1: W inside the init range, b == 0 exactly
-    for iW, ib, fan in ((24, 25, 1 + 6), (26, 27, 6 + 1), (28, 29, 2 + 140), (30, 31, 140 + 1)):
-        assert (arr(ib) == 0).all()
-        assert np.abs(arr(iW)).max() <= np.sqrt(6.0 / fan) and np.abs(arr(iW)).max() > 0.9 * np.sqrt(6.0 / fan)
+    for name in ("ks22_agent.npz", "ks200_agent_train.npz"):         # two independent training runs of the reference
+        g = load_golden(name)
+        arr = lambda i: g[f"f32_{i:02d}"]
+        # behaviour actor / critic: trained
+        assert np.abs(arr(0)).max() > 2 and np.abs(arr(1)).max() > 0.1 and np.abs(arr(13)).max() > 0.1
+        # target actor 1 -> 6 -> 1, target critic 2 -> 140 -> 1: W inside the init range, b == 0 exactly
+        for iW, ib, fan in ((24, 25, 1 + 6), (26, 27, 6 + 1), (28, 29, 2 + 140), (30, 31, 140 + 1)):
+            assert (arr(ib) == 0).all()
+            lim = np.sqrt(6.0 / fan)
+            assert np.abs(arr(iW)).max() <= lim and np.abs(arr(iW)).max() > (0.9 if arr(iW).size >= 100 else 0.5) * lim
 
 
 def test_last_logged_action_is_the_saved_actor_on_the_last_state():
