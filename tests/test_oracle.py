@@ -286,3 +286,25 @@ def test_c_oracle_is_clean_under_asan_and_ubsan():
     r = subprocess.run([os.path.join(root, "oracle", "_build", "oracle_sanitize")], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "sanitize: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_global_agent_last_logged_action_is_the_saved_best_actor_on_the_last_state():
+    """The mono / global path (KSglobalSetup.jl:211-249 featurize -> [8, 1] state; actor 8 -> 48 -> 8, src/PDEagent.jl:18-30) against
+    reference-held data: scripts/KS/KS22_global-agent/saves/hook.jld2 logs the best episode (noise 1.2 * 0.2^k, small by then) and
+    keeps a copy of the actor taken at that episode's end (`bestNNA`, src/PDEhook.jl:68-75).  The action of the last logged row is that
+    actor -- 20 minibatch updates earlier -- on the state of the row before: the oracle's featurize + forward give it to 7e-2 on all
+    eight actuators; the sensors in reversed order miss by 0.70, a state scaled by 2 by 0.50."""
+    from oracle import ks, nn
+    g = load_golden("ks22_global_hook.npz")
+    nx, Lx, stride, sigma = int(g["nx"]), float(g["Lx"]), int(g["sensor_stride"]), float(g["sigma"])
+    cfg = ks.KSConfig(nx, Lx, np.arange(1, nx + 1, stride), sigma_sensors=sigma, sigma_actuators=sigma, mono=True,
+                      disturbance_in_step=False)
+    P = [g["best_W1"], g["best_b1"], g["best_W2"], g["best_b2"]]
+    assert [p.shape for p in P] == [(48, 8), (48,), (8, 48), (8,)]
+    acts = [nn.RELU, nn.TANH]
+    st = ks.featurize(cfg, g["y"][49])
+    assert st.shape == (8, 1)
+    a = g["action"][50].reshape(-1)
+    f = lambda s: nn.policy_act(P, acts, s, None, 0.0, 1.0, learning=False).reshape(-1)
+    assert np.abs(f(st) - a).max() <= 0.09
+    assert np.abs(f(st[::-1]) - a).max() > 0.4 and np.abs(f(2 * st) - a).max() > 0.3
