@@ -2,7 +2,7 @@
 """Keller-Segel over the reference's whole train() (13 loops x >= 5000 steps): how often does a seed of this path hold the
 controller the way the reference's saved run does (episodes 5-35 between -1 and -3.4)?  Variants of the switches whose reference
 behaviour is uncertain for the Julia-1.9.4 artifacts (HISTORY.md round 5).
-    python tools/kseg_longrun_sweep.py n_seeds variant[,variant...]      variants: moving | moving_wrap | moving_diag | frozen"""
+    python tools/kseg_longrun_sweep.py n_seeds variant[,variant...]      variants: moving | moving_wrap | moving_diag | frozen | frozen_diag"""
 import importlib
 import os
 import sys
@@ -32,7 +32,7 @@ def main():
         for seed in range(n):
             env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
             agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(700 + seed), noise_seed=1700 + seed, stream=s_upd,
-                                     quirk_frozen_targets=(v == "frozen"), quirk_target_broadcast=(v != "moving_diag"))
+                                     quirk_frozen_targets=v.startswith("frozen"), quirk_target_broadcast=not v.endswith("_diag"))
             if v == "moving_wrap":
                 agent.policy.sampling = "host"
                 agent.trajectory.emulate_rlcore_wrap = True
