@@ -10,7 +10,7 @@ from .env import PDEenv  # noqa: F401
 from .nna import (HipMLP, ADAM, CustomNeuralNetworkApproximator, create_NNA, create_chain,  # noqa: F401
                   glorot_uniform, layer_spec)
 from .agent import (Agent, CustomDDPGPolicy, CircularArraySARTTrajectory, ZeroPolicy, RandomPolicy,  # noqa: F401
-                    NegatePolicy, NegateAgent, create_agent_negate, create_agent, PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE,
+                    NegatePolicy, NegateAgent, create_agent_negate, create_agent, TargetNetworkWarning, PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE,
                     POST_EPISODE_STAGE, POST_EXPERIMENT_STAGE)
 from .hook import PDEhook  # noqa: F401
 from .run import run, testrun, StopAfterEpisode, StopAfterEpisodeWithMinSteps  # noqa: F401

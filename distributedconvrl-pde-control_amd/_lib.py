@@ -52,9 +52,6 @@ SIGNATURES = {
     "pdec_fluid_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _pd, _pi32, _pd, _pi32, _pi32],
     "pdec_kseg2d_env_create": [C.POINTER(Handle), C.POINTER(EnvCfg), _i, _i, _i, _pi32, _pi32, _i, _pi32],
     "pdec_fluid_ic": [Handle, _pd, _i, _vp],
-    "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
-    "pdec_debug_critic_stamps": [Handle, _i, _pd],
-    "pdec_debug_kseg2d_probe": [Handle, _i, _i, _i, _pd],
     "pdec_actuate": [Handle, _vp, _vp],
     "pdec_pde_step": [Handle, _vp, _vp, _vp, _vp],
     "pdec_featurize": [Handle, _vp, _vp, _vp], "pdec_featurize_action": [Handle, _vp, _vp, _vp, _vp], "pdec_mlp_set_noise_rows": [Handle, _i],
@@ -97,6 +94,7 @@ SIGNATURES = {
     "pdec_capture_begin": [Handle], "pdec_capture_end": [Handle, C.POINTER(Handle)],
     "pdec_graph_launch": [Handle, _vp], "pdec_graph_num_nodes": [Handle, C.POINTER(_i)],
     "pdec_event_create": [C.POINTER(Handle)], "pdec_event_record": [Handle, _vp], "pdec_stream_wait_event": [_vp, Handle], "pdec_mlp_set_stop_event": [Handle, Handle], "pdec_mlp_flush_stop_event": [Handle],
+    "pdec_mlp_set_reduce_event": [Handle, Handle],
     "pdec_env_set_simd_sharing": [Handle, C.c_int, C.POINTER(C.c_int)],
     "pdec_ddpg_critic_grads": [Handle] * 4 + [_vp] * 5 + [_i, _d, _i, _d, _vp],
     "pdec_ddpg_actor_grads": [Handle, Handle, _vp, _i, _d, _vp],
@@ -104,6 +102,14 @@ SIGNATURES = {
     "pdec_comm_unique_id": [_vp], "pdec_comm_create": [C.POINTER(Handle), _i, _i, _vp],
     "pdec_comm_create_timeout": [C.POINTER(Handle), _i, _i, _vp, _i],
     "pdec_allreduce_grads": [Handle, Handle], "pdec_allreduce": [Handle, _vp, _sz, _i, _vp],
+    "pdec_allreduce_grads_on": [Handle, Handle, _vp],
+}
+# include/pdeconv_debug.h: unit-test / measurement entry points (tests/, bench.py, tools/), not part of the drop-in surface
+DEBUG_SIGNATURES = {
+    "pdec_debug_wave_fft": [_vp, _vp, _i, _i, _i],
+    "pdec_debug_critic_stamps": [Handle, _i, _pd],
+    "pdec_debug_kseg2d_probe": [Handle, _i, _i, _i, _pd],
+    "pdec_debug_spin_us": [_vp, _d],
 }
 _RESTYPES = {"pdec_last_error": C.c_char_p}
 
@@ -165,7 +171,7 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C distributedconvrl-pde-control_amd/csrc` (there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
-    for name, args in SIGNATURES.items():
+    for name, args in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int

@@ -15,6 +15,11 @@ from . import _lib
 from .env import _on_stream
 from .nna import create_NNA
 
+class TargetNetworkWarning(UserWarning):
+    """create_agent was asked for a target-network regime other than the one that reproduces the reference's saved runs of
+    the setup's experiment family (setup.reproduces_reference_with)"""
+
+
 PRE_EXPERIMENT_STAGE, PRE_EPISODE_STAGE, PRE_ACT_STAGE, POST_ACT_STAGE, POST_EPISODE_STAGE, POST_EXPERIMENT_STAGE = range(6)
 
 
@@ -80,7 +85,8 @@ def create_agent_negate(*, setup, start_steps=0, start_policy=None):
 class CircularArraySARTTrajectory:
     """Device-resident replay with the reference's trace layout (state/action one `stride`
     longer than reward/terminal; Float32, src/PDEagent.jl:112-117).  Unlike RLCore's buffer the
-    four traces stay aligned after wrap-around (reference quirks)."""
+    four traces stay aligned after wrap-around (reference quirks; the reference's misaligned buffer is emulated
+    for learning-curve studies by a subclass in tests/util.py, outside the product)."""
 
     def __init__(self, capacity, ns, na, stride, device, reward_per_column=True):
         """On a CUDA device the stage operations are library kernels once `bind(model)` has named the handle whose
@@ -185,9 +191,8 @@ class CircularArraySARTTrajectory:
         inds = rng.integers(0, hi, batch_size)
         base = max(0, self.n_rt - self.capacity)          # logical index of the oldest entry
         lg = base + inds
-        ls = lg + self._rlcore_wrap_shift()
-        return (ls % (self.capacity + self.stride), lg % self.capacity,
-                (ls + self.stride) % (self.capacity + self.stride))
+        return (lg % (self.capacity + self.stride), lg % self.capacity,
+                (lg + self.stride) % (self.capacity + self.stride))
 
     def sample_slots_many(self, rng, batch_size, loops):
         """`loops` independent pde_sample draws in one vectorised call -> int array [3, loops, batch_size]
@@ -195,23 +200,8 @@ class CircularArraySARTTrajectory:
         hi = len(self) - self.stride
         inds = rng.integers(0, hi, (loops, batch_size))
         lg = max(0, self.n_rt - self.capacity) + inds
-        ls = lg + self._rlcore_wrap_shift()
         cap1 = self.capacity + self.stride
-        return np.stack([ls % cap1, lg % self.capacity, (ls + self.stride) % cap1])
-
-    def _rlcore_wrap_shift(self):
-        """0 unless `emulate_rlcore_wrap` is set.  RLCore's CircularArraySARTTrajectory keeps capacity + 1 frames of state /
-        action and `capacity` frames of reward / terminal, and pde_sample (src/PDEagent.jl:317-340) uses ONE index for all four
-        traces.  Index i of a buffer that has seen G pushes and holds len = min(G, its capacity) frames is logical row
-        G - len + i, so once the traces have wrapped, (s, a, s') come from rows (G_s - len_s) - (G_r - len_r) later than (r, t):
-        A - 1 rows at the PRE_ACT update (the A state rows of this step are pushed, its rewards are not) -- the state and action
-        of the NEXT control step of the neighbouring actuator.  The product keeps the four traces aligned (shift 0); the
-        host-sampling path can emulate the reference's buffer to study its effect on the learning curve (KS200's buffer wraps
-        at episode 37; its reference curve relapses from episode 39)."""
-        if not getattr(self, "emulate_rlcore_wrap", False):
-            return 0
-        cap = self.capacity
-        return (self.n_sa - min(self.n_sa, cap + 1)) - (self.n_rt - min(self.n_rt, cap))
+        return np.stack([lg % cap1, lg % self.capacity, (lg + self.stride) % cap1])
 
     def sample(self, rng, batch_size):
         """pde_sample / pde_fetch! (src/PDEagent.jl:317-340)"""
@@ -321,7 +311,6 @@ class CustomDDPGPolicy:
         dt = Cn.dtype
         s, a, r, t, sn = (batch[k].to(dt).contiguous() for k in ("state", "action", "reward", "terminal", "next_state"))
         Bu = s.shape[0]
-        scale = 1.0 if self.reducer is None else 1.0 / self.reducer.world_size
         L = self._losses
         oc, oa = self.behavior_critic.optimizer, self.behavior_actor.optimizer
         self._batch_keepalive = (s, a, r, t, sn)
@@ -341,26 +330,56 @@ class CustomDDPGPolicy:
                 A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), Bu, self.rho_effective, float(oa.eta),
                 C.c_void_p(L.data_ptr())))
             return
+        self.update_critic_half(batch)
+        if before_actor_half is not None:
+            before_actor_half()
+        self.actor_grads(batch)
+        self.reducer.all_reduce(A)
+        self.apply_actor()
+
+    # ---- the pieces of the data-parallel update (reducer active), callable one by one: pipeline.TrainPipeline issues them in
+    # another ORDER (the actor's ADAM step deferred behind the next critic half, its all-reduce on a side stream)
+    def _batch_arrays(self, batch):
+        dt = self.behavior_critic.model.dtype
+        arrs = tuple(batch[k].to(dt).contiguous() for k in ("state", "action", "reward", "terminal", "next_state"))
+        self._batch_keepalive = arrs
+        return arrs
+
+    def update_critic_half(self, batch):
+        """critic pass + ADAM(C) + Polyak(Ct) (src/PDEagent.jl:385-400, :415-417 for the critic pair): the local fused form when
+        only the policy gradient is exchanged, gradient pass -> all-reduce -> apply launch otherwise"""
+        A, Cn, At, Ct = (self.behavior_actor.model, self.behavior_critic.model, self.target_actor.model,
+                         self.target_critic.model)
+        s, a, r, t, sn = self._batch_arrays(batch)
+        Bu, L, oc = s.shape[0], self._losses, self.behavior_critic.optimizer
         if not self.reducer.reduce_critic:
             # policy-gradient-only exchange: the critic half is the local fused form (no all-reduce)
             _lib.check(self.lib.pdec_ddpg_update_critic_async(
                 A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a), _lib.ptr(r), _lib.ptr(t),
                 _lib.ptr(sn), Bu, float(self.y), self.rho_effective, int(self.quirk), float(oc.eta), C.c_void_p(L.data_ptr())))
-        else:
-            _lib.check(self.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a),
-                                                       _lib.ptr(r), _lib.ptr(t), _lib.ptr(sn), Bu, float(self.y),
-                                                       int(self.quirk), scale, C.c_void_p(L.data_ptr())))
-            self.reducer.all_reduce(Cn)
-            # update!(critic) :400 fused with the critic's Polyak step :415-417 (independent of the actor)
-            _lib.check(self.lib.pdec_adam_polyak_step(Cn.handle, Ct.handle, float(oc.eta), oc.beta[0], oc.beta[1],
-                                                      oc.epsilon, self.rho_effective))
-        if before_actor_half is not None:
-            before_actor_half()
-        _lib.check(self.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, _lib.ptr(s), Bu, scale,
+            return
+        _lib.check(self.lib.pdec_ddpg_critic_grads(A.handle, Cn.handle, At.handle, Ct.handle, _lib.ptr(s), _lib.ptr(a),
+                                                   _lib.ptr(r), _lib.ptr(t), _lib.ptr(sn), Bu, float(self.y),
+                                                   int(self.quirk), 1.0 / self.reducer.world_size, C.c_void_p(L.data_ptr())))
+        self.reducer.all_reduce(Cn)
+        # update!(critic) :400 fused with the critic's Polyak step :415-417 (independent of the actor)
+        _lib.check(self.lib.pdec_adam_polyak_step(Cn.handle, Ct.handle, float(oc.eta), oc.beta[0], oc.beta[1],
+                                                  oc.epsilon, self.rho_effective))
+
+    def actor_grads(self, batch):
+        """actor pass with the current critic + slab reduction: leaves this rank's share of the policy gradient (scaled by
+        1 / world_size) in the actor's flat gradient buffer (src/PDEagent.jl:402-409)"""
+        A, Cn = self.behavior_actor.model, self.behavior_critic.model
+        s = self._batch_arrays(batch)[0]
+        L = self._losses
+        _lib.check(self.lib.pdec_ddpg_actor_grads(A.handle, Cn.handle, _lib.ptr(s), s.shape[0], 1.0 / self.reducer.world_size,
                                                   C.c_void_p(L.data_ptr() + L.element_size())))
-        self.reducer.all_reduce(A)
+
+    def apply_actor(self):
+        """ADAM(A) + Polyak(At) from the (all-reduced) flat gradient buffer (:412, :415-417)"""
+        A, At, oa = self.behavior_actor.model, self.target_actor.model, self.behavior_actor.optimizer
         _lib.check(self.lib.pdec_adam_polyak_step(A.handle, At.handle, float(oa.eta), oa.beta[0], oa.beta[1],
-                                                  oa.epsilon, self.rho_effective))                  # :412, :415-417
+                                                  oa.epsilon, self.rho_effective))
 
     def small_update_ok(self):
         A, Cn = self.behavior_actor.model, self.behavior_critic.model
@@ -453,9 +472,7 @@ class Agent:
             return
         if p.update_step % p.update_freq != 0:                # :355
             return
-        # (the emulation of RLCore's wrapped, misaligned traces lives in the host-sampling path only: _rlcore_wrap_shift)
-        on_device = (p.sampling == "device" and getattr(tr, "_h", None) is not None
-                     and not getattr(tr, "emulate_rlcore_wrap", False))
+        on_device = p.sampling == "device" and getattr(tr, "_h", None) is not None
         if p.small_update_ok():
             # all update_loops minibatch updates in ONE launch; the slots of every loop (pde_sample,
             # src/PDEagent.jl:317-321) are drawn inside the kernel from the Philox stream, or here from the host rng
@@ -472,10 +489,34 @@ class Agent:
                 p.update(tr.sample(p.rng, p.batch_size))
 
 
+def resolve_target_networks(setup, requested=None, stacklevel=2):
+    """-> quirk_frozen_targets for an agent on `setup`: `requested` (True / False) if given, else the regime under which this path
+    reproduces the reference's saved runs of the setup's experiment family (setup.reproduces_reference_with).  A request for the
+    other regime is honoured with a TargetNetworkWarning that names the measured consequence (HISTORY.md 5.1)."""
+    import warnings
+    family = getattr(setup, "reproduces_reference_with", "frozen")
+    if requested is None:
+        return family == "frozen"
+    if bool(requested) != (family == "frozen"):
+        warnings.warn(f"{type(setup).__name__}: quirk_frozen_targets={bool(requested)} but the reference's saved runs of this experiment "
+                      f"family are reproduced only with {family} target networks (setup.reproduces_reference_with; HISTORY.md 5.1: "
+                      "Keller-Segel under frozen targets saturates at return -30 in 24 of 24 seeds, the fluid diverges in 4 of 6; "
+                      "KS22 / KS200 under moving targets stay a factor 3 off the reference curve)", TargetNetworkWarning,
+                      stacklevel=stacklevel)
+    return bool(requested)
+
+
 def create_agent(*, setup, B=1, rng=None, dtype=torch.float32, device="cuda:0", start_policy=None, mono=None,
                  max_update_cols=None, reducer=None, stream=None, **overrides):
-    """src/PDEagent.jl:58-119 with the setup's agent constants (KSSetup.jl:38-77)."""
+    """src/PDEagent.jl:58-119 with the setup's agent constants (KSSetup.jl:38-77).
+
+    Target networks: `quirk_frozen_targets` defaults PER SETUP to the regime under which this path reproduces the reference's
+    saved runs of that experiment family (`setup.reproduces_reference_with`: "frozen" for KSSetup -- the reference as its
+    committed source runs --, "moving" for the Keller-Segel and fluid setups, whose artifacts a later session of the authors
+    wrote; HISTORY.md 5.1).  Passing the other value explicitly is honoured and raises a TargetNetworkWarning that names the
+    measured consequence."""
     rng = rng or np.random.default_rng(0)
+    frozen = resolve_target_networks(setup, overrides.get("quirk_frozen_targets"), stacklevel=3)
     g = lambda k: overrides.get(k, getattr(setup, k))
     ns, cols_per_env = setup.state_shape
     mono = setup.mono if mono is None else mono
@@ -501,7 +542,7 @@ def create_agent(*, setup, B=1, rng=None, dtype=torch.float32, device="cuda:0", 
         act_limit=g("act_limit"), act_noise=g("act_noise"), memory_size=setup.memory_size,
         number_actuators=cols_per_env, reducer=reducer,
         quirk_target_broadcast=overrides.get("quirk_target_broadcast", True),
-        quirk_frozen_targets=overrides.get("quirk_frozen_targets", True),
+        quirk_frozen_targets=bool(frozen),
         noise_seed=overrides.get("noise_seed", 0))
     trajectory = CircularArraySARTTrajectory(g("trajectory_length") * B, ns, na, stride, torch.device(device))
     trajectory.bind(behavior_critic.model)         # stage kernels on the networks' stream (row F1)

@@ -124,10 +124,12 @@ int pdec_allreduce(pdec_handle comm, void* dptr, size_t n, int dtype, void* hip_
   return PDEC_OK;
 }
 
-int pdec_allreduce_grads(pdec_handle comm, pdec_handle mlp) {
+int pdec_allreduce_grads_on(pdec_handle comm, pdec_handle mlp, void* hip_stream) {
   Mlp* M = lookup_as<Mlp>(mlp, Kind::Mlp);
   if (!M) { set_error("pdec_allreduce_grads: not an mlp handle"); return PDEC_E_HANDLE; }
-  return pdec_allreduce(comm, M->grads.p, (size_t)M->nparams, M->dtype, (void*)M->stream);
+  return pdec_allreduce(comm, M->grads.p, (size_t)M->nparams, M->dtype, hip_stream ? hip_stream : (void*)M->stream);
 }
+
+int pdec_allreduce_grads(pdec_handle comm, pdec_handle mlp) { return pdec_allreduce_grads_on(comm, mlp, nullptr); }
 
 }  // extern "C"

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/pdeconv.h"
+#include "../../include/pdeconv_debug.h"   // (includes pdeconv.h)
 
 namespace pdec {
 

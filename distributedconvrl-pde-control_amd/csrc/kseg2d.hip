@@ -488,6 +488,7 @@ static int k2_sense(Kseg2dEnv& E, const void* y, const void* action, const void*
   return PDEC_OK;
 }
 
+#ifdef PDEC_DEBUG_PROBES
 // Timing probe for the time-resident design question (HISTORY.md round 5): the fp32 tile kernel on `nb` trajectories with
 // `reps` sub-steps per launch, `iters` launches between two events on the environment's stream -> microseconds per launch.
 static int k2_probe(Kseg2dEnv& E, int nb, int reps, int iters, double* us) {
@@ -518,6 +519,7 @@ static int k2_probe(Kseg2dEnv& E, int nb, int reps, int iters, double* us) {
   *us = (double)ms * 1e3 / iters;
   return PDEC_OK;
 }
+#endif
 
 #define K2_DISPATCH(fn, ...) (E.cfg.dtype == PDEC_F64 ? fn<double>(E, __VA_ARGS__) : fn<float>(E, __VA_ARGS__))
 
@@ -673,5 +675,11 @@ extern "C" int pdec_kseg2d_env_create(pdec_handle* h, const pdec_env_cfg* cfg, i
 extern "C" int pdec_debug_kseg2d_probe(pdec_handle h, int nb, int reps, int iters, double* us_per_launch) {
   Env* E = lookup_as<Env>(h, Kind::Env);
   PDEC_REQUIRE(E && E->cfg.pde_kind == PDEC_PDE_KSEG2D_RK4 && us_per_launch, "pdec_debug_kseg2d_probe: a 2-D Keller-Segel environment handle");
+#ifdef PDEC_DEBUG_PROBES
   return k2_probe(as_k2(*E), nb, reps, iters, us_per_launch);
+#else
+  (void)nb; (void)reps; (void)iters;
+  set_error("pdec_debug_kseg2d_probe: this library was built without -DPDEC_DEBUG_PROBES (include/pdeconv_debug.h)");
+  return PDEC_E_INVALID;
+#endif
 }

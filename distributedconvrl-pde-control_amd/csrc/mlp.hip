@@ -692,6 +692,8 @@ int pdec_polyak(pdec_handle dst, pdec_handle src, double rho) {
   PDEC_REQUIRE(D->dims == S->dims && D->dtype == S->dtype, "pdec_polyak: shape/dtype mismatch");
   // rho == 1: dest = 1 * dest + 0 * src -- the reference as it runs (its loop body never executes, include/pdeconv.h at this
   // entry point): the target is left untouched, also where src holds an Inf / NaN that 0 * src would turn into NaN
+  // (compared as Float32 for fp64 networks too: the kernels below receive r = (float)rho -- the reference holds p = 0.995f0 --, so a
+  // rho that rounds to 1.0f IS the frozen case in their arithmetic: (double)r = 1, (double)(1.0f - r) = 0)
   if ((float)rho == 1.0f) return PDEC_OK;
   const int n = D->nparams;
   dim3 grid(cdiv(n, 256)), block(256);
@@ -817,13 +819,20 @@ int pdec_ddpg_critic_grads(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec
   PDEC_REQUIRE(s && a && r && t && snext && Bu >= 1, "pdec_ddpg_critic_grads: null/empty batch");
   PDEC_REQUIRE(A->dtype == C->dtype && At->dtype == C->dtype && Ct->dtype == C->dtype, "ddpg: dtype mismatch");
   PDEC_REQUIRE(At->dims == A->dims && Ct->dims == C->dims, "ddpg: target networks must have the behaviour networks' shapes");
+  int rc;
   if (fused_supported(A, C) && A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream)
-    return fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev, nullptr);
-  if (fused2_supported(A, C) && A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream)
-    return fused2_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev, nullptr);
-  return C->dtype == PDEC_F64
+    rc = fused_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev, nullptr);
+  else if (fused2_supported(A, C) && A->stream == C->stream && At->stream == C->stream && Ct->stream == C->stream)
+    rc = fused2_critic_grads(A, C, At, Ct, s, a, r, t, snext, Bu, (double)(float)gamma, quirk, grad_scale, critic_loss_dev, nullptr);
+  else
+    rc = C->dtype == PDEC_F64
              ? critic_grads_t<double>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev)
              : critic_grads_t<float>(A, C, At, Ct, s, a, r, t, snext, Bu, gamma, quirk, grad_scale, critic_loss_dev);
+  if (rc == PDEC_OK && C->reduce_event) {     // see pdec_ddpg_actor_grads
+    PDEC_HIP(hipEventRecord(C->reduce_event, C->stream));
+    C->reduce_event = nullptr;
+  }
+  return rc;
 }
 
 int pdec_ddpg_actor_grads(pdec_handle hA, pdec_handle hC, const void* s, int Bu, double grad_scale, void* actor_loss_dev) {
@@ -831,10 +840,17 @@ int pdec_ddpg_actor_grads(pdec_handle hA, pdec_handle hC, const void* s, int Bu,
   GET_MLP(C, hC);
   PDEC_REQUIRE(s && Bu >= 1, "pdec_ddpg_actor_grads: null/empty batch");
   PDEC_REQUIRE(A->dtype == C->dtype, "ddpg: dtype mismatch");
-  if (fused_supported(A, C) && A->stream == C->stream) return fused_actor_grads(A, C, nullptr, s, Bu, grad_scale, actor_loss_dev, nullptr);
-  if (fused2_supported(A, C) && A->stream == C->stream) return fused2_actor_grads(A, C, nullptr, s, Bu, grad_scale, actor_loss_dev, nullptr);
-  return C->dtype == PDEC_F64 ? actor_grads_t<double>(A, C, s, Bu, grad_scale, actor_loss_dev)
-                              : actor_grads_t<float>(A, C, s, Bu, grad_scale, actor_loss_dev);
+  int rc;
+  if (fused_supported(A, C) && A->stream == C->stream) rc = fused_actor_grads(A, C, nullptr, s, Bu, grad_scale, actor_loss_dev, nullptr);
+  else if (fused2_supported(A, C) && A->stream == C->stream) rc = fused2_actor_grads(A, C, nullptr, s, Bu, grad_scale, actor_loss_dev, nullptr);
+  else rc = C->dtype == PDEC_F64 ? actor_grads_t<double>(A, C, s, Bu, grad_scale, actor_loss_dev)
+                                 : actor_grads_t<float>(A, C, s, Bu, grad_scale, actor_loss_dev);
+  // a reduce event (pdec_mlp_set_reduce_event) that the path taken did not put on its reduction launch: recorded behind it
+  if (rc == PDEC_OK && A->reduce_event) {
+    PDEC_HIP(hipEventRecord(A->reduce_event, A->stream));
+    A->reduce_event = nullptr;
+  }
+  return rc;
 }
 
 int pdec_ddpg_update(pdec_handle hA, pdec_handle hC, pdec_handle hAt, pdec_handle hCt, const void* s, const void* a,

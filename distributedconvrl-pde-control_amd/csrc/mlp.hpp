@@ -20,6 +20,7 @@ struct Mlp : Object {
   int bp_sel = 0;
   bool bp_init = false;
   hipEvent_t stop_event = nullptr;   // one-shot (pdec_mlp_set_stop_event): attached to the next reduction / update launch on this net
+  hipEvent_t reduce_event = nullptr; // one-shot (pdec_mlp_set_reduce_event): attached to the next reduce-ONLY launch (flat gradient ready)
   const float* rpart_ext = nullptr;  // per-workgroup reward sums of the producer (pdec_ddpg_set_reward_partials), consumed likewise
   int rpart_n = 0;
   const void* rbar_ext = nullptr;    // batch-mean reward reduced elsewhere (pdec_ddpg_set_reward_mean), consumed by the next critic pass

@@ -1162,24 +1162,28 @@ static int launch_finish(Mlp* M, Mlp* Mt, const float* slabs, int nslab, int MT,
   {
     const char* label = ap ? (nslab > 0 ? "fused_finish" : "fused_apply") : "fused_reduce";
     const bool use_ref = getenv("PDEC_FINISH_REF") != nullptr;            // tests only: the round-2 kernel (bit-identity reference)
+    // the one-shot completion event of this launch: the apply launch carries the stop event (parameters updated), a reduce-only
+    // launch the reduce event (flat gradient ready: what an all-reduce on another stream waits for)
+    hipEvent_t& slot = ap ? M->stop_event : M->reduce_event;
+    const hipEvent_t ev = slot;
     if (use_ref) {
       const int nblk = nslab > 0 ? 4 * slab_tiles(MT) : (n + 63) / 64;
       hipLaunchKernelGGL(fused_finish_ref_kernel, dim3(nblk), dim3(1024), 0, M->stream, g);
-      if (M->stop_event && ap) (void)hipEventRecord(M->stop_event, M->stream);
+      if (ev) (void)hipEventRecord(ev, M->stream);
     } else {
       const int nblk = nslab > 0 ? 8 * slab_tiles(MT) : (n + FIN_THREADS - 1) / FIN_THREADS;
       if (M->prof) {
         PDEC_TIMED_LAUNCH(M, label, fused_finish_kernel, dim3(nblk), dim3(FIN_THREADS), 0, g);
-        if (M->stop_event && ap) (void)hipEventRecord(M->stop_event, M->stream);
-      } else if (M->stop_event && ap) {
+        if (ev) (void)hipEventRecord(ev, M->stream);
+      } else if (ev) {
         // the event rides on this kernel's own dispatch packet (its completion signal): a hipEventRecord behind the
         // launch is a packet of its own that the next kernel of the stream has to wait for (~4.5 us of the update chain)
-        hipExtLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(FIN_THREADS), 0, M->stream, nullptr, M->stop_event, 0, g);
+        hipExtLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(FIN_THREADS), 0, M->stream, nullptr, ev, 0, g);
       } else {
         hipLaunchKernelGGL(fused_finish_kernel, dim3(nblk), dim3(FIN_THREADS), 0, M->stream, g);
       }
     }
-    if (ap) M->stop_event = nullptr;     // consumed by the launch that applies the update (not by a reduce-only one)
+    slot = nullptr;     // consumed (the stop event only by a launch that applies the update, the reduce event only by a reduce-only one)
   }
   PDEC_HIP(hipGetLastError());
   if (ap) {

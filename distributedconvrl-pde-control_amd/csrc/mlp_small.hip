@@ -284,8 +284,13 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g_in) 
     sm_adam_polyak(g.A, g.eta_a, g.b1, g.b2, g.eps, 1.0 - bpa0, 1.0 - bpa1, g.rho, omr, tid);
     bpa0 *= g.b1;
     bpa1 *= g.b2;
-    sm_polyak(g.A, g.rho, omr, tid);                                               // :415-417
-    sm_polyak(g.C, g.rho, omr, tid);
+    // rho == 1 (the reference as it runs: its Polyak loop iterates over an empty list, agent.py quirk_frozen_targets): the
+    // targets are not touched at all, as in launch_finish / pdec_polyak -- dest = 1 * dest + 0 * src would rewrite them and
+    // turn a non-finite behaviour parameter into a NaN target
+    if (g.rho != 1.0f) {
+      sm_polyak(g.A, g.rho, omr, tid);                                             // :415-417
+      sm_polyak(g.C, g.rho, omr, tid);
+    }
   }
   if (tid == 0 && g.losses) {
     g.losses[0] = red[0];
@@ -375,14 +380,14 @@ __device__ __forceinline__ void s2_reduce2(float (&v)[N], int n, float* buf, int
 // (i1, i2) and multiplied in: m * (1/c) instead of m / c differs from Flux's quotient by at most one fp64 ulp, far below
 // the fp32 rounding of the stored step; it removes two of the three fp64 divisions per parameter.
 __device__ __forceinline__ void s2_adam(float& p, float& m, float& v, float& pt, float gi, double eta, double b1, double b2,
-                                        double eps, double i1, double i2, float rho, float omr) {
+                                        double eps, double i1, double i2, float rho, float omr, bool frozen) {
 #pragma clang fp contract(off)
   const double gd = (double)gi;
   m = (float)(b1 * (double)m + (1.0 - b1) * gd);
   v = (float)(b2 * (double)v + (1.0 - b2) * gd * gd);
   const float delta = (float)((double)m * i1 / (sqrt((double)v * i2) + eps) * eta);
   p = p - delta;
-  pt = rho * pt + omr * p;
+  if (!frozen) pt = rho * pt + omr * p;      // frozen (rho == 1, uniform per launch): the target keeps its bits (see ddpg_small_kernel)
 }
 
 // EXACT: ns == KA and Bu == BUT are compile-time constants (the shipped experiments: (1,3) KS, (12,3) Keller-Segel,
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   }
   double bpa0 = g.bpA.cur[0], bpa1 = g.bpA.cur[1], bpc0 = g.bpC.cur[0], bpc1 = g.bpC.cur[1];
   const float omr = 1.0f - g.rho, invB = 1.f / (float)Bu;
+  const bool frz = g.rho == 1.0f;
   float closs = 0.f, aloss = 0.f;
   for (int it = 0; it < g.loops; ++it) {
     const float* bsn = batch + it * bstride;
@@ -550,11 +556,11 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       if (isC) {
 #pragma unroll
         for (int k = 0; k < KC; ++k)
-          if (k < K0) s2_adam(cw1[k], cw1m[k], cw1v[k], cw1t[k], gw1[k], g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
-        s2_adam(cb1, cb1m, cb1v, cb1t, gb1, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
-        s2_adam(cw2, cw2m, cw2v, cw2t, gw2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+          if (k < K0) s2_adam(cw1[k], cw1m[k], cw1v[k], cw1t[k], gw1[k], g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
+        s2_adam(cb1, cb1m, cb1v, cb1t, gb1, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
+        s2_adam(cw2, cw2m, cw2v, cw2t, gw2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
       }
-      s2_adam(cb2, cb2m, cb2v, cb2t, gb2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+      s2_adam(cb2, cb2m, cb2v, cb2t, gb2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
       bpc0 *= g.b1;
       bpc1 *= g.b2;
     }
@@ -600,11 +606,11 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       if (isA) {
 #pragma unroll
         for (int k = 0; k < KA; ++k)
-          if (k < ns) s2_adam(aw1[k], aw1m[k], aw1v[k], aw1t[k], gw1[k], g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
-        s2_adam(ab1, ab1m, ab1v, ab1t, gb1, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
-        s2_adam(aw2, aw2m, aw2v, aw2t, gw2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+          if (k < ns) s2_adam(aw1[k], aw1m[k], aw1v[k], aw1t[k], gw1[k], g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
+        s2_adam(ab1, ab1m, ab1v, ab1t, gb1, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
+        s2_adam(aw2, aw2m, aw2v, aw2t, gw2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
       }
-      s2_adam(ab2, ab2m, ab2v, ab2t, gb2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr);
+      s2_adam(ab2, ab2m, ab2v, ab2t, gb2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
       bpa0 *= g.b1;
       bpa1 *= g.b2;
     }
@@ -614,23 +620,31 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
 #pragma unroll
     for (int k = 0; k < KC; ++k)
       if (k < K0) {
-        g.C.p[tid * K0 + k] = cw1[k]; g.C.m[tid * K0 + k] = cw1m[k]; g.C.v[tid * K0 + k] = cw1v[k]; g.C.pt[tid * K0 + k] = cw1t[k];
+        g.C.p[tid * K0 + k] = cw1[k]; g.C.m[tid * K0 + k] = cw1m[k]; g.C.v[tid * K0 + k] = cw1v[k];
+        if (!frz) g.C.pt[tid * K0 + k] = cw1t[k];
       }
-    g.C.p[cob1 + tid] = cb1; g.C.m[cob1 + tid] = cb1m; g.C.v[cob1 + tid] = cb1v; g.C.pt[cob1 + tid] = cb1t;
-    g.C.p[cow2 + tid] = cw2; g.C.m[cow2 + tid] = cw2m; g.C.v[cow2 + tid] = cw2v; g.C.pt[cow2 + tid] = cw2t;
+    g.C.p[cob1 + tid] = cb1; g.C.m[cob1 + tid] = cb1m; g.C.v[cob1 + tid] = cb1v;
+    if (!frz) g.C.pt[cob1 + tid] = cb1t;
+    g.C.p[cow2 + tid] = cw2; g.C.m[cow2 + tid] = cw2m; g.C.v[cow2 + tid] = cw2v;
+    if (!frz) g.C.pt[cow2 + tid] = cw2t;
   }
   if (isA) {
 #pragma unroll
     for (int k = 0; k < KA; ++k)
       if (k < ns) {
-        g.A.p[tid * ns + k] = aw1[k]; g.A.m[tid * ns + k] = aw1m[k]; g.A.v[tid * ns + k] = aw1v[k]; g.A.pt[tid * ns + k] = aw1t[k];
+        g.A.p[tid * ns + k] = aw1[k]; g.A.m[tid * ns + k] = aw1m[k]; g.A.v[tid * ns + k] = aw1v[k];
+        if (!frz) g.A.pt[tid * ns + k] = aw1t[k];
       }
-    g.A.p[aob1 + tid] = ab1; g.A.m[aob1 + tid] = ab1m; g.A.v[aob1 + tid] = ab1v; g.A.pt[aob1 + tid] = ab1t;
-    g.A.p[aow2 + tid] = aw2; g.A.m[aow2 + tid] = aw2m; g.A.v[aow2 + tid] = aw2v; g.A.pt[aow2 + tid] = aw2t;
+    g.A.p[aob1 + tid] = ab1; g.A.m[aob1 + tid] = ab1m; g.A.v[aob1 + tid] = ab1v;
+    if (!frz) g.A.pt[aob1 + tid] = ab1t;
+    g.A.p[aow2 + tid] = aw2; g.A.m[aow2 + tid] = aw2m; g.A.v[aow2 + tid] = aw2v;
+    if (!frz) g.A.pt[aow2 + tid] = aw2t;
   }
   if (tid == 0) {
-    g.C.p[cob2] = cb2; g.C.m[cob2] = cb2m; g.C.v[cob2] = cb2v; g.C.pt[cob2] = cb2t;
-    g.A.p[aob2] = ab2; g.A.m[aob2] = ab2m; g.A.v[aob2] = ab2v; g.A.pt[aob2] = ab2t;
+    g.C.p[cob2] = cb2; g.C.m[cob2] = cb2m; g.C.v[cob2] = cb2v;
+    if (!frz) g.C.pt[cob2] = cb2t;
+    g.A.p[aob2] = ab2; g.A.m[aob2] = ab2m; g.A.v[aob2] = ab2v;
+    if (!frz) g.A.pt[aob2] = ab2t;
     if (g.losses) { g.losses[0] = closs; g.losses[1] = aloss; }
     g.bpA.next[0] = bpa0; g.bpA.next[1] = bpa1;
     g.bpC.next[0] = bpc0; g.bpC.next[1] = bpc1;

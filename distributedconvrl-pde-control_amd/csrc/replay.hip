@@ -393,6 +393,18 @@ int pdec_mlp_set_stop_event(pdec_handle mlp, pdec_handle event) {
   return PDEC_OK;
 }
 
+// The same for the next reduce-ONLY launch (flat gradient complete): what an all-reduce on another stream waits for.
+int pdec_mlp_set_reduce_event(pdec_handle mlp, pdec_handle event) {
+  Mlp* M = lookup_as<Mlp>(mlp, Kind::Mlp);
+  if (!M) { set_error("pdec_mlp_set_reduce_event: bad handle"); return PDEC_E_HANDLE; }
+  if (!event) { M->reduce_event = nullptr; return PDEC_OK; }
+  Event* e = lookup_as<Event>(event, Kind::Event);
+  if (!e) { set_error("pdec_mlp_set_reduce_event: bad event handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(fused_net_supported(M), "pdec_mlp_set_reduce_event: fused 3-layer networks only");
+  M->reduce_event = e->ev;
+  return PDEC_OK;
+}
+
 // An event set by pdec_mlp_set_stop_event that no launch has consumed (the update took another path) is recorded on the
 // net's stream now, so a waiter never sees a stale event; no-op otherwise.
 int pdec_mlp_flush_stop_event(pdec_handle mlp) {

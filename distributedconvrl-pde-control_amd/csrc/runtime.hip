@@ -62,6 +62,18 @@ int upload_converted(DevBuf& dst, const double* src, size_t n, int dtype) {
   return PDEC_OK;
 }
 
+// pdec_debug_spin_us (include/pdeconv_debug.h): one wave waits on the constant-rate 100 MHz counter; both exits are certain
+// (the counter advances whatever the shader clock does, and the iteration cap ends the loop regardless)
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks, long long max_iter, unsigned long long* sink) {
+  const long long t0 = (long long)wall_clock64();
+  long long i = 0;
+  for (; i < max_iter; ++i) {
+    if ((long long)wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  if (sink && threadIdx.x == 0) *sink = (unsigned long long)i;
+}
+
 }  // namespace pdec
 
 using namespace pdec;
@@ -71,6 +83,17 @@ extern "C" {
 const char* pdec_last_error(void) { return g_err; }
 
 int pdec_version(void) { return 100; }
+
+int pdec_debug_spin_us(void* hip_stream, double us) {
+  PDEC_REQUIRE(us >= 0.0 && us <= 10000.0, "pdec_debug_spin_us: 0 <= us <= 10000");
+  if (us == 0.0) return PDEC_OK;
+  const long long ticks = (long long)(us * 100.0 + 0.5);           // 100 MHz
+  // one iteration (counter read + s_sleep 4 = 256 clocks) lasts >= 0.1 us at any shader clock: 64 iterations per tick is
+  // ~600x more than the wait needs and still ends a stalled-counter launch within seconds
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, ticks, ticks * 64 + 1024, (unsigned long long*)nullptr);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
 
 int pdec_device_count(int* n) {
   PDEC_REQUIRE(n, "pdec_device_count: null");

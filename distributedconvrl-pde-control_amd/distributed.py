@@ -52,12 +52,14 @@ class GradReducer:
 
     native = False        # torch.distributed issues the collective (host path of the process group)
 
-    def all_reduce(self, model):
+    def all_reduce(self, model, stream=None):
+        """stream: the stream the collective is enqueued on (default: the network's own -- between the launch that leaves the
+        gradient and the ADAM launch; pipeline.TrainPipeline passes a side stream and orders it with events)"""
         if self.world_size == 1:
             return
         # through _Lib.note: a recorded control step (pipeline._eager) keeps the collective at its place between the
         # gradient launch and the ADAM launch and re-issues it on replay
-        model.lib.note(self._reduce, self._view(model), model.stream)
+        model.lib.note(self._reduce, self._view(model), stream if stream is not None else model.stream)
 
     def _reduce(self, g, stream):
         if stream is not None:
@@ -155,11 +157,15 @@ class NativeGradReducer:
     def active(self):
         return self.world_size > 1 or self.force_split
 
-    def all_reduce(self, model):
+    def all_reduce(self, model, stream=None):
         if not self.active:
             return
+        import ctypes as C
         from . import _lib
-        _lib.check(self.lib.pdec_allreduce_grads(self.comm, model.handle))
+        if stream is None:
+            _lib.check(self.lib.pdec_allreduce_grads(self.comm, model.handle))
+        else:
+            _lib.check(self.lib.pdec_allreduce_grads_on(self.comm, model.handle, C.c_void_p(stream.cuda_stream)))
 
     def verify_against_torch(self, device, n=20441, timeout_s=30.0, group=None):
         """one all-reduce of a KNOWN buffer through this communicator and one through torch.distributed, before anything is

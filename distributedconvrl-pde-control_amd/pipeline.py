@@ -12,6 +12,17 @@ back to back behind update_{k-1} beside act_k / env_k; act_{k+1} follows update_
 `update!` in the run loop.  (update_k must follow act_{k-1}, the last reader of the image its actor half republishes;
 env_{k-LAG}, its batch, precedes act_{k-1} on the env stream.)
 
+Data-parallel runs (N > 1, policy-gradient-only exchange, frozen target networks): the all-reduce of the actor's gradient and
+the ADAM launch that consumes it leave the update stream (`stream_ar`):
+
+    update stream:  critic half_k -> [wait apply_{k-1}] actor pass_k -> slab reduction_k ---------> critic half_{k+1} -> ...
+    side stream:                                                        wait reduction_k -> all-reduce_k -> ADAM(actor)_k
+
+The critic half reads the TARGET actor only (a' = At(s'), src/PDEagent.jl:385), which never moves (quirk_frozen_targets), so
+critic half_{k+1} does not depend on ADAM(actor)_k and hides the collective; the next readers of the updated actor -- act_{k+1} on
+the env stream and actor pass_{k+1} -- wait for the event on the ADAM launch.  Same kernels, same arguments, same order of
+arithmetic as the in-chain order: bit-identical (tests/test_gpu_pipeline.py, tests/test_aa_multirank_gpu.py).
+
 Every buffer a step touches is a pure function of the step counter k (rings indexed by k mod 2 / 3 / 6) and every
 per-step scalar lives on the device (noise counter: pdec_policy_act_rng_dev; ADAM beta powers), so the launch arguments
 of step k + 6 are those of step k: chunks of 24 / 6 / 1 consecutive steps starting at each of the six ring phases are
@@ -66,13 +77,17 @@ class _TorchEvent:
 
 class TrainPipeline:
     def __init__(self, env, agent, lag=2, episode_steps=51, stream_env=None, stream_upd=None, use_graphs=True,
-                 chunks=(24, 6, 1), use_replay=False, noise_seed=1234, kick_env_after_critic=None):
+                 chunks=(24, 6, 1), use_replay=False, noise_seed=1234, kick_env_after_critic=None, stream_ar=None,
+                 ar_off_chain=None):
         """env: PDEenv on `stream_env`; agent: create_agent(..., stream=stream_upd).  lag: the update of step k trains on
         the transition of step k - lag (>= 1).  episode_steps: lock-stepped episodes of that many control steps (0: one
         endless episode): the last transition is terminal (done = time >= te, src/PDEenv.jl:227) and the next step starts
         from env.y0 (reset!, :183-193).  use_replay: route the update through the device-resident replay (row F1): every
         transition is pushed (src/PDEagent.jl:254-289) and the update trains on B * A transitions drawn from it
-        (:317-340) instead of the B * A fresh ones (eager only)."""
+        (:317-340) instead of the B * A fresh ones (eager only).  stream_ar: a third stream for the gradient all-reduce + the
+        actor's ADAM launch of a data-parallel run (module docstring); ar_off_chain: None = whenever that order is legal
+        (split update, policy-gradient-only exchange, frozen targets, stream_ar given), False = keep the collective on the update
+        stream, True = insist (raises when illegal)."""
         self.env, self.agent, self.policy = env, agent, agent.policy
         self.lib = env.lib
         self.LAG = max(1, int(lag))
@@ -86,6 +101,16 @@ class TrainPipeline:
         self.use_replay = bool(use_replay)
         reducer = self.policy.reducer
         self.multi_rank = reducer is not None and reducer.active      # the split update sequence (N > 1, or forced)
+        # the all-reduce + ADAM(actor) beside the next critic half instead of in front of it: legal when that critic half cannot
+        # see the actor's update -- it reads the target actor, so the targets must be frozen -- and the critic is not exchanged
+        self._ar_legal = (self.multi_rank and not reducer.reduce_critic and bool(self.policy.quirk_frozen_targets)
+                          and stream_ar is not None and stream_ar.cuda_stream not in (self.s_upd.cuda_stream, self.s_env.cuda_stream))
+        if ar_off_chain and not self._ar_legal:
+            raise _lib.PdecError("TrainPipeline(ar_off_chain=True) needs an active reducer with reduce_critic=False, frozen target "
+                                 "networks (quirk_frozen_targets) and a stream_ar that is neither the env nor the update stream")
+        self._stream_ar = stream_ar
+        self.ar_off_chain = self._ar_legal if ar_off_chain is None else bool(ar_off_chain)
+        self.s_ar = stream_ar if self.ar_off_chain else None
         # a recorded step / a graph holds POINTERS: policy.update must hand the ring tensors through unchanged, which it
         # does only when no dtype conversion makes a temporary (`.to(dt).contiguous()` is the identity then)
         self._batch_aliases = env.dtype == self.policy.behavior_critic.model.dtype
@@ -136,6 +161,11 @@ class TrainPipeline:
         self.ev_mid = Ev(self.lib)                                  # critic half of update_k done (update stream)
         self.ev_push = [Ev(self.lib), Ev(self.lib)]                 # replay pushes of step k done (env stream)
         self.ev_samp = Ev(self.lib)                                 # replay sample of update_k done (update stream)
+        self.ev_red = Ev(self.lib)                                  # actor gradient of update_k reduced (update stream) -> side stream
+        self.ev_env = [Ev(self.lib), Ev(self.lib)]                  # env_k done (env stream; collective off the chain only)
+        # collective off the chain, two streams, LAG >= 2: both cross-stream waits of the update stream sit between the halves
+        # of an update (between_halves) instead of one there and one at the top of the step
+        self._mid_waits = self.ar_off_chain and not self.serial and self.LAG >= 2 and not self.use_replay
         self._samp_pending = False
         self._after_graph = False
         self.tick = 0             # control steps issued so far: every buffer of step k is indexed by k mod 2 / 3 / 6
@@ -171,6 +201,7 @@ class TrainPipeline:
             _lib.check(self.lib.pdec_env_set_simd_sharing(env.handle, 1, C.byref(eff)))
             self.simd_sharing = bool(eff.value)
         self._sp_env, self._sp_upd = C.c_void_p(self.s_env.cuda_stream), C.c_void_p(self.s_upd.cuda_stream)
+        self._sp_ar = C.c_void_p(self.s_ar.cuda_stream) if self.s_ar is not None else None
         self.graphs = {}          # (chunk, pos) -> graph handle
         self._progs = {}          # ring phase -> recorded library calls of an interior eager step
         # the recorded-call replay re-issues LIBRARY calls only: with torch events (PDEC_TORCH_EVENTS=1) the cross-stream
@@ -185,6 +216,21 @@ class TrainPipeline:
         self._captured = False
         self.n_graph_launches = self.n_eager_steps = 0
         self.reset_from(env.y0)
+
+    def set_ar_order(self, off_chain):
+        """switch between the two places of the gradient all-reduce (module docstring) in a running pipeline: drains the
+        streams, drops the recorded steps.  Both orders compute the same numbers; a caller times both and keeps the faster
+        (bench.py: a collective of a few microseconds is cheaper left on the chain than two stream hops are)."""
+        off_chain = bool(off_chain)
+        if off_chain and not self._ar_legal:
+            raise _lib.PdecError("set_ar_order(True): not legal for this pipeline (see TrainPipeline(ar_off_chain=...))")
+        self.sync()
+        self.ar_off_chain = off_chain
+        self.s_ar = self._stream_ar if off_chain else None
+        self._sp_ar = C.c_void_p(self.s_ar.cuda_stream) if self.s_ar is not None else None
+        self._mid_waits = self.ar_off_chain and not self.serial and self.LAG >= 2 and not self.use_replay
+        self._mid_wait_prev = False
+        self._progs = {}
 
     # ------------------------------------------------------------------ state
     def reset_from(self, y0):
@@ -230,6 +276,7 @@ class TrainPipeline:
         act, act_prev = self.aring[k % 3], self.aring[(k - 1) % 3]
         rew, flags, term = self.rring[k % 3], self.fring[k % 3], self.tring[k % 3]
         capturing = chunk_first or chunk_last or self._capturing
+        mid_wait_prev, self._mid_wait_prev = self._mid_wait_prev, False
         if not self.serial:
             if chunk_first:                       # fork: everything before this chunk is ordered before it on the env stream
                 self.ev_fork.record(self.s_env)
@@ -242,22 +289,37 @@ class TrainPipeline:
                     self.ev_graph.wait(self.s_upd)
                     self._after_graph = False
                 elif k > 0:
-                    self.ev_act[(k - 1) % 2].wait(self.s_upd)
+                    # (collective off the chain: update_{k-1} waited for env_{k-2} between its halves, see between_halves)
+                    if not mid_wait_prev:
+                        self.ev_act[(k - 1) % 2].wait(self.s_upd)
                     self.ev_upd[(k - 1) % 2].wait(self.s_env)
-        with torch.cuda.stream(self.s_env):
-            if first:                                  # reset!(env): this step starts from the initial condition
-                y_in.copy_(env.y0)
-                s_in.copy_(self.state0)
-                act_prev = self.azero
-            # actor forward on all B*A columns + exploration noise (Philox, counter on the device) + clamp: one launch
-            L.check(lib.pdec_set_stream(self.actor.handle, self._sp_env))
-            L.check(lib.pdec_policy_act_rng_dev(self.actor.handle, L.ptr(s_in), self.cols, float(pol.act_noise),
-                                                float(pol.act_limit), 1, self.noise_seed, L.ptr(act)))
-            L.check(lib.pdec_set_stream(self.actor.handle, self._sp_upd))
-            if not self.serial and self.LAG >= 2:
-                self.ev_act[k % 2].record(self.s_env)
-        if self.drain_between:
-            torch.cuda.synchronize()
+
+        def act_part():
+            nonlocal act_prev
+            if self.serial and self.ar_off_chain and k > 0:
+                self.ev_upd[(k - 1) % 2].wait(self.s_env)      # ADAM(actor)_{k-1} ran on the side stream
+            with torch.cuda.stream(self.s_env):
+                if first:                                  # reset!(env): this step starts from the initial condition
+                    y_in.copy_(env.y0)
+                    s_in.copy_(self.state0)
+                    act_prev = self.azero
+                # actor forward on all B*A columns + exploration noise (Philox, counter on the device) + clamp: one launch
+                L.check(lib.pdec_set_stream(self.actor.handle, self._sp_env))
+                L.check(lib.pdec_policy_act_rng_dev(self.actor.handle, L.ptr(s_in), self.cols, float(pol.act_noise),
+                                                    float(pol.act_limit), 1, self.noise_seed, L.ptr(act)))
+                L.check(lib.pdec_set_stream(self.actor.handle, self._sp_upd))
+                if not self.serial and self.LAG >= 2:
+                    self.ev_act[k % 2].record(self.s_env)
+            if self.drain_between:
+                torch.cuda.synchronize()
+
+        j = k - self.LAG
+        # one stream + the collective off the chain: act_k needs ADAM(actor)_{k-1}, which waits for the all-reduce on the side
+        # stream -- so the critic half of update_k, which needs neither, goes first and hides it (two streams: the critic half is
+        # on the other stream anyway)
+        late_env = self.serial and self.ar_off_chain and j >= self._first_tick and not self.use_replay
+        if not late_env:
+            act_part()
 
         def env_part():
             with torch.cuda.stream(self.s_env):
@@ -277,10 +339,11 @@ class TrainPipeline:
                     # LAG = 1: update_{k+1} trains on the transition env_k is producing, so the event it waits on is
                     # recorded behind the whole env branch, not behind the acting kernel
                     self.ev_act[k % 2].record(self.s_env)
+                if self._mid_waits:
+                    self.ev_env[k % 2].record(self.s_env)
             if self.drain_between:                     # kernel-timing pass: nothing of the env branch overlaps the update
                 torch.cuda.synchronize()
 
-        j = k - self.LAG
         batch = None
         if j >= self._first_tick:
             if self.use_replay:
@@ -293,10 +356,13 @@ class TrainPipeline:
                              next_state=self.sring[(j + 1) % PERIOD].view(self.cols, self.ns))
         # (inside a captured chunk the extra fork / join edge of the kick costs more than it gives: 202 vs 148 us per step)
         kick = self.kick_env_after_critic and batch is not None and not self.serial and not capturing
-        if not kick:
+        if not kick and not late_env:
             env_part()
 
         def between_halves():
+            if late_env:
+                act_part()
+                env_part()
             # Beside the critic pass the PDE step makes almost no progress and then collides with the whole actor pass;
             # released when the critic half (pass + reduction) is done it runs beside the actor pass, the second
             # reduction and the head of the next critic pass instead (r02i, same box: 152 -> 130 us per control step)
@@ -309,6 +375,19 @@ class TrainPipeline:
                 env_part()
             if self.act_in_place and not self.serial:
                 self.ev_act[k % 2].wait(self.s_upd)
+            if self.ar_off_chain and k > 0:
+                # the actor pass reads the actor that ADAM(actor)_{k-1} on the side stream has written (done long ago: it ran
+                # beside the critic half that has just ended) ...
+                self.ev_upd[(k - 1) % 2].wait(self.s_upd)
+                if self._mid_waits:
+                    # ... and the wait for the batch of update_{k+1} -- env_{k-1}, done since the middle of this critic pass --
+                    # sits here too, instead of at the top of step k + 1.  Why: every cross-stream wait is a barrier packet of
+                    # 5 - 7 us on the update chain even when it is satisfied (measured: the step with either wait removed),
+                    # two adjacent ones cost less than two apart (116.5 - 117.7 against 118 - 119 us per step), a single
+                    # wait on act_k's event (which implies both) or on a join event made on the side stream stalls on events
+                    # that complete just before they are needed (123 / 125 us) -- HISTORY.md 6.1
+                    self.ev_env[(k - 1) % 2].wait(self.s_upd)
+                    self._mid_wait_prev = True
 
         # eager steps on the fused 3-layer path: the two events the env stream waits for ride on the reduction launches' own
         # dispatch packets (pdec_mlp_set_stop_event) instead of being recorded as packets behind them
@@ -323,19 +402,52 @@ class TrainPipeline:
                     L.check(lib.pdec_ddpg_set_reward_partials(pol.behavior_critic.model.handle, L.ptr(self.rpart[j % 3]), self.n_rpart))
                 elif self.pre_rbar:
                     L.check(lib.pdec_ddpg_set_reward_mean(pol.behavior_critic.model.handle, L.ptr(self.rbar[j % 3])))
-                if kick or (self.act_in_place and not self.serial):
+                if self.ar_off_chain:
+                    self._update_ar_off_chain(k, batch, between_halves, use_stop)
+                elif kick or (self.act_in_place and not self.serial):
                     pol.update(batch, before_actor_half=between_halves)
                 else:
                     pol.update(batch)
-            if use_stop:
+            if self.ar_off_chain and batch is not None:
+                pass                                    # (the completion event was recorded on the side stream)
+            elif use_stop:
                 L.check(lib.pdec_mlp_flush_stop_event(pol.behavior_actor.model.handle))          # no-op when consumed
             elif not self.serial:
                 self.ev_upd[k % 2].record(self.s_upd)
         if chunk_last and not self.serial:
             self.ev_upd[k % 2].wait(self.s_env)    # join: the graph ends on the env stream
 
+    def _update_ar_off_chain(self, k, batch, between_halves, use_stop):
+        """update_k of a data-parallel run with the collective off the update chain (module docstring).  On the update stream:
+        critic half, actor pass, slab reduction (its completion = `ev_red`, riding on the reduction launch where the fused path
+        allows); on the side stream behind that event: all-reduce of the flat actor gradient, then the ADAM launch -- issued
+        through the actor's handles while they are set to the side stream -- whose completion is `ev_upd[k % 2]`, the event the
+        next acting kernel (env stream) and the next actor pass (update stream) wait for."""
+        pol, lib, L = self.policy, self.lib, _lib
+        A, At = pol.behavior_actor.model, pol.target_actor.model
+        pol.update_critic_half(batch)
+        between_halves()
+        red_on_launch = use_stop and lib.pdec_mlp_set_reduce_event(A.handle, self.ev_red.h) == 0
+        pol.actor_grads(batch)                                      # (records a reduce event its launches did not carry)
+        if not red_on_launch:
+            self.ev_red.record(self.s_upd)
+        self.ev_red.wait(self.s_ar)
+        pol.reducer.all_reduce(A, stream=self.s_ar)
+        L.check(lib.pdec_set_stream(A.handle, self._sp_ar))
+        L.check(lib.pdec_set_stream(At.handle, self._sp_ar))
+        try:
+            pol.apply_actor()
+            if use_stop:
+                L.check(lib.pdec_mlp_flush_stop_event(A.handle))    # no-op when the ADAM launch carried ev_upd[k % 2]
+            else:
+                self.ev_upd[k % 2].record(self.s_ar)
+        finally:
+            L.check(lib.pdec_set_stream(A.handle, self._sp_upd))
+            L.check(lib.pdec_set_stream(At.handle, self._sp_upd))
+
     _capturing = False
     _first_tick = 0
+    _mid_wait_prev = False    # update_{k-1} waited for env_{k-2} between its halves (so step k needs no wait at its top)
     drain_between = False
 
     def _first_last(self, k):
@@ -538,6 +650,8 @@ class TrainPipeline:
     def sync(self):
         self.s_env.synchronize()
         self.s_upd.synchronize()
+        if self.s_ar is not None:
+            self.s_ar.synchronize()
 
     def close(self):
         if getattr(self, "simd_sharing", False):

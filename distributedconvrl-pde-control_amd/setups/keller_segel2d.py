@@ -10,6 +10,9 @@ from .. import _lib
 
 
 class KellerSegel2DSetup:
+    # create_agent's default for `quirk_frozen_targets`: the Keller-Segel family learns only with moving targets (KellerSegelSetup)
+    reproduces_reference_with = "moving"
+
     is_kseg2d = True
 
     def __init__(self, nx=256, ny=256, Lx=None, sensor_step=8, sensor_x=None, sensor_y=None, border=2, border_y=None,

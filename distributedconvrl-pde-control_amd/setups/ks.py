@@ -41,6 +41,12 @@ def _refuse_unbuilt_branches(setup, where, memory_built=False, reward_check_with
 
 
 class KSSetup:
+    # Which target-network regime reproduces the reference's saved runs of this experiment family (create_agent's default for
+    # `quirk_frozen_targets`): KS22 / KS200 were produced with src/custom_nna.jl:20 as committed -- the Polyak loop of
+    # src/PDEagent.jl:415-417 iterates over an empty parameter list, the targets in agent.jld2 are the initial ones
+    # (tests/test_replay_golden.py) -- and their learning curves are reproduced only with frozen targets (HISTORY.md 5.1).
+    reproduces_reference_with = "frozen"
+
     def __init__(self, nx, Lx, sensor_positions, actuator_positions=None, actuators_to_sensors=None,
                  sigma_sensors=1.0, sigma_actuators=1.0, mu=0.0, te=5.0, t0=0.0, dt=0.1, oversampling=30,
                  max_value=30.0, check_max_value="y", agent_power=7.5, action_punish=0.002,

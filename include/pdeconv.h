@@ -214,22 +214,6 @@ int pdec_env_step_host(pdec_handle h, const void* y_in, const void* action, cons
                        const void* state_prev, void* y_out, void* p_out, void* state_out,
                        void* reward_out, int32_t* done);
 
-/* Unit-test entry of the register-resident wave FFT the fluid kernels are built on (csrc/wave_fft.hpp): nlines
- * lines of `len` complex doubles (device), natural order in and out, unnormalised forward (sgn < 0) / inverse
- * (sgn > 0) with FFTW's conventions (src/fluid_rk4.jl uses FFTW's fft / ifft).  len in {128,256,384,512,768}. */
-int pdec_debug_wave_fft(const void* in_dev, void* out_dev, int len, int nlines, int sgn);
-
-/* Measurement aid of bench.py (no reference counterpart): arm = 1 makes the NEXT fused critic pass launched on `critic`
- * (the behaviour critic of a 3-layer pair, src/PDEagent.jl:385-400) record s_memtime / s_memrealtime stamps at its phase
- * boundaries; arm = 0 copies the record of that launch to out13[13] (host): the mean shader cycles of the ten phases per
- * workgroup, their sum, the shader clock in GHz (d s_memtime / d s_memrealtime x 100 MHz) and the workgroup count.
- * Synchronises the stream of the pass. */
-int pdec_debug_critic_stamps(pdec_handle critic, int arm, double* out13);
-/* Measurement aid (no counterpart in the reference): the fp32 2-D Keller-Segel tile kernel on `nb` trajectories with `reps` RK4
- * sub-steps per launch on the tile held in registers (no halo refresh: timing only), `iters` launches between two events ->
- * microseconds per launch.  What a time-resident form of KellerSegelSetup.jl:213-239 x 32 could at best cost (HISTORY.md round 5). */
-int pdec_debug_kseg2d_probe(pdec_handle env, int nb, int reps, int iters, double* us_per_launch);
-
 /* ---------------------------------------------------------------- networks ----------- */
 /* Chain(Dense...) with weights shared across columns (src/PDEagent.jl:14-56).
  * dims[n_layers+1], acts[n_layers].  params_host: Flux.params order W1,b1,W2,b2,... each W
@@ -459,6 +443,12 @@ int pdec_graph_num_nodes(pdec_handle graph, int* n);
  * packet: what pdec_event_record(event, stream) right behind that call would give, without the record's own packet in the
  * stream (each costs the update chain ~4.5 us).  PDEC_E_INVALID for networks outside that path. */
 int pdec_mlp_set_stop_event(pdec_handle mlp, pdec_handle event);
+/* The same for the next reduce-ONLY launch on `mlp` (the second kernel of pdec_ddpg_actor_grads / pdec_ddpg_critic_grads on the
+ * fused 3-layer path: the flat gradient buffer is complete when it ends) -- the event an all-reduce issued on ANOTHER stream
+ * waits for, so that the collective leaves the update chain (pipeline.py).  A launch that applies the update never consumes
+ * it, a reduce-only launch never consumes the stop event, and pdec_ddpg_actor_grads / _critic_grads record it behind their
+ * last launch when the path they took has no such launch (so a waiter never sees a stale event). */
+int pdec_mlp_set_reduce_event(pdec_handle mlp, pdec_handle event);
 /* records a still pending stop event on the net's stream (the update took a path that does not consume it); else no-op */
 int pdec_mlp_flush_stop_event(pdec_handle mlp);
 /* Device-scope events for the hand-offs between two streams of one device (no system-scope cache fence, unlike a
@@ -477,8 +467,11 @@ int pdec_comm_create(pdec_handle* c, int nranks, int rank, const void* id128);
  * others for ever; past timeout_ms (> 0) this returns PDEC_E_COMM instead and the caller can agree on another path
  * (bench.py: torch.distributed).  timeout_ms <= 0 = pdec_comm_create. */
 int pdec_comm_create_timeout(pdec_handle* c, int nranks, int rank, const void* id128, int timeout_ms);
-/* sum-all-reduce the internal gradient buffer of an MLP in place (fp32/fp64) */
+/* sum-all-reduce the internal gradient buffer of an MLP in place (fp32/fp64), on the network's stream ... */
 int pdec_allreduce_grads(pdec_handle comm, pdec_handle mlp);
+/* ... or on `hip_stream` (NULL = the network's): the caller orders it against the launch that leaves the gradient
+ * (pdec_mlp_set_reduce_event) and the one that consumes it (pdec_stream_wait_event before pdec_adam_polyak_step) */
+int pdec_allreduce_grads_on(pdec_handle comm, pdec_handle mlp, void* hip_stream);
 int pdec_allreduce(pdec_handle comm, void* dptr, size_t n, int dtype, void* hip_stream);
 
 #ifdef __cplusplus

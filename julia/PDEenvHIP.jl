@@ -91,6 +91,7 @@ function env_create(cfg::EnvCfg, gaussians, gaussians_actuators, actuators_to_se
     a2s = Int32.(actuators_to_sensors .- 1)
     check(ccall((:pdec_env_create, LIB), Cint,
                 (Ref{UInt64}, Ref{EnvCfg}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}), h, cfg, G, Ga, a2s))
+    note_experiment_family!(cfg.pde_kind)
     h[]
 end
 
@@ -152,6 +153,7 @@ function fluid_env_create(cfg::EnvCfg, BH, BW, sensor_boxes, sensor_origin, actu
     check(ccall((:pdec_fluid_env_create, LIB), Cint,
                 (Ref{UInt64}, Ref{EnvCfg}, Cint, Cint, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}),
                 h, cfg, BH, BW, sensor_boxes, sensor_origin, actuator_boxes, actuator_origin, a2s))
+    note_experiment_family!(cfg.pde_kind)
     h[]
 end
 # do_step(env) (FluidSetup.jl:163-172): env.y, env.p are ComplexF64[ny, nx], passed as they lie (re, im interleaved)
@@ -173,6 +175,7 @@ function kseg2d_env_create(cfg::EnvCfg, ny, sensor_x::Vector{Int32}, sensor_y::V
     check(ccall((:pdec_kseg2d_env_create, LIB), Cint,
                 (Ref{UInt64}, Ref{EnvCfg}, Cint, Cint, Cint, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Int32}),
                 h, cfg, ny, length(sensor_x), length(sensor_y), sensor_x, sensor_y, half_window, a2s))
+    note_experiment_family!(cfg.pde_kind)
     h[]
 end
 
@@ -237,7 +240,29 @@ end
 # src/custom_nna.jl:20 defines a `functor` of its own instead of extending Functors.functor -- so its target networks never
 # move (scripts/KS/KS22/saves/agent.jld2: zero target biases after 130 340 updates).  true = the reference as it runs (the
 # kernels get rho = 1: dest = 1 * dest + 0 * src); false = the loop as written (rho = policy.p).
+# The default is PER EXPERIMENT FAMILY, as in the Python host (setup.reproduces_reference_with): creating an environment sets it
+# to the regime under which this path reproduces the reference's saved runs of that family -- frozen for KS (KS22 / KS200),
+# moving for Keller-Segel and the fluid, whose artifacts a later session of the authors wrote (under frozen targets
+# Keller-Segel saturates at return -30 in 24 of 24 seeds and the fluid diverges in 4 of 6: HISTORY.md 5.1).
+# `set_target_networks!(:frozen | :moving)` pins a choice; a pinned choice that differs from the family's regime is honoured
+# with a warning.
 const FROZEN_TARGETS = Ref(true)
+const TARGETS_PINNED = Ref(false)
+const REPRODUCES_REFERENCE_WITH = Dict(KS_CNAB2 => :frozen, KS_RK4_FD => :frozen, KSEG_RK4 => :moving, KSEG2D_RK4 => :moving,
+                                       FLUID_RK4 => :moving)
+function set_target_networks!(regime::Symbol)
+    regime in (:frozen, :moving) || error("set_target_networks!: :frozen or :moving")
+    FROZEN_TARGETS[] = regime == :frozen
+    TARGETS_PINNED[] = true
+end
+function note_experiment_family!(pde_kind)
+    want = REPRODUCES_REFERENCE_WITH[Cint(pde_kind)]
+    if !TARGETS_PINNED[]
+        FROZEN_TARGETS[] = want == :frozen
+    elseif FROZEN_TARGETS[] != (want == :frozen)
+        @warn "target networks pinned to $(FROZEN_TARGETS[] ? :frozen : :moving), but the reference's saved runs of this experiment family are reproduced only with $want targets (HISTORY.md 5.1)"
+    end
+end
 function ddpg_update!(policy, batch)
     s, a, r, t, snext = batch                            # Float32; s [ns,Bu], a [na,Bu], r [1,Bu], t [Bu]
     rho = FROZEN_TARGETS[] ? 1.0 : Float64(policy.p)

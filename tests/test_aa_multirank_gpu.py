@@ -126,6 +126,43 @@ if mode == "grads":
         print("RESULT " + json.dumps(out))
     dist.destroy_process_group()
     sys.exit(0)
+if mode == "pipeline":
+    # VERDICT r5 item 1: the two-stream training pipeline of each rank on its shard of the trajectories, gradient exchange
+    # (policy only) over gloo -- once with the all-reduce ON the update stream, once on a third stream beside the next critic
+    # half (TrainPipeline(stream_ar=...)); both orders must leave the same networks and fields bit for bit on every rank, and
+    # the actors must be identical replicas across the ranks.
+    B = 16
+    y0_all = setup.generate_random_init(np.random.default_rng(0), B * world) * 0.15
+    def run(off_chain):
+        s_env, s_upd, s_ar = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0_all[rank * B:(rank + 1) * B], stream=s_env, autoreset=False)
+        agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
+                                 noise_seed=7 + rank, trajectory_length=1, reducer=pkg.distributed.GradReducer(reduce_critic=False))
+        agent.policy.act_noise = 0.3
+        torch.cuda.synchronize()
+        p = pkg.TrainPipeline(env, agent, lag=2, episode_steps=11, stream_env=s_env, stream_upd=s_upd, use_graphs=False,
+                              noise_seed=99 + rank, stream_ar=s_ar, ar_off_chain=off_chain)
+        assert p.multi_rank and p.ar_off_chain == off_chain
+        p.run(30); p.sync()
+        torch.cuda.synchronize()
+        return p
+    pc, ps = run(False), run(True)
+    out = {"rank": rank, "mode": mode, "recorded": bool(ps._progs) and bool(pc._progs)}
+    same = torch.equal(pc.y, ps.y) and bool(torch.isfinite(ps.y).all())
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        same = same and torch.equal(flat(getattr(pc.policy, n)), flat(getattr(ps.policy, n)))
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(same))
+    out["orders_identical_on_every_rank"] = all(flags)
+    for k, v in (("actor", flat(ps.policy.behavior_actor)), ("critic", flat(ps.policy.behavior_critic))):
+        got = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(got, v)
+        out[k + "_identical"] = all(torch.equal(x, got[0]) for x in got)
+    dist.barrier()
+    if rank == 0:
+        print("RESULT " + json.dumps(out))
+    dist.destroy_process_group()
+    sys.exit(0)
 red = pkg.distributed.GradReducer(reduce_critic=(mode == "all"))
 assert red.world_size == world
 agent = make(red, hi - lo)
@@ -211,6 +248,15 @@ def test_two_ranks_all_reduced_gradient_is_the_oracles_full_batch_gradient(tmp_p
     assert r["gC_identical"] and r["gA_identical"], r
     assert r["gC_vs_oracle"] <= 1e-4 and r["gA_vs_oracle"] <= 1e-4, r
     assert r["shard_vs_full"] > 1e-3, r
+
+
+def test_two_ranks_allreduce_off_the_update_chain_is_bit_identical(tmp_path):
+    """two ranks on the one GPU, gradient exchange over gloo, the training pipeline with the all-reduce +
+    ADAM(actor) on a third stream beside the next critic half vs on the update stream: same networks and PDE state bit for bit
+    on both ranks; actors identical replicas, critics local (policy-gradient-only exchange)"""
+    r = _run_ranks(tmp_path, "pipeline")
+    assert r["orders_identical_on_every_rank"] and r["recorded"], r
+    assert r["actor_identical"] and not r["critic_identical"], r
 
 
 def test_native_rccl_reducer_with_two_ranks(tmp_path):

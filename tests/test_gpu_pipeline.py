@@ -206,6 +206,91 @@ def test_split_update_sequence_on_one_rank_equals_the_fused_finish(pkg):
     pa.close()
 
 
+def _make_dp(pkg, red, serial=False, off_chain=None, B=64, E=17, nx=256, **agent_kw):
+    """a data-parallel pipeline on ONE rank (split update sequence through `red`), with a third stream for the collective"""
+    setup = pkg.KSSetup.bench_C2(nx)
+    s_env = torch.cuda.Stream()
+    s_upd = s_env if serial else torch.cuda.Stream()
+    s_ar = torch.cuda.Stream()
+    y0 = setup.generate_random_init(np.random.default_rng(0), B) * 0.15
+    env = pkg.PDEenv(setup, B=B, dtype=torch.float32, y0=y0, stream=s_env, autoreset=False)
+    agent = pkg.create_agent(setup=setup, B=B, rng=np.random.default_rng(1), dtype=torch.float32, stream=s_upd, start_steps=-1,
+                             noise_seed=7, trajectory_length=1, reducer=red, **agent_kw)
+    agent.policy.act_noise = 0.3
+    torch.cuda.synchronize()
+    return pkg.TrainPipeline(env, agent, lag=2, episode_steps=E, stream_env=s_env, stream_upd=s_upd, use_graphs=False, noise_seed=99,
+                             stream_ar=s_ar, ar_off_chain=off_chain)
+
+
+@pytest.mark.parametrize("serial", [False, True])
+def test_allreduce_off_the_update_chain_is_bit_identical(pkg, serial):
+    """with the policy-gradient-only exchange and the reference's frozen target networks the
+    all-reduce of the actor gradient and the ADAM launch behind it run on a third stream beside the NEXT critic half (which reads
+    only the target actor, src/PDEagent.jl:385), and the next acting kernel / actor pass wait for the ADAM launch's event.  Same
+    kernels, same arguments, same order of arithmetic: after 40 control steps (two episode boundaries, recorded-step replay)
+    every network and the PDE state equal, bit for bit, (a) the same sequence with the collective ON the update stream and (b)
+    the fused single-GPU finish -- through a 1-rank RCCL communicator and through bench.py's emulated-latency reducer (a 25 us
+    spin kernel where the collective goes), on two streams and on one (config C3's issue order: critic half first)."""
+    import bench
+    lib = pkg._lib.load()
+    for kind in ("rccl", "spin"):
+        pf = _make(pkg, False)
+        pf.run(40); pf.sync()
+        mk = (lambda: pkg.distributed.NativeGradReducer(lib, rank=0, world_size=1, reduce_critic=False, force_split=True)) if kind == "rccl" \
+            else (lambda: bench.EmulatedLatencyReducer(lib, 25.0))
+        reds = [mk(), mk()]
+        pc = _make_dp(pkg, reds[0], serial=serial, off_chain=False)
+        ps = _make_dp(pkg, reds[1], serial=serial)                       # None = off the chain whenever legal
+        assert pc.multi_rank and not pc.ar_off_chain and ps.ar_off_chain and ps.s_ar is not None and pc.s_ar is None
+        pc.run(40); ps.run(40)
+        pc.sync(); ps.sync()
+        assert bool(ps._progs) and bool(pc._progs)                       # interior steps came from recorded call lists
+        for p in (pc, ps):
+            assert torch.equal(pf.y, p.y) and bool(torch.isfinite(p.y).all()), kind
+            _same_networks(pf, p)
+            for k in range(3):
+                assert torch.equal(pf.aring[k], p.aring[k])
+        # ... the order can be switched in a running pipeline (bench.py times both and keeps the faster)
+        pc.set_ar_order(True); ps.set_ar_order(False)
+        assert pc.ar_off_chain and not ps.ar_off_chain and not pc._progs
+        pf.run(15); pc.run(15); ps.run(15)
+        pf.sync(); pc.sync(); ps.sync()
+        for p in (pc, ps):
+            assert torch.equal(pf.y, p.y), kind
+            _same_networks(pf, p)
+        pc.set_ar_order(False); ps.set_ar_order(True)
+        # ... and a restart in the middle of an episode (steps without an update while an apply is still in flight)
+        for p in (pc, ps):
+            p.reset_from(p.env.y0)
+            p.run(9); p.sync()
+        assert torch.equal(pc.y, ps.y)
+        _same_networks(pc, ps)
+        pc.close(); ps.close(); pf.close()
+        for r in reds:
+            r.close()
+
+
+def test_allreduce_off_the_chain_is_refused_where_it_would_change_the_arithmetic(pkg):
+    """the order is legal only when critic half_{k+1} cannot see ADAM(actor)_k: moving targets (the Polyak step of the target
+    actor rides on that ADAM launch and the critic half reads the target actor) or an exchanged critic -> automatic selection
+    keeps the collective on the chain, insisting raises"""
+    lib = pkg._lib.load()
+    red = pkg.distributed.NativeGradReducer(lib, rank=0, world_size=1, reduce_critic=False, force_split=True)
+    p = _make_dp(pkg, red, quirk_frozen_targets=False)
+    assert p.multi_rank and not p.ar_off_chain
+    with pytest.raises(pkg.PdecError):
+        _make_dp(pkg, red, off_chain=True, quirk_frozen_targets=False)
+    red_all = pkg.distributed.NativeGradReducer(lib, rank=0, world_size=1, reduce_critic=True, force_split=True)
+    assert not _make_dp(pkg, red_all).ar_off_chain
+    with pytest.raises(pkg.PdecError):
+        _make_dp(pkg, red_all, off_chain=True)
+    # moving targets on the chain still equal the fused finish
+    pm = _make_dp(pkg, red, quirk_frozen_targets=False)
+    pm.run(12); pm.sync()
+    assert bool(torch.isfinite(pm.y).all())
+    p.close(); pm.close(); red.close(); red_all.close()
+
+
 def test_checkpoint_keeps_the_device_noise_counter(pkg, tmp_path):
     """TrainPipeline's acting kernel advances a DEVICE-resident Philox counter
     (pdec_policy_act_rng_dev); save_agent stores it and load_agent restores it, so a resumed pipeline continues the

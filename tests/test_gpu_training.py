@@ -12,7 +12,7 @@ the frame counts 52 224 / 52 232 and hook.rewards = sum over steps of mean over 
 import numpy as np
 import pytest
 
-from util import load_golden, train
+from util import emulate_rlcore_wrap, load_golden, train
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -99,9 +99,8 @@ def _curves(pkg, setup, seeds, frozen, loops, no_steps, decay, hook_kw=None, rlc
         env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
         agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(100 + seed), noise_seed=1000 + seed, stream=s_upd,
                                  quirk_frozen_targets=frozen)
-        if rlcore_wrap:                      # RLCore's misaligned traces after wrap-around (agent.py: _rlcore_wrap_shift), host sampling
-            agent.policy.sampling = "host"
-            agent.trajectory.emulate_rlcore_wrap = True
+        if rlcore_wrap:                      # RLCore's misaligned traces after wrap-around (tests/util.py), host sampling
+            emulate_rlcore_wrap(pkg, agent)
         hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, init_seed=2000 + seed, init_rng=np.random.default_rng(seed),
                            **(hook_kw or {}))
         train(pkg, agent, env, hook, loops=loops, no_steps=no_steps, decay=decay)
@@ -133,7 +132,7 @@ def test_ks22_learning_curve_lands_in_the_band_of_the_reference_run(pkg):
 
 def test_ks200_learning_curve_before_the_buffer_wraps(pkg):
     """scripts/KS/KS200/saves/hook.jld2: same train(), 80 actuators; the 150 000-row buffer wraps in episode 37, after which
-    RLCore's traces are misaligned (agent.py: _rlcore_wrap_shift) and the reference curve relapses (-23.6 at episode 43, -26.2
+    RLCore's traces are misaligned (tests/util.py: rlcore_wrap_shift) and the reference curve relapses (-23.6 at episode 43, -26.2
     at 88); the product keeps its traces aligned, so only the episodes before the wrap are compared"""
     ref = load_golden("ks200_hook.npz")["episode_rewards"]
     band = lambda r: (-20.0 <= r[:16].mean() <= -4.0, -2.8 <= r[16:36].mean() <= -1.2)

@@ -14,17 +14,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_c_abi_exports_every_declared_symbol(pkg):
-    """the shared library loads without a GPU and exports every function include/pdeconv.h declares"""
-    hdr = open(os.path.join(ROOT, "include", "pdeconv.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(pdec_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 40
+    """the shared library loads without a GPU and exports every function include/pdeconv.h declares -- and the unit-test /
+    measurement entry points of include/pdeconv_debug.h, which are NOT part of the drop-in surface: no
+    `pdec_debug_*` name is left in the public header, and the Julia glue binds none of them"""
     lib = ctypes.CDLL(pkg._lib.LIB_PATH)
-    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
-    assert not missing, missing
-    # and the ctypes binding covers the same set
-    bound = set(pkg._lib.SIGNATURES) | {"pdec_last_error"}
-    assert declared == bound, declared ^ bound
+    for header, sigs, extra in (("pdeconv.h", pkg._lib.SIGNATURES, {"pdec_last_error"}),
+                                ("pdeconv_debug.h", pkg._lib.DEBUG_SIGNATURES, set())):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        declared = set(re.findall(r"\b(pdec_[a-z0-9_]+)\s*\(", hdr))
+        assert len(declared) >= (40 if header == "pdeconv.h" else 4)
+        missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+        assert not missing, missing
+        # and the ctypes binding covers the same set
+        bound = set(sigs) | extra
+        assert declared == bound, declared ^ bound
+        assert all(n.startswith("pdec_debug_") for n in declared) == (header == "pdeconv_debug.h")
+        assert not any(n.startswith("pdec_debug_") for n in declared) or header == "pdeconv_debug.h"
+    for jl in os.listdir(os.path.join(ROOT, "julia")):
+        assert "pdec_debug_" not in open(os.path.join(ROOT, "julia", jl)).read(), jl
 
 
 def _c_decls():
@@ -501,29 +509,63 @@ def test_negate_policy_is_the_fluid_scripts_baseline_controller(pkg):
 
 
 def test_rlcore_wrap_shift_is_zero_until_the_traces_wrap(pkg):
-    """agent.py _rlcore_wrap_shift: index i of an RLCore CircularArrayBuffer with G pushes and len = min(G, capacity) frames is
-    logical row G - len + i; state / action hold capacity + 1 frames, reward / terminal `capacity`, and pde_sample
-    (src/PDEagent.jl:317-340) indexes all four with one index -> A - 1 rows apart at the PRE_ACT update once both have wrapped"""
+    """tests/util.py rlcore_wrap_shift (study code, outside the product): index i of an RLCore CircularArrayBuffer with G pushes and
+    len = min(G, capacity) frames is logical row G - len + i; state / action hold capacity + 1 frames, reward / terminal
+    `capacity`, and pde_sample (src/PDEagent.jl:317-340) indexes all four with one index -> A - 1 rows apart at the PRE_ACT update
+    once both have wrapped.  The product's own trajectory stays aligned (shift 0 in its slots at every fill level)."""
     import torch
+    from types import SimpleNamespace
     from importlib import import_module
+    from util import emulate_rlcore_wrap, rlcore_wrap_shift
     agent = import_module("distributedconvrl-pde-control_amd.agent")
     A, cap = 8, 64
     tr = agent.CircularArraySARTTrajectory(cap, 1, 1, A, torch.device("cpu"))
-    assert tr.capacity == cap and tr._rlcore_wrap_shift() == 0
-    tr.emulate_rlcore_wrap = True
-    rng = np.random.default_rng(0)
+    plain = agent.CircularArraySARTTrajectory(cap, 1, 1, A, torch.device("cpu"))
+    assert tr.capacity == cap and rlcore_wrap_shift(tr) == 0
+    holder = SimpleNamespace(trajectory=tr, policy=SimpleNamespace(sampling="device"))
+    emulate_rlcore_wrap(pkg, holder)
+    assert holder.policy.sampling == "host" and type(tr) is not agent.CircularArraySARTTrajectory
     seen = []
     for step in range(20):
-        tr.push_sa(torch.full((A, 1), float(step)), torch.zeros(A, 1))            # PRE_ACT push ...
-        seen.append(tr._rlcore_wrap_shift())                                       # ... update samples here
+        for t in (tr, plain):
+            t.push_sa(torch.full((A, 1), float(step)), torch.zeros(A, 1))          # PRE_ACT push ...
+        seen.append(rlcore_wrap_shift(tr))                                         # ... update samples here
         if len(tr) > A:
-            i_s, i_rt, i_sn = tr.sample_slots_many(rng, 3, 2)
+            i_s, i_rt, i_sn = tr.sample_slots_many(np.random.default_rng(step), 3, 2)
             assert ((i_sn - i_s) % (cap + A) == A).all()
-        tr.push_rt(torch.zeros(A), torch.zeros(A))                                 # POST_ACT
+            j_s, j_rt, j_sn = plain.sample_slots_many(np.random.default_rng(step), 3, 2)
+            assert (j_rt == i_rt).all() and ((i_s - j_s) % (cap + A) == seen[-1] % (cap + A)).all()      # same draw, shifted (s, a, s')
+        for t in (tr, plain):
+            t.push_rt(torch.zeros(A), torch.zeros(A))                              # POST_ACT
     # the state trace (65 frames) overflows at the 9th push (72 rows), the reward trace (64) holds 64 rows then
     assert seen == [0] * 8 + [A - 1] * 12
-    tr.emulate_rlcore_wrap = False
-    assert tr._rlcore_wrap_shift() == 0
+
+
+def test_target_network_regime_is_per_experiment_family_and_a_mismatch_warns(pkg):
+    """VERDICT r5 item 5 / ADVICE r5 (medium): `quirk_frozen_targets` defaults per setup to the regime under which this path
+    reproduces the reference's saved runs -- frozen for KS (src/custom_nna.jl:20 as committed: the Polyak loop of
+    src/PDEagent.jl:415-417 runs over an empty list), moving for Keller-Segel and the fluid (HISTORY.md 5.1) -- and asking
+    create_agent for the other one raises a TargetNetworkWarning that a caller sees.  Same table in the Julia glue."""
+    import warnings
+    from importlib import import_module
+    agent = import_module("distributedconvrl-pde-control_amd.agent")
+    want = {pkg.KSSetup.KS22(): True, pkg.KSSetup.bench_C2(256): True, pkg.KellerSegelSetup(): False,
+            pkg.KellerSegel2DSetup(nx=64, ny=64): False, pkg.FluidSetup(nx=64): False}
+    for setup, frozen in want.items():
+        assert setup.reproduces_reference_with == ("frozen" if frozen else "moving")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                           # the default and the matching explicit request are silent
+            assert agent.resolve_target_networks(setup) is frozen
+            assert agent.resolve_target_networks(setup, frozen) is frozen
+        with pytest.warns(pkg.TargetNetworkWarning, match="reproduced only with " + ("frozen" if frozen else "moving")):
+            assert agent.resolve_target_networks(setup, not frozen) is (not frozen)       # honoured, loudly
+    src = open(os.path.join(ROOT, "distributedconvrl-pde-control_amd", "agent.py")).read()
+    assert "resolve_target_networks(setup, overrides.get(\"quirk_frozen_targets\")" in src       # create_agent goes through it
+    jl = open(os.path.join(ROOT, "julia", "PDEenvHIP.jl")).read()
+    table = re.search(r"REPRODUCES_REFERENCE_WITH = Dict\((.*?)\)\n", jl, flags=re.S).group(1)
+    assert dict(re.findall(r"(\w+) => :(\w+)", table)) == {"KS_CNAB2": "frozen", "KS_RK4_FD": "frozen", "KSEG_RK4": "moving",
+                                                           "KSEG2D_RK4": "moving", "FLUID_RK4": "moving"}
+    assert jl.count("note_experiment_family!(cfg.pde_kind)") == 3
 
 
 def test_native_reducer_agrees_on_failure_through_an_exchange_callable(pkg):
