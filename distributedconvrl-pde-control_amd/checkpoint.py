@@ -86,6 +86,7 @@ def save_agent(path, agent, with_trajectory=True):
         kw[f"{name}/dims"] = np.array(model.dims)
     kw["update_step"] = np.array(p.update_step)
     kw["act_noise"] = np.array(p.act_noise)
+    kw["rho_effective"] = np.array(p.rho_effective)       # 1.0 = the targets never moved (quirk_frozen_targets), else the Polyak factor
     # exploration-noise and minibatch-sampling streams (counter-based: seed + offset is the whole state), the host rng
     kw["noise_seed_off"] = np.array([p._noise_seed, p._noise_off], dtype=np.uint64)
     kw["sample_seed_off"] = np.array([p._sample_seed, p._sample_off], dtype=np.uint64)
@@ -127,6 +128,12 @@ def load_agent(path, agent):
         _lib.check(model.lib.pdec_adam_set_state(model.handle, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), bp))
     p.update_step = int(z["update_step"])
     p.act_noise = float(z["act_noise"])
+    if "rho_effective" in z.files and float(z["rho_effective"]) != float(p.rho_effective):
+        import warnings
+        from .agent import TargetNetworkWarning
+        warnings.warn(f"checkpoint {path} was written under rho_effective = {float(z['rho_effective']):g} "
+                      f"({'frozen' if float(z['rho_effective']) == 1.0 else 'moving'} target networks), this agent runs with "
+                      f"{float(p.rho_effective):g}: its target networks come from the other regime", TargetNetworkWarning, stacklevel=2)
     if "noise_seed_off" in z.files:
         p._noise_seed, p._noise_off = (int(x) for x in z["noise_seed_off"])
         p._sample_seed, p._sample_off = (int(x) for x in z["sample_seed_off"])
@@ -174,8 +181,11 @@ def save_agent_jld2(path, agent):
     arrays = {}
     for name in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
         arrays.update(_net_arrays(name, getattr(p, name).model))
+    # hyper = [gamma, rho (the policy's field p), act_limit, act_noise, eta_actor, eta_critic, rho_effective]: the last entry is the
+    # Polyak factor the update kernels RECEIVED -- 1.0 under quirk_frozen_targets (the targets in this file are then the initial
+    # networks, as in the reference's own agent.jld2), rho otherwise (a consumer can tell the two regimes apart)
     arrays["hyper"] = np.array([p.y, p.p, p.act_limit, p.act_noise, p.behavior_actor.optimizer.eta,
-                                p.behavior_critic.optimizer.eta], dtype=np.float64)
+                                p.behavior_critic.optimizer.eta, p.rho_effective], dtype=np.float64)
     write_arrays(path, arrays)
 
 

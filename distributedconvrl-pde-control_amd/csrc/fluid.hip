@@ -1337,7 +1337,10 @@ int fluid_env_step(Env& E0, const void* y_in, const void* action, const void* ac
       PDEC_REQUIRE(!refused, "fluid step: its %d part streams do not exist yet and cannot be made while the environment's stream is "
                    "being captured; run one step (or pdec_env_set_part_streams) before the capture, or PDEC_FLUID_SPLIT=0", E.nparts - 1);
     }
-    PDEC_HIP(E.ps.fork(E.stream, E.nparts));
+    {   // a fork that fails midway has already made some part streams wait: join them before returning
+      const hipError_t ef = E.ps.fork(E.stream, E.nparts);
+      if (ef != hipSuccess) { (void)E.ps.join(E.stream, E.nparts); PDEC_HIP(ef); }
+    }
     int b0 = 0, rc_part = PDEC_OK;
     for (int hh = 0; hh < E.nparts; ++hh) {
       FluidEnv& H = *E.half[hh];

@@ -101,9 +101,15 @@ __global__ __launch_bounds__(K2Tile<T>::NT, (NSUB == 1 && sizeof(T) == 4) ? 4 : 
                                                            int32_t* __restrict__ done, int last) {
   constexpr int K2_TY = K2Tile<T>::TY, K2_NT = K2Tile<T>::NT;
   constexpr int H = 4 * NSUB, RX = K2_TX + 2 * H, RY = K2_TY + 2 * H, SW = RX / 4, NSTRIP = SW * RY;
-  constexpr int NS = (NSTRIP + K2_NT - 1) / K2_NT, RXP = RX + 4;
+  constexpr int NS = (NSTRIP + K2_NT - 1) / K2_NT, RXP = RX;
   extern __shared__ __align__(16) unsigned char k2_smem[];
-  // stage values, one plane per species (a thread's 4 cells = one conflict-free 128-bit access per plane)
+  // Stage values, one plane per species; a thread's 4 cells = one 128-bit access per plane.  Row pitch = RX, no padding
+  // (round 6): strip id lies at dword 4 * id, so the 128-bit accesses of a wave -- own strip, north, south -- are 64
+  // CONSECUTIVE 16-byte pieces and conflict-free; with the pitch RX + 4 of rounds 3 - 5 every row end inside a 16-lane
+  // group shifted the rest of the group by four banks onto the banks of its first lane (SQ_LDS_BANK_CONFLICT 4.0 M of the
+  // 7.9 M per launch; bit-identical, C4 78.1 - 79.2 k -> 80.2 - 81.4 k env-steps/s, HISTORY.md 6.2).  The west / east reads
+  // stay single dwords out of these planes at a lane stride of 16 bytes (4-way conflicted): compact per-strip edge arrays
+  // remove those conflicts and make the kernel SLOWER (more vector instructions; the LDS wait is latency, not bandwidth).
   T* Su = reinterpret_cast<T*>(k2_smem);        // [RY][RXP]
   T* Sv = Su + RY * RXP;                        // [RY][RXP]
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive
@@ -350,8 +356,8 @@ static K2Dev<T> k2_dev(const Kseg2dEnv& E) {
 }
 
 template <int NSUB>
-static constexpr size_t k2_lds(size_t pair_bytes) {   // two planes [RY][RX + 4] of T
-  return (size_t)((pair_bytes == 8 ? 64 : 32) + 8 * NSUB) * (K2_TX + 8 * NSUB + 4) * pair_bytes;
+static constexpr size_t k2_lds(size_t pair_bytes) {   // two planes [RY][RX] of T
+  return (size_t)((pair_bytes == 8 ? 64 : 32) + 8 * NSUB) * (K2_TX + 8 * NSUB) * pair_bytes;
 }
 
 // b0, nb: the trajectories [b0, b0 + nb) of the batch on stream `st` (the whole batch on the environment's stream by default)
@@ -423,7 +429,10 @@ static int k2_integrate(Kseg2dEnv& E, const void* y_in, const void* p, const voi
   const int np = sizeof(T) == 4 && ns == 1 && !E.prof ? k2_parts(E) : 0;
   if (np >= 2) {
     { const int rc = k2_make_part_streams(E, np); if (rc) return rc; }
-    PDEC_HIP(E.ps.fork(E.stream, np));
+    {   // a fork that fails midway has already made some part streams wait: join them before returning
+      const hipError_t ef = E.ps.fork(E.stream, np);
+      if (ef != hipSuccess) { (void)E.ps.join(E.stream, np); PDEC_HIP(ef); }
+    }
     int rc_launch = PDEC_OK;
     for (int l = 0; l < launches && !rc_launch; ++l) {
       void* dst = ((launches - 1 - l) & 1) ? E.ytmp.p : y_out;

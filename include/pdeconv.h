@@ -366,7 +366,11 @@ int pdec_env_set_reward_partials_out(pdec_handle env, void* partial_sums, int* n
  * uses besides the environment's own; pdec_env_set_part_streams hands over the caller's instead (made back to back with its
  * pipeline streams, see pdec_stream_create; the library's are released, the caller's are never destroyed by the library).
  * Fewer than asked for: 2-D Keller-Segel runs that many parts + 1 (0: unsplit), fluid refuses (PDEC_E_INVALID).  Environments
- * without parts accept and ignore the call.  Same results bit for bit either way. */
+ * without parts accept and ignore the call.  Same results bit for bit either way.
+ * The library's own part streams (and their events) are made at the FIRST split step, not at environment creation -- by then
+ * the environment's stream, whose priority level they take, is known.  Nothing can be created while a stream is being
+ * captured, so a caller that opens pdec_capture_begin before any eager step must either run one step first or hand over its
+ * own streams with pdec_env_set_part_streams; otherwise the captured step returns PDEC_E_INVALID naming this. */
 int pdec_env_part_streams(pdec_handle env, int* n);
 int pdec_env_set_part_streams(pdec_handle env, void* const* hip_streams, int n);
 int pdec_ddpg_set_reward_partials(pdec_handle critic, const void* partial_sums, int n);
@@ -433,6 +437,8 @@ int pdec_env_random_init(pdec_handle env, uint64_t seed, uint64_t offset, void* 
  * state, which the captured calls flipped on the host, are flipped again by every pdec_graph_launch after the first
  * (capturing records the work without running it, so the first launch is the execution the capture stands for).
  * A graph must be replayed at a step whose buffers are those of the captured one (same ring phase).
+ * Precondition for environments that step their batch in parts (fluid, 2-D Keller-Segel): their part streams exist -- one
+ * eager step or pdec_env_set_part_streams before the capture (see pdec_env_part_streams).
  * The graph handle is released with pdec_destroy. */
 int pdec_capture_begin(pdec_handle origin);
 int pdec_capture_end(pdec_handle origin, pdec_handle* graph);

@@ -23,5 +23,10 @@ function load_agent_arrays!(agent, path::String)
     agent
 end
 
+# d["hyper"] = [gamma, rho, act_limit, act_noise, eta_actor, eta_critic, rho_effective]; rho_effective == 1.0: the run kept its
+# target networks frozen (PDEenvHIP.FROZEN_TARGETS, the reference as its committed source runs), so the target_* arrays are the
+# initial networks; otherwise they are Polyak averages with that factor
+target_regime(path::String) = (h = load(path)["hyper"]; length(h) >= 7 && h[7] == 1.0 ? :frozen : :moving)
+
 # hook.bestNNA for plot_heat (src/plotting.jl:26-31): copyto!(agent.policy.behavior_actor, best)
 best_actor(path::String; name = "bestNNA") = chain_from_arrays(load(path), name)

@@ -436,6 +436,40 @@ def test_in_kernel_sampling_equals_host_slots_from_the_same_stream(pkg):
         assert p0.losses() == p1.losses()
 
 
+@pytest.mark.parametrize("which", ["two_layer_register_kernel", "three_layer_generic_kernel"])
+def test_small_update_leaves_frozen_targets_untouched(pkg, which):
+    """with the reference's frozen target networks (rho = 1; src/PDEagent.jl:415-417 iterates over an empty list)
+    the small-batch update -- the path of the reference-shaped B = 1, 20 x 3 training -- must not TOUCH the targets, like the
+    large-batch finish kernels and pdec_polyak: dest = 1 * dest + 0 * src would rewrite them, and turn a non-finite behaviour
+    parameter into a NaN target.  An Inf planted in a behaviour bias stays out of the targets (bit-identical to before the
+    update); with moving targets (rho = 0.995) the same update does move them."""
+    import warnings
+    setup = pkg.KSSetup.KS22() if which.startswith("two") else pkg.KSSetup.bench_C2(256)
+    ns, A = setup.state_shape
+    for frozen in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", pkg.TargetNetworkWarning)
+            agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=320, quirk_frozen_targets=frozen)
+        pol, tr = agent.policy, agent.trajectory
+        g = torch.Generator().manual_seed(3)
+        for step in range(30):
+            tr.push_sa(torch.randn(A, ns, generator=g).cuda(), (torch.rand(A, 1, generator=g) * 2 - 1).cuda())
+            tr.push_rt(-torch.rand(A, generator=g).cuda(), torch.zeros(A).cuda())
+        tr.push_sa(torch.randn(A, ns, generator=g).cuda(), None)
+        assert pol.small_update_ok()
+        if frozen:                                   # an Inf in the behaviour critic's last bias
+            prm = [x.copy() for x in pol.behavior_critic.model.params()]
+            prm[-1][...] = np.inf
+            pol.behavior_critic.model.set_params(prm)
+        before = [x.copy() for n in (pol.target_actor, pol.target_critic) for x in n.model.params()]
+        pol.update_small_rng(tr)
+        torch.cuda.synchronize()
+        after = [x for n in (pol.target_actor, pol.target_critic) for x in n.model.params()]
+        same = all(np.array_equal(a, b) for a, b in zip(before, after))
+        assert same == frozen
+        assert all(np.isfinite(x).all() for x in after)
+
+
 def test_random_init_kernels_match_the_oracle_stream(pkg):
     """pdec_env_random_init (generate_random_init of KSSetup.jl:288-298 / KellerSegelSetup.jl:373-384 as a kernel) against
     the oracle's formulas evaluated with the coefficients of the same Philox stream (oracle/rng.py)"""
