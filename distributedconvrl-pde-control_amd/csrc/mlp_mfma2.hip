@@ -242,6 +242,7 @@ struct Fused2Args {
   int quirk;
   float* slab;
   const float* rbar;          // device scalar: mean reward (quirk) written by rmean_kernel
+  int tpw;                    // wave tiles (16 columns) per workgroup: workgroup b owns tiles [b tpw, (b + 1) tpw) (grid2_of)
 };
 
 // mean of r in a fixed order (one block): the batch-mean reward of the reference's (1xBu).+(Bu) broadcast
@@ -370,7 +371,12 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
   float* redA = Lm;
   const Lds2 SA = carve2(base + imgc + stg, HPa, LDK);
   float* dacc = SA.W1 + lds2_floats(HPa, LDK); // [HP]
-  const int nchunk = (g.Bu + FCOLS - 1) / FCOLS;
+  // Columns in units of WAVE TILES (16 columns): workgroup b owns the tiles [t0, t1) and walks them in chunks of 8 (one per
+  // wave).  Round 6: the tiles are dealt evenly over the grid (grid2_of) instead of whole 128-column chunks strided over it --
+  // config C4's 784 chunks came as 196 workgroups x 4 chunks (60 CUs idle, x0.77); now 256 workgroups take 24.5 tiles each: three
+  // full chunks and one with a single live wave, in which the other waves skip their forward passes and the dW1 GEMM skips the
+  // column quarters that hold no live wave.
+  const int nt = (g.Bu + 15) / 16, t0 = blockIdx.x * g.tpw, t1 = min(t0 + g.tpw, nt);
 
   load_net2(SA, g.At, HPa, LDK, tid);
   load_net2(SC, g.Ct, HP, LDK, tid);
@@ -381,10 +387,10 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
   float tgt[CPWMAX];
 #pragma unroll
   for (int j = 0; j < CPWMAX; ++j) {
-    const int chunk = blockIdx.x + j * gridDim.x;
+    const int tile = t0 + 8 * j + w;
     tgt[j] = 0.f;
-    if (chunk < nchunk) {
-      const int col = chunk * FCOLS + w * 16 + lr;
+    if (tile < t1) {
+      const int col = tile * 16 + lr;
       const bool valid = col < g.Bu;
       float xn[K2MAX][2];
       load_x2(xn, g.sn, (size_t)col, ns, KB, q, valid);
@@ -408,21 +414,29 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
   const int cw = (w & 1) * 16 + lr;
 #pragma unroll 1
   for (int j = 0; j < CPWMAX; ++j) {
-    const int chunk = blockIdx.x + j * gridDim.x;
-    if (chunk >= nchunk) break;
+    const int tb = t0 + 8 * j;                  // first tile of this chunk
+    if (tb >= t1) break;
+    const int live = min(8, t1 - tb);           // waves 0 .. live-1 hold columns (uniform over the workgroup)
     const float tgj = j == 0 ? tgt[0] : (j == 1 ? tgt[1] : (j == 2 ? tgt[2] : tgt[3]));
-    const int col = chunk * FCOLS + w * 16 + lr;
-    const bool valid = col < g.Bu;
+    const int col = (tb + w) * 16 + lr;
+    const bool valid = w < live && col < g.Bu;
     float xq[K2MAX][2];
-    load_x2(xq, g.s, (size_t)col, ns, KB, q, valid);
-    const float av = valid ? g.a[col] : 0.f, rv = valid ? g.r[col] : 0.f;
-    set_row2(xq, ns, av, q);
     f32x4 h1[MT];
-    layer1_keep<MT, KB>(h1, xq, SC, lr, q);
-    const float qv = head<MT>(h1, SC.w2, SC.b2[0], q);
-    const float c = valid ? tgj - qv : 0.f;
-    const float dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
-    if (valid && q == 0) { sv[0] += c; sv[1] += c * c; sv[2] += rv; sv[3] += rv * rv; sv[4] += (rv + c) * (rv + c); }
+    float dq = 0.f;
+    if (w < live) {
+      load_x2(xq, g.s, (size_t)col, ns, KB, q, valid);
+      const float av = valid ? g.a[col] : 0.f, rv = valid ? g.r[col] : 0.f;
+      set_row2(xq, ns, av, q);
+      layer1_keep<MT, KB>(h1, xq, SC, lr, q);
+      const float qv = head<MT>(h1, SC.w2, SC.b2[0], q);
+      const float c = valid ? tgj - qv : 0.f;
+      dq = valid ? -(2.f / (float)g.Bu) * ((g.quirk ? rbar : rv) + c) : 0.f;
+      if (valid && q == 0) { sv[0] += c; sv[1] += c * c; sv[2] += rv; sv[3] += rv * rv; sv[4] += (rv + c) * (rv + c); }
+    } else {                                    // a wave without columns in this chunk contributes zeros
+#pragma unroll
+      for (int blk = 0; blk < K2MAX; ++blk) { xq[blk][0] = 0.f; xq[blk][1] = 0.f; }
+      zero_(h1);
+    }
     __syncthreads();                            // the previous chunk's tiles have been consumed
     out_row_grad<MT>(h1, dq, g.C.H, redA, dacc, tid);      // dW2 / db2
     // dz1 in place; dW1 / db1 += dz1 x [x; 1]^T over the 128 columns (four 32-column quarters)
@@ -432,11 +446,11 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_critic_kernel(Fused2Args g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) h1[m][r] = h1[m][r] > 0.f ? wv[r] * dq : 0.f;
     }
-    for (int qq = 0; qq < 4; ++qq) {
+    for (int qq = 0; 2 * qq < live; ++qq) {     // (a quarter = the columns of waves 2 qq, 2 qq + 1)
       __syncthreads();
       if ((w >> 1) == qq) {
         stage_rows_ld<MT, LDQ>(Lm, h1, cw, q);
-        stage_x2_ld<LDQ>(Rm, xq, 16 * nR, cw, q, K0);
+        stage_x2_ld<LDQ>(Rm, xq, 16 * nR, cw, q, w < live ? K0 : -1);      // (no bias-gradient ones in a dead wave's columns)
       }
       __syncthreads();
       gemm_cols<NACC, LDQ, 2>(acc, Lm, Rm, MT, nR, w, lr, q);
@@ -480,7 +494,7 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_actor_kernel(Fused2Args g) {
   float* redA = Rm + 16 * nRa * LDP;           // [8][HPa]
   float* dacc = redA + 8 * HPa;                // [HPa]
   float* red = dacc + HPa;                     // [8]
-  const int nchunk = (g.Bu + FCOLS - 1) / FCOLS;
+  const int nt = (g.Bu + 15) / 16, t0 = blockIdx.x * g.tpw, t1 = min(t0 + g.tpw, nt);     // wave tiles of this workgroup (critic pass)
 
   load_net2(SA, g.A, HPa, LDK, tid);
   load_net2(SC, g.C, HP, LDK, tid);
@@ -491,28 +505,36 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_actor_kernel(Fused2Args g) {
   float st0 = 0.f;
   const int cw = (w & 3) * 16 + lr;
 #pragma unroll 1
-  for (int chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
-    const int col = chunk * FCOLS + w * 16 + lr;
-    const bool valid = col < g.Bu;
+  for (int tb = t0; tb < t1; tb += 8) {
+    const int live = min(8, t1 - tb);           // waves 0 .. live-1 hold columns (uniform over the workgroup)
+    const int col = (tb + w) * 16 + lr;
+    const bool valid = w < live && col < g.Bu;
     float xs[K2MAX][2];
-    load_x2(xs, g.s, (size_t)col, ns, KB, q, valid);
     f32x4 ha[MTA];
-    layer1_keep<MTA, KB>(ha, xs, SA, lr, q);
-    const float aout = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
-    float x[K2MAX][2];
+    float dza2 = 0.f;
+    if (w < live) {
+      load_x2(xs, g.s, (size_t)col, ns, KB, q, valid);
+      layer1_keep<MTA, KB>(ha, xs, SA, lr, q);
+      const float aout = tanhf(head<MTA>(ha, SA.w2, SA.b2[0], q));
+      float x[K2MAX][2];
 #pragma unroll
-    for (int blk = 0; blk < K2MAX; ++blk) { x[blk][0] = xs[blk][0]; x[blk][1] = xs[blk][1]; }
-    set_row2(x, ns, valid ? aout : 0.f, q);
-    // q = C([s; a]) and da = sum_i W1c[i][ns] * relu'(h1_i) * w2c_i * dq, tile by tile (nothing of h1 is kept)
-    const float dq = valid ? -1.f / (float)g.Bu : 0.f;
-    float qacc = 0.f, da = 0.f;
-    layer1_head_da<MT, KB>(x, SC, ns, lr, q, qacc, da);
-    qacc += __shfl_xor(qacc, 16);
-    qacc += __shfl_xor(qacc, 32);
-    da += __shfl_xor(da, 16);
-    da += __shfl_xor(da, 32);
-    if (valid && q == 0) st0 += qacc + SC.b2[0];
-    const float dza2 = da * dq * (1.f - aout * aout);
+      for (int blk = 0; blk < K2MAX; ++blk) { x[blk][0] = xs[blk][0]; x[blk][1] = xs[blk][1]; }
+      set_row2(x, ns, valid ? aout : 0.f, q);
+      // q = C([s; a]) and da = sum_i W1c[i][ns] * relu'(h1_i) * w2c_i * dq, tile by tile (nothing of h1 is kept)
+      const float dq = valid ? -1.f / (float)g.Bu : 0.f;
+      float qacc = 0.f, da = 0.f;
+      layer1_head_da<MT, KB>(x, SC, ns, lr, q, qacc, da);
+      qacc += __shfl_xor(qacc, 16);
+      qacc += __shfl_xor(qacc, 32);
+      da += __shfl_xor(da, 16);
+      da += __shfl_xor(da, 32);
+      if (valid && q == 0) st0 += qacc + SC.b2[0];
+      dza2 = da * dq * (1.f - aout * aout);
+    } else {                                    // a wave without columns in this chunk contributes zeros
+#pragma unroll
+      for (int blk = 0; blk < K2MAX; ++blk) { xs[blk][0] = 0.f; xs[blk][1] = 0.f; }
+      zero_(ha);
+    }
     __syncthreads();                            // the previous chunk's tiles have been consumed
     out_row_grad<MTA>(ha, dza2, g.A.H, redA, dacc, tid);
 #pragma unroll
@@ -521,11 +543,11 @@ __global__ __launch_bounds__(FTHREADS) void ddpg2_actor_kernel(Fused2Args g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ha[m][r] = ha[m][r] > 0.f ? wv[r] * dza2 : 0.f;
     }
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; 4 * half < live; ++half) {
       __syncthreads();
       if ((w >> 2) == half) {
         stage_rows<MTA>(Lm, ha, cw, q, -1);
-        stage_x2(Rm, xs, 16 * nRa, cw, q, ns);
+        stage_x2(Rm, xs, 16 * nRa, cw, q, w < live ? ns : -1);
       }
       __syncthreads();
       gemm_pass(acc, Lm, Rm, MTA, nRa, w, lr, q);
@@ -731,11 +753,16 @@ bool fused2_supported(const Mlp* A, const Mlp* C) {
   return (mt == 22 || mt == 9) && (mta == 2 || mta == 1);
 }
 
-// workgroups of a pass: up to CPWMAX chunks of 128 columns each once the batch exceeds one chunk per CU
-static int grid2_of(int Bu) {
-  const int nchunk = (Bu + FCOLS - 1) / FCOLS;
-  const int cpw = std::min(CPWMAX, std::max(1, (nchunk + 255) / 256));
-  return (nchunk + cpw - 1) / cpw;
+// Workgroups of a pass and wave tiles (16 columns) per workgroup.  Up to one 128-column chunk per CU: one chunk each.  Beyond
+// that the tiles are dealt EVENLY over 256 workgroups (one per CU: a pass's LDS images leave room for one), each walking
+// ceil(tpw / 8) <= CPWMAX chunks; more than CPWMAX chunks per CU: more workgroups.  (Rounds 3 - 5 dealt whole chunks strided over
+// ceil(nchunk / cpw) workgroups: C4's 784 chunks = 196 workgroups x 4.)
+static int grid2_of(int Bu, int* tpw) {
+  const int nt = (Bu + 15) / 16, nchunk = (nt + 7) / 8;
+  if (nchunk <= 256) { *tpw = 8; return nchunk; }
+  const int grid = std::max(256, (nchunk + CPWMAX - 1) / CPWMAX);
+  *tpw = (nt + grid - 1) / grid;
+  return (nt + *tpw - 1) / *tpw;
 }
 
 static Net2 net2_of(const Mlp* M) {
@@ -893,13 +920,14 @@ int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const v
                         const void* sn, int Bu, double gamma, int quirk, double grad_scale, void* loss_dev,
                         const AdamPolyak* apply) {
   const int mt = mt2_of(C->dims[1]), mta = mt2_of(A->dims[1]), nR = nr_of(C->dims[0]);
-  const int grid = grid2_of(Bu);
+  int tpw = 8;
+  const int grid = grid2_of(Bu, &tpw);
   const size_t need = slab2_floats(mt, nR, grid) * 4;
   if (C->fslab.bytes < need) PDEC_HIP(C->fslab.alloc(need));
   Fused2Args g{};
   g.C = net2_of(C); g.At = net2_of(At); g.Ct = net2_of(Ct); g.A = g.At;
   g.s = (const float*)s; g.a = (const float*)a; g.r = (const float*)r; g.t = (const float*)t; g.sn = (const float*)sn;
-  g.Bu = Bu; g.ns = A->dims[0]; g.gamma = (float)gamma; g.quirk = quirk;
+  g.Bu = Bu; g.ns = A->dims[0]; g.gamma = (float)gamma; g.quirk = quirk; g.tpw = tpw;
   g.slab = C->fslab.as<float>();
   if (quirk && C->rbar_ext) {          // reduced by the producer of r on its own stream (pdec_reward_mean)
     g.rbar = (const float*)C->rbar_ext;
@@ -918,12 +946,13 @@ int fused2_critic_grads(Mlp* A, Mlp* C, Mlp* At, Mlp* Ct, const void* s, const v
 int fused2_actor_grads(Mlp* A, Mlp* C, Mlp* At, const void* s, int Bu, double grad_scale, void* loss_dev,
                        const AdamPolyak* apply) {
   const int mt = mt2_of(C->dims[1]), mta = mt2_of(A->dims[1]), nRa = nr_of(A->dims[0]);
-  const int grid = grid2_of(Bu);
+  int tpw = 8;
+  const int grid = grid2_of(Bu, &tpw);
   const size_t need = slab2_floats(mta, nRa, grid) * 4;
   if (A->fslab.bytes < need) PDEC_HIP(A->fslab.alloc(need));
   Fused2Args g{};
   g.C = net2_of(C); g.A = net2_of(A); g.At = g.A; g.Ct = g.C;
-  g.s = (const float*)s; g.Bu = Bu; g.ns = A->dims[0];
+  g.s = (const float*)s; g.Bu = Bu; g.ns = A->dims[0]; g.tpw = tpw;
   g.slab = A->fslab.as<float>();
   int rc = dispatch2(C, g, grid, true, mt, mta);       // on the critic's stream object (shared stream, checked by the caller)
   if (rc) return rc;
