@@ -73,6 +73,7 @@ SIGNATURES = {
     "pdec_polyak": [Handle, Handle, _d],
     "pdec_adam_polyak_step": [Handle, Handle, _d, _d, _d, _d, _d],
     "pdec_policy_act_rng": [Handle, _vp, _i, _d, _d, _i, _u64, _u64, _vp],
+    "pdec_policy_act_rng_as": [Handle, _i, _vp, _i, _d, _d, _i, _u64, _u64, _vp, C.POINTER(_i)],
     "pdec_ddpg_update_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _vp],
     "pdec_ddpg_update_small": [Handle] * 4 + [_vp] * 7 + [_i, _i, _d, _d, _i, _d, _d, _vp],
     "pdec_ddpg_update_critic_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _vp],
@@ -89,6 +90,7 @@ SIGNATURES = {
     "pdec_replay_push_sa": [Handle, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _i64, _i],
     "pdec_replay_push_rt": [Handle, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _i64, _i],
     "pdec_replay_sample": [Handle, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i64, _i64, _u64, _u64, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdec_set_episode_halt": [Handle, _vp],
     "pdec_env_autoreset": [Handle] + [_vp] * 8,
     "pdec_env_random_init": [Handle, _u64, _u64, _vp],
     "pdec_capture_begin": [Handle], "pdec_capture_end": [Handle, C.POINTER(Handle)],

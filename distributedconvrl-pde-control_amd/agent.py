@@ -284,22 +284,38 @@ class CustomDDPGPolicy:
             return self.start_policy(env)
         s = env.state                                     # [B, A, ns] == columns [B*A, ns]
         cols = s.shape[0] * s.shape[1]
-        actor = self._actor_for(env.dtype, cols)
-        na = actor.dims[-1]
+        na = self.behavior_actor.model.dims[-1]
         if self._actions is None or self._actions.shape != (cols, na) or self._actions.dtype != env.dtype:
             # two buffers, alternated: the env may adopt the returned tensor without copying (PDEenv.__call__(adopt=True))
             self._action_ring = [torch.empty((cols, na), dtype=env.dtype, device=env.device) for _ in range(2)]
             self._actions = self._action_ring[0]
         self._action_ring.reverse()
         self._actions = self._action_ring[0]
-        # actor forward + randn(rng, ...) .* act_noise + clamp (:189-204): one launch, noise drawn in-kernel from
-        # the counter stream (seed, offset) -- the same numbers pdec_randn would produce
-        _lib.check(self.lib.pdec_policy_act_rng(actor.handle, _lib.ptr(s), cols, float(self.act_noise),
-                                                float(self.act_limit), int(bool(learning)), self._noise_seed,
-                                                self._noise_off, _lib.ptr(self._actions)))
+        self.act_into(s, cols, env.dtype, self._actions, learning)
+        return self._actions.view(env._ashape)
+
+    def act_into(self, state, cols, dtype, out, learning=True):
+        """actor forward + randn(rng, ...) .* act_noise + clamp (:189-204) of `cols` state columns of type `dtype` into `out`
+        [cols, na]: one launch, noise drawn in-kernel from the counter stream (seed, offset) -- the same numbers pdec_randn
+        would produce.  An environment that computes in another type than the networks (the reference: fp64 fields, Float32
+        nets) is served without a promoted copy of the actor where the library's few-column acting kernel covers the case
+        (pdec_policy_act_rng_as), through a promoted clone otherwise; bit-identical either way."""
+        m = self.behavior_actor.model
+        na = m.dims[-1]
+        served = False
+        if dtype != m.dtype:
+            flag = C.c_int(0)
+            _lib.check(self.lib.pdec_policy_act_rng_as(m.handle, _lib.dtype_code(dtype), _lib.ptr(state), cols, float(self.act_noise),
+                                                       float(self.act_limit), int(bool(learning)), self._noise_seed, self._noise_off,
+                                                       _lib.ptr(out), C.byref(flag)))
+            served = bool(flag.value)
+        if not served:
+            actor = self._actor_for(dtype, cols)
+            _lib.check(self.lib.pdec_policy_act_rng(actor.handle, _lib.ptr(state), cols, float(self.act_noise),
+                                                    float(self.act_limit), int(bool(learning)), self._noise_seed,
+                                                    self._noise_off, _lib.ptr(out)))
         if learning:
             self._noise_off += (cols * na + 3) // 4
-        return self._actions.view(env._ashape)
 
     # ---- update!(policy, batch) (src/PDEagent.jl:363-418), fused on the device
     def update(self, batch, before_actor_half=None):

@@ -53,6 +53,10 @@ struct Object {
                        // inside one event pair, so the per-launch figure is free of event-record overhead
                        // and comparable with rocprofv3's kernel-trace duration
   std::map<std::string, ProfEntry> profs;
+  // pdec_set_episode_halt: device flag of a speculatively issued episode (run.py, device-side episodes).  The launches that
+  // change persistent learner state through this handle -- replay pushes, the small-batch DDPG update -- do nothing once it is
+  // raised, and the POST_ACT push raises it when the environment reported the end of the episode (B = 1)
+  int* halt = nullptr;
   explicit Object(Kind k) : kind(k) {}
   virtual ~Object();
 };

@@ -971,6 +971,117 @@ int pdec_ddpg_update_actor_async(pdec_handle hA, pdec_handle hC, pdec_handle hAt
                             losses_dev);
 }
 
+
+}  // extern "C"
+
+// ---- acting for FEW columns in one launch (the reference's own shape: one trajectory, A columns; src/PDEagent.jl:175-209)
+// The generic path is pack + one GEMM launch per layer + randn + noise / clamp -- and, when the environment computes in fp64
+// while the networks are Float32 (as in the reference), a promoted copy of the parameters first: seven launches of ~5.5 us for
+// a few hundred multiply-adds.  This kernel does the same arithmetic in ONE workgroup: parameters of type TP promoted to T on
+// the fly (exact), activations [feature][column] in LDS, per element acc = sum_k w x in ascending k from zero, then + bias and
+// the activation -- the order of gemm_kernel's epilogue --, the Philox / Box-Muller draw of randn_kernel for element
+// column * outputs + row, then v += noise * act_noise and the clamp of act_noise_clamp_kernel.
+#define SMALL_ACT_MAXL 4
+struct SmallActArgs {
+  int L, cols, maxw, learning, nrows;
+  int dims[SMALL_ACT_MAXL + 1], acts[SMALL_ACT_MAXL], woff[SMALL_ACT_MAXL], boff[SMALL_ACT_MAXL];
+  const void* p;
+  double act_noise, lim;
+  uint64_t seed, offset;
+  const uint64_t* ctr_cur;
+  uint64_t* ctr_next;
+  uint64_t ctr_inc;
+};
+template <class T, class TP>
+__global__ __launch_bounds__(256) void small_act_kernel(SmallActArgs g, const T* __restrict__ state, T* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char small_act_smem[];
+  T* X0 = reinterpret_cast<T*>(small_act_smem);
+  T* X1 = X0 + (size_t)g.maxw * g.cols;
+  const TP* p = static_cast<const TP*>(g.p);
+  const int tid = threadIdx.x, cols = g.cols;
+  uint64_t offset = g.offset;
+  if (g.ctr_cur) {       // device-resident noise counter (pdec_policy_act_rng_dev)
+    offset += *g.ctr_cur;
+    if (tid == 0) *g.ctr_next = offset + g.ctr_inc;
+  }
+  const int ns = g.dims[0];
+  for (int i = tid; i < ns * cols; i += 256) {
+    const int c = i / ns, k = i - c * ns;
+    X0[k * cols + c] = state[i];
+  }
+  __syncthreads();
+  T* xin = X0;
+  T* xout = X1;
+  for (int l = 0; l < g.L; ++l) {
+    const int in = g.dims[l], on = g.dims[l + 1];
+    const TP* W = p + g.woff[l];
+    const TP* b = p + g.boff[l];
+    for (int i = tid; i < on * cols; i += 256) {
+      const int j = i / cols, c = i - j * cols;
+      T acc = 0;
+      for (int k = 0; k < in; ++k) acc += (T)W[j * in + k] * xin[k * cols + c];
+      xout[j * cols + c] = apply_act<T>(acc + (T)b[j], g.acts[l]);
+    }
+    __syncthreads();
+    T* t = xin; xin = xout; xout = t;
+  }
+  const int no = g.dims[g.L];
+  const T an = (T)g.act_noise, lim = (T)g.lim;
+  for (int i = tid; i < no * cols; i += 256) {       // i = column * outputs + row: the element index of the noise stream
+    const int c = i / no, f = i - c * no;
+    T v = xin[f * cols + c];
+    if (g.learning && f < g.nrows) {
+      const uint64_t ctr = offset + (uint64_t)(i >> 2);
+      uint32_t ph[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+      philox4x32(ph, (uint32_t)g.seed, (uint32_t)(g.seed >> 32));
+      const int h = (i >> 1) & 1;
+      const double sc = 1.0 / 4294967296.0;
+      const double u1 = ((double)ph[2 * h] + 0.5) * sc, u2 = ((double)ph[2 * h + 1] + 0.5) * sc;
+      const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+      const T z = (T)((i & 1) ? rad * sin(ang) : rad * cos(ang));
+      v += z * an;
+    }
+    v = v < -lim ? -lim : (v > lim ? lim : v);
+    out[i] = v;
+  }
+}
+
+// does the single-launch form serve this actor at `cols` columns of type `dtype`?  (the fused MFMA acting kernels keep fp32
+// actors at fp32 states; PDEC_SMALL_ACT=0: the generic launch sequence, for A/B tests)
+static bool small_act_ok(const Mlp* M, int dtype, int cols) {
+  static const bool off = [] { const char* e = getenv("PDEC_SMALL_ACT"); return e && e[0] == '0'; }();
+  if (off || M->L > SMALL_ACT_MAXL || cols < 1) return false;
+  if (!(M->dtype == dtype || (M->dtype == PDEC_F32 && dtype == PDEC_F64))) return false;
+  int maxw = 1;
+  for (int l = 0; l <= M->L; ++l) maxw = std::max(maxw, M->dims[l]);
+  return (size_t)2 * maxw * cols * dtype_size(dtype) <= 48 * 1024;
+}
+
+static int small_act(Mlp* M, int dtype, const void* state, int cols, double act_noise, double act_limit, int learning, uint64_t seed,
+                     uint64_t offset, void* actions_out, const uint64_t* ctr_cur, uint64_t* ctr_next, uint64_t ctr_inc) {
+  SmallActArgs g{};
+  g.L = M->L; g.cols = cols; g.learning = learning;
+  g.maxw = 1;
+  for (int l = 0; l <= M->L; ++l) { g.dims[l] = M->dims[l]; g.maxw = std::max(g.maxw, M->dims[l]); }
+  for (int l = 0; l < M->L; ++l) { g.acts[l] = M->acts[l]; g.woff[l] = (int)M->w_off[l]; g.boff[l] = (int)M->b_off[l]; }
+  g.nrows = M->noise_rows < 0 ? M->dims[M->L] : M->noise_rows;
+  g.p = M->params.p;
+  g.act_noise = act_noise; g.lim = act_limit; g.seed = seed; g.offset = offset;
+  g.ctr_cur = ctr_cur; g.ctr_next = ctr_next; g.ctr_inc = ctr_inc;
+  const size_t lds = (size_t)2 * g.maxw * cols * dtype_size(dtype);
+  ProfScope ps(M, "small_act");
+  if (dtype == PDEC_F64 && M->dtype == PDEC_F32)
+    hipLaunchKernelGGL((small_act_kernel<double, float>), dim3(1), dim3(256), lds, M->stream, g, (const double*)state, (double*)actions_out);
+  else if (dtype == PDEC_F64)
+    hipLaunchKernelGGL((small_act_kernel<double, double>), dim3(1), dim3(256), lds, M->stream, g, (const double*)state, (double*)actions_out);
+  else
+    hipLaunchKernelGGL((small_act_kernel<float, float>), dim3(1), dim3(256), lds, M->stream, g, (const float*)state, (float*)actions_out);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+extern "C" {
+
 static int policy_act_rng_impl(pdec_handle actor, Mlp* M, const void* state, int cols, double act_noise, double act_limit,
                                int learning, uint64_t seed, uint64_t offset, void* actions_out, const uint64_t* ctr_cur,
                                uint64_t* ctr_next, uint64_t ctr_inc) {
@@ -978,6 +1089,8 @@ static int policy_act_rng_impl(pdec_handle actor, Mlp* M, const void* state, int
     return fused_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, ctr_cur, ctr_next, ctr_inc);
   if (fused2_act_supported(M, cols))
     return fused2_policy_act(M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, ctr_cur, ctr_next, ctr_inc);
+  if (small_act_ok(M, M->dtype, cols))
+    return small_act(M, M->dtype, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, ctr_cur, ctr_next, ctr_inc);
   void* noise = nullptr;
   const size_t n = (size_t)cols * M->dims[M->L];
   if (learning || ctr_cur) {
@@ -999,6 +1112,21 @@ int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double a
   GET_MLP(M, actor);
   PDEC_REQUIRE(state && actions_out && cols >= 1, "pdec_policy_act_rng: null/empty");
   return policy_act_rng_impl(actor, M, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, nullptr, nullptr, 0);
+}
+
+// agent(env) for an environment that computes in `state_dtype` with an actor of another parameter type (the reference: fp64
+// fields, Float32 networks) WITHOUT a promoted copy of the actor: *served = 1 and the action is enqueued when the single-launch
+// form covers the case, *served = 0 (nothing enqueued) otherwise -- the caller then acts through a promoted clone.
+int pdec_policy_act_rng_as(pdec_handle actor, int state_dtype, const void* state, int cols, double act_noise, double act_limit,
+                           int learning, uint64_t seed, uint64_t offset, void* actions_out, int* served) {
+  GET_MLP(M, actor);
+  PDEC_REQUIRE(served, "pdec_policy_act_rng_as: null");
+  PDEC_REQUIRE(state_dtype == PDEC_F32 || state_dtype == PDEC_F64, "pdec_policy_act_rng_as: bad dtype %d", state_dtype);
+  *served = 0;
+  if (!small_act_ok(M, state_dtype, cols) || M->dtype == state_dtype) return PDEC_OK;
+  PDEC_REQUIRE(state && actions_out, "pdec_policy_act_rng_as: null");
+  *served = 1;
+  return small_act(M, state_dtype, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, nullptr, nullptr, 0);
 }
 
 static int ensure_noise_ctr(Mlp* M) {

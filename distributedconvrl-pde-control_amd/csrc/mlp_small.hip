@@ -35,6 +35,7 @@ struct SmallArgs {
   double eta_a, eta_c, b1, b2, eps;
   BpArgs bpA, bpC;          // device-resident ADAM beta powers of the actor / critic (read cur, thread 0 writes next)
   float* losses;            // [2]: critic loss, actor loss of the last loop
+  const int* halt;          // != null and *halt != 0: the launch leaves the learner as it is (pdec_set_episode_halt on the critic)
   // pde_sample on the device (src/PDEagent.jl:317-321): when smp_on, the slots are not read from i_s / i_rt / i_sn but
   // drawn here from the Philox counter stream (seed, offset): draw k (= loop * Bu + column) is word k % 4 of counter
   // offset + k / 4, ind = (word * hi) >> 32 in [0, hi), logical index lg = base + ind,
@@ -183,6 +184,10 @@ __global__ __launch_bounds__(SM_THREADS) void ddpg_small_kernel(SmallArgs g_in) 
   float* qt = q; q += Bu;
   float* red = q;                         // [4]
   double bpa0 = g.bpA.cur[0], bpa1 = g.bpA.cur[1], bpc0 = g.bpC.cur[0], bpc1 = g.bpC.cur[1];
+  if (g.halt && *g.halt) {     // the episode ended before this step: only the beta powers move on to the slot the host flipped to
+    if (tid == 0) { g.bpA.next[0] = bpa0; g.bpA.next[1] = bpa1; g.bpC.next[0] = bpc0; g.bpC.next[1] = bpc1; }
+    return;
+  }
   const float omr = 1.0f - g.rho;
   if (g.smp_on) {
     int* tab = reinterpret_cast<int*>(sm + g.smp_lds);
@@ -397,6 +402,13 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   const SmallArgs& g = a_in.g;
   extern __shared__ __align__(16) float sm[];
   const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
+  if (g.halt && *g.halt) {     // the episode ended before this step (see ddpg_small_kernel)
+    if (tid == 0) {
+      g.bpA.next[0] = g.bpA.cur[0]; g.bpA.next[1] = g.bpA.cur[1];
+      g.bpC.next[0] = g.bpC.cur[0]; g.bpC.next[1] = g.bpC.cur[1];
+    }
+    return;
+  }
   const int Bu = EXACT ? BUT : g.Bu, ns = EXACT ? KA : g.ns, K0 = ns + 1, nC = a_in.nC, nA = a_in.nA;
   const bool isC = tid < nC, isA = tid < nA;
   // the minibatches of ALL loops are fetched into LDS up front (pde_fetch!, src/PDEagent.jl:323-340): the replay traces
@@ -721,6 +733,7 @@ static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hA
   g.eta_a = eta_actor; g.eta_c = eta_critic; g.b1 = 0.9; g.b2 = 0.999; g.eps = 1e-8;
   if ((rc = bp_begin(A, g.b1, g.b2, &g.bpA)) || (rc = bp_begin(C, g.b1, g.b2, &g.bpC))) return rc;
   g.losses = (float*)losses_dev;
+  g.halt = C->halt;
   const size_t tab_floats = smp ? (size_t)3 * loops * Bu : 0;
   if (smp) {
     const int64_t hi = smp->n_valid - smp->stride;           // inds in 1:length(t)-number_actuators (src/PDEagent.jl:318)

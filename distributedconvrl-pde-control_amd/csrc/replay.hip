@@ -16,7 +16,9 @@ namespace pdec {
 // rows start .. start + n - 1 (mod cap) of two circular traces; the sources are [n][wa] / [n][wb] of type T
 template <class T>
 __global__ void replay_push2_kernel(float* __restrict__ ta, int wa, const T* __restrict__ sa, float* __restrict__ tb, int wb,
-                                    const T* __restrict__ sb, long long cap, long long start, long long n) {
+                                    const T* __restrict__ sb, long long cap, long long start, long long n,
+                                    const int* __restrict__ halt) {
+  if (halt && *halt) return;          // the episode ended at an earlier step of a speculatively issued episode
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long na_ = n * wa, nb_ = n * wb;
   if (i < na_) {
@@ -32,12 +34,20 @@ __global__ void replay_push2_kernel(float* __restrict__ ta, int wa, const T* __r
 template <class T>
 __global__ void replay_push_rt_kernel(float* __restrict__ tr, float* __restrict__ tt, const T* __restrict__ r,
                                       const int32_t* __restrict__ done, int cols_per_traj, int force, long long cap,
-                                      long long start, long long n) {
+                                      long long start, long long n, int* __restrict__ halt) {
+  // halt (pdec_set_episode_halt; single-block launches only, checked on the host): nothing is pushed once the episode has
+  // ended; the push of the step that ends it -- its terminal transition, src/PDEagent.jl:276-289 -- still happens and raises it
+  if (halt && *halt) return;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const long long slot = (start + i) % cap;
-  tr[slot] = (float)r[i];
-  tt[slot] = (force || (done && done[i / cols_per_traj] != 0)) ? 1.f : 0.f;
+  if (i < n) {
+    const long long slot = (start + i) % cap;
+    tr[slot] = (float)r[i];
+    tt[slot] = (force || (done && done[i / cols_per_traj] != 0)) ? 1.f : 0.f;
+  }
+  if (halt) {
+    __syncthreads();                  // every thread has read *halt before one of them writes it
+    if (threadIdx.x == 0 && done && done[0] != 0) *halt = 1;
+  }
 }
 
 // ------------------------------------------------------------------ pde_sample + pde_fetch!
@@ -215,10 +225,10 @@ int pdec_replay_push_sa(pdec_handle any_handle, void* state_trace, void* action_
   ProfScope ps(o, "replay_push_sa");
   if (dtype == PDEC_F64)
     hipLaunchKernelGGL((replay_push2_kernel<double>), grid, block, 0, o->stream, (float*)state_trace, ns, (const double*)s,
-                       (float*)action_trace, na, (const double*)a, (long long)capacity_rows, (long long)start, (long long)n);
+                       (float*)action_trace, na, (const double*)a, (long long)capacity_rows, (long long)start, (long long)n, o->halt);
   else
     hipLaunchKernelGGL((replay_push2_kernel<float>), grid, block, 0, o->stream, (float*)state_trace, ns, (const float*)s,
-                       (float*)action_trace, na, (const float*)a, (long long)capacity_rows, (long long)start, (long long)n);
+                       (float*)action_trace, na, (const float*)a, (long long)capacity_rows, (long long)start, (long long)n, o->halt);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }
@@ -230,17 +240,27 @@ int pdec_replay_push_rt(pdec_handle any_handle, void* reward_trace, void* termin
   PDEC_REQUIRE(reward_trace && terminal_trace && r && capacity_rows >= 1 && start >= 0 && n >= 0 && n <= capacity_rows &&
                cols_per_traj >= 1, "pdec_replay_push_rt: bad argument");
   if (n == 0) return PDEC_OK;
+  PDEC_REQUIRE(!o->halt || n <= 256, "pdec_replay_push_rt: an episode halt flag (pdec_set_episode_halt) needs a single-block push (n <= 256)");
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   ProfScope ps(o, "replay_push_rt");
   if (dtype == PDEC_F64)
     hipLaunchKernelGGL((replay_push_rt_kernel<double>), grid, block, 0, o->stream, (float*)reward_trace, (float*)terminal_trace,
                        (const double*)r, done_flags, cols_per_traj, force_terminal, (long long)capacity_rows, (long long)start,
-                       (long long)n);
+                       (long long)n, o->halt);
   else
     hipLaunchKernelGGL((replay_push_rt_kernel<float>), grid, block, 0, o->stream, (float*)reward_trace, (float*)terminal_trace,
                        (const float*)r, done_flags, cols_per_traj, force_terminal, (long long)capacity_rows, (long long)start,
-                       (long long)n);
+                       (long long)n, o->halt);
   PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
+}
+
+// Speculatively issued episodes (run.py): `flag` (device int32, 0 at the episode's start) is attached to the handle; see
+// Object::halt.  NULL detaches.
+int pdec_set_episode_halt(pdec_handle any_handle, int32_t* flag) {
+  Object* o = lookup(any_handle);
+  if (!o) { set_error("pdec_set_episode_halt: bad handle"); return PDEC_E_HANDLE; }
+  o->halt = flag;
   return PDEC_OK;
 }
 

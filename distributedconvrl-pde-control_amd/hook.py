@@ -29,6 +29,7 @@ class PDEhook:
         self.log_trajectory = log_trajectory
         self.init_seed, self._init_off = int(init_seed), 0      # Philox stream of the device-side initialisers
         self._reward_dev, self._rows_dev, self._ret_dev = None, [], None
+        self._rows_bulk = None       # (steps, action [n, ...], p, y, reward): a whole episode's rows in four device tensors
 
     def _flush(self, env):
         """bring the episode's device-side accumulators to the host (one synchronisation per episode)"""
@@ -39,7 +40,13 @@ class PDEhook:
         if self.log_trajectory == "best" and self._ret_dev is not None:
             pick = int(self._ret_dev.argmax().item())            # one scalar per episode crosses to the host
         self._ret_dev = None
-        for steps, a, p, y, r in self._rows_dev:
+        rows = self._rows_dev
+        if self._rows_bulk is not None:      # run(device_episodes=True): one device->host copy per array instead of one per row
+            steps_l, ab, pb, yb, rb = self._rows_bulk
+            ab, pb, yb, rb = (t.cpu() for t in (ab, pb, yb, rb))
+            rows = rows + [(st, ab[i], pb[i], yb[i], rb[i]) for i, st in enumerate(steps_l)]
+            self._rows_bulk = None
+        for steps, a, p, y, r in rows:
             if pick is not None:
                 a, p, y, r = a[pick], p[pick], y[pick], r[pick]
             a, p, y = (t.cpu().numpy().astype(np.float64) for t in (a, p, y))

@@ -27,7 +27,30 @@ class StopAfterEpisodeWithMinSteps:
         return stop
 
 
-def run(agent, env, stop_condition, hook, overlap=None):
+def device_episodes_ok(agent, env, stop_condition, hook):
+    """can `run` issue whole episodes without reading the environment's flags back after every step (_run_device_episodes)?
+    The reference's own shape: ONE trajectory (any environment kind: every output of a step goes to a per-step slot), the
+    small-batch update with minibatches drawn on the device, the reference's zero start policy, a stop condition that fires at
+    episode ends."""
+    from .agent import Agent, CircularArraySARTTrajectory, CustomDDPGPolicy, ZeroPolicy
+    from .hook import PDEhook
+    if not isinstance(agent, Agent) or not isinstance(getattr(agent, "policy", None), CustomDDPGPolicy) or type(hook) is not PDEhook:
+        return False
+    pol, tr, setup = agent.policy, agent.trajectory, env.setup
+    if type(stop_condition) not in (StopAfterEpisode, StopAfterEpisodeWithMinSteps):
+        return False
+    if env.B != 1 or env.autoreset or getattr(setup, "memory_size", 0):
+        return False
+    if getattr(env, "stream", None) is None or getattr(tr, "stream", None) is None or type(tr) is not CircularArraySARTTrajectory:
+        return False
+    if getattr(tr, "_h", None) is None or pol.sampling != "device" or not pol.small_update_ok() or pol.memory_size:
+        return False
+    if not (type(pol.start_policy) is ZeroPolicy or pol.start_steps <= 0) or hook.log_trajectory != 0:
+        return False
+    return tr.stride <= 256 and agent.after_push is None
+
+
+def run(agent, env, stop_condition, hook, overlap=None, device_episodes=None):
     """RL.jl's `run(agent, env, stop_condition, hook)`: the stage order of every control step is the reference's
     (action = agent(env); PRE_ACT: push + update; env(action); POST_ACT: push r, t).
 
@@ -38,8 +61,20 @@ def run(agent, env, stop_condition, hook, overlap=None):
     step waits for the acting kernel and the PRE_ACT push (which read env.state) but not for the update; the POST_ACT push and
     the next acting kernel wait for the env step.  Same kernels, same arguments, same order per stream: results are bit-identical
     to the one-stream loop.  (For the reference-shaped single-trajectory loops the 20-update launch and the PDE step are of
-    similar length: KS22 4.8 k -> 7+ k env-steps/s.)"""
+    similar length: KS22 4.8 k -> 7+ k env-steps/s.)
+
+    device_episodes (default: automatic, whenever device_episodes_ok): the control steps of a whole episode are ENQUEUED
+    without waiting for any of them -- the one thing the host needs from the device per step, `is_terminated(env)`, is decided
+    on the device (a halt flag, pdec_set_episode_halt) and read back once per episode.  Same kernels, same arguments, same
+    order: bit-identical to the stage loop (tests/test_gpu_training.py)."""
     s_env, s_upd = getattr(env, "stream", None), getattr(getattr(agent, "trajectory", None), "stream", None)
+    if device_episodes is None:
+        device_episodes = device_episodes_ok(agent, env, stop_condition, hook)
+    elif device_episodes and not device_episodes_ok(agent, env, stop_condition, hook):
+        raise ValueError("run(device_episodes=True): this agent / environment / stop condition / hook needs the stage loop "
+                         "(see device_episodes_ok)")
+    if device_episodes:
+        return _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd)
     two = s_env is not None and s_upd is not None and s_env.cuda_stream != s_upd.cuda_stream
     if overlap is None:
         overlap = two
@@ -92,6 +127,160 @@ def run(agent, env, stop_condition, hook, overlap=None):
         hook(POST_EXPERIMENT_STAGE, agent, env)
     finally:
         agent.after_push = prev_hook
+    return hook
+
+
+class _EpisodeLogs:
+    """per-step output slots of one episode: every launch of step t writes into slot t (t + 1 for what the NEXT step reads),
+    so a step issued behind the end of the episode overwrites nothing that is still needed"""
+
+    def __init__(self, env, T):
+        import torch
+        kw = dict(dtype=env.dtype, device=env.device)
+        self.T = T
+        self.y = torch.zeros((T + 1,) + env._yshape, **kw)
+        self.state = torch.zeros((T + 1,) + env._sshape, **kw)
+        self.action = torch.zeros((T + 1,) + env._ashape, **kw)       # slot 0 = action0, slot t + 1 = the action of step t
+        self.p = torch.zeros((T,) + env._pshape, **kw)
+        self.reward = torch.zeros((T, env.B, env.setup.reward_len), **kw)
+        self.done = torch.zeros(T, dtype=torch.int32, device=env.device)
+        self.halt = torch.zeros(1, dtype=torch.int32, device=env.device)
+
+
+def _episode_steps(env):
+    """control steps until time >= te, with the floating-point sum the step loop makes (50 x 0.1 != 5.0)"""
+    t, n = 0.0, 0
+    while True:
+        t += env.dt
+        n += 1
+        if t >= env.te or n > 100000:
+            return n
+
+
+def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
+    """RL.jl's run loop with every episode issued in one go (module docstring of run / device_episodes_ok).  Stream protocol of
+    the overlapped loop: acting kernel, PRE_ACT push and the update on the networks' stream, the env step on the environment's
+    beside the update, POST_ACT push behind the env step.  What the host knows in advance -- ring positions, Philox offsets,
+    the update trigger of src/PDEagent.jl:354-355 -- is passed as scalars, exactly the values the stage loop would pass; the
+    one thing it does not know, whether a step blew the trajectory up, is the device's halt flag: the POST_ACT push of that
+    step raises it and the pushes / updates of the later steps do nothing, all their other outputs go to per-step slots.  One
+    read-back per episode tells how many steps counted; the host counters are set to that."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from . import _lib
+    from .env import _on_stream
+
+    pol, tr, lib = agent.policy, agent.trajectory, env.lib
+    two = s_env.cuda_stream != s_upd.cuda_stream
+    ns, A = env.setup.state_shape
+    cols, na = env.B * A, env._ashape[-1]
+    T = _episode_steps(env)
+    logs = getattr(env, "_episode_logs", None)
+    if logs is None or logs.T != T:
+        with _on_stream(s_env):
+            logs = env._episode_logs = _EpisodeLogs(env, T)
+    ev_act, ev_env = torch.cuda.Event(), torch.cuda.Event()
+    P = _lib.ptr
+    np_dt = np.float64 if env.dtype == torch.float64 else np.float32
+
+    def join():
+        if two:
+            s_upd.wait_stream(s_env)
+            s_env.wait_stream(s_upd)
+
+    class _Ended:                      # what the stop condition sees of the environment at a step
+        def __init__(self, ended):
+            self.ended = ended
+
+        def is_terminated(self):
+            return self.ended
+
+    def episode():
+        """enqueue the T control steps, read back once, settle the host state; returns True when the stop condition fired"""
+        with _on_stream(s_env):
+            logs.y[0].copy_(env.y)
+            logs.state[0].copy_(env.state)
+            logs.done.zero_()
+            logs.halt.zero_()
+        join()
+        start = (pol.update_step, tr.n_sa, tr.n_rt, pol._noise_off, pol._sample_off)
+        marks = []                                        # per step: (noise draws so far, sample offset so far)
+        _lib.check(lib.pdec_set_episode_halt(tr._h, P(logs.halt)))
+        try:
+            with _on_stream(s_upd):
+                for t in range(T):
+                    pol.update_step += 1
+                    a_t = logs.action[t + 1]
+                    if pol.update_step > pol.start_steps:                      # agent(env): src/PDEagent.jl:175-209
+                        pol.act_into(logs.state[t], cols, env.dtype, a_t.view(cols, na))
+                    else:
+                        a_t.zero_()                                            # ZeroPolicy
+                    tr.push_sa(logs.state[t].view(cols, ns), a_t.view(cols, na))          # PRE_ACT :254-274
+                    if two:
+                        ev_act.record(s_upd)
+                        s_env.wait_event(ev_act)
+                    agent._maybe_update()                                      # :342-361
+                    _lib.check(lib.pdec_env_step(env.handle, P(logs.y[t]), P(a_t), P(logs.action[t]), P(logs.state[t]), P(logs.y[t + 1]),
+                                                 P(logs.p[t]), P(logs.state[t + 1]), P(logs.reward[t]), P(logs.done[t:t + 1])))
+                    if two:
+                        ev_env.record(s_env)
+                        s_upd.wait_event(ev_env)
+                    tr.push_rt_flags(logs.reward[t].view(-1), logs.done[t:t + 1], A, t == T - 1)      # POST_ACT :276-289
+                    marks.append((pol._noise_off, pol._sample_off))
+                join()
+                # the per-step episode reward of PDEhook (src/PDEhook.jl:51-63): mean over the actuators, summed over the steps
+                means = logs.reward.reshape(T, -1).mean(dim=1)
+                flags = logs.done.cpu().numpy()                                # the one read-back (waits for the whole episode)
+        finally:
+            _lib.check(lib.pdec_set_episode_halt(tr._h, None))
+        bad = np.flatnonzero(flags)
+        n = int(bad[0]) + 1 if bad.size and bad[0] < T - 1 else T
+        # ---- settle the host state at n executed steps
+        pol.update_step = start[0] + n
+        tr.n_sa, tr.n_rt = start[1] + n * cols, start[2] + n * cols
+        pol._noise_off, pol._sample_off = marks[n - 1]
+        env.y, env.state, env.prev_state = logs.y[n], logs.state[n], logs.state[n - 1]
+        env.action, env._action_prev = logs.action[n], logs.action[n - 1]
+        env._adopted.update((env.action.data_ptr(), env._action_prev.data_ptr()))          # views of the log: never written by the env
+        env.p, env.reward, env._done_flags = logs.p[n - 1], logs.reward[n - 1], logs.done[n - 1:n]
+        env.steps = n
+        env.time = 0.0
+        for _ in range(n):
+            env.time += env.dt
+        env._done_stale = True
+        # ---- the hook's POST_ACT bookkeeping of the n steps (src/PDEhook.jl:51-63)
+        m = means[:n].cpu().numpy().astype(np_dt)
+        acc = m[0]
+        for v in m[1:]:
+            acc = np_dt(acc + v)
+        hook.reward += float(acc)
+        if hook.collect_bestDF:
+            hook._rows_bulk = (list(range(1, n + 1)), logs.action[1:n + 1, 0], logs.p[:n, 0], logs.y[1:n + 1, 0], logs.reward[:n, 0])
+        fired = False
+        for i in range(n):
+            fired = stop_condition(agent, _Ended(i == n - 1)) or fired
+        return fired
+
+    hook(PRE_EXPERIMENT_STAGE, agent, env)
+    agent(PRE_EXPERIMENT_STAGE, env)
+    is_stop = False
+    while not is_stop:
+        join()
+        env.reset()
+        join()
+        agent(PRE_EPISODE_STAGE, env)
+        hook(PRE_EPISODE_STAGE, agent, env)
+        join()
+        is_stop = episode()
+        if env.is_terminated():
+            join()
+            agent(POST_EPISODE_STAGE, env)
+            hook(POST_EPISODE_STAGE, agent, env)
+    join()
+    hook(POST_EXPERIMENT_STAGE, agent, env)
     return hook
 
 

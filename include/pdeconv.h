@@ -290,6 +290,13 @@ int pdec_policy_act(pdec_handle actor, const void* state, const void* noise, int
 int pdec_mlp_set_noise_rows(pdec_handle actor, int rows);
 int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double act_noise, double act_limit,
                         int learning, uint64_t seed, uint64_t offset, void* actions_out);
+/* agent(env) where the environment computes in `state_dtype` and the actor keeps parameters of another type -- the reference's
+ * case: fp64 fields, Float32 networks (src/PDEagent.jl:183-207 promotes in the broadcast) -- without a promoted copy of the
+ * actor: when the single-launch acting kernel for few columns covers the case (<= 4 layers, activations of both buffers within
+ * 48 KB of LDS) the action is enqueued and *served = 1; otherwise nothing is enqueued, *served = 0, and the caller acts through a
+ * clone of the actor in `state_dtype` (pdec_mlp_copy + pdec_policy_act_rng).  Same arithmetic, bit for bit, either way. */
+int pdec_policy_act_rng_as(pdec_handle actor, int state_dtype, const void* state, int cols, double act_noise, double act_limit,
+                           int learning, uint64_t seed, uint64_t offset, void* actions_out, int* served);
 /* the same with the noise counter kept ON THE DEVICE (one per actor handle): the kernel reads the current counter and
  * one of its threads stores the advanced value (+ ceil(cols*na/4) when learning), so no launch argument depends on how
  * many calls came before -- the form a captured HIP graph of the control step replays (pdec_capture_begin).
@@ -416,6 +423,15 @@ int pdec_replay_sample(pdec_handle any_handle, const void* state_trace, const vo
                        const void* terminal_trace, int ns, int na, int64_t capacity, int stride, int64_t n_valid, int64_t n_rt,
                        uint64_t seed, uint64_t offset, int Bu, void* s_out, void* a_out, void* r_out, void* t_out,
                        void* sn_out, int32_t* slots_out);
+
+/* Speculatively issued episodes (run.py: the control steps of a whole episode are enqueued without reading the environment's
+ * `done` flag back after every step, src/PDEenv.jl:226-240 / RL.jl's `while !is_terminated(env)`).  `flag` is a device int32,
+ * zero at the episode's start.  Attached to a handle, it makes the launches issued THROUGH that handle that change persistent
+ * learner state no-ops once it is raised: pdec_replay_push_sa / pdec_replay_push_rt (the handle passed as any_handle) and
+ * pdec_ddpg_update_small(_rng) (the behaviour critic's handle; the ADAM beta powers move on unchanged).  pdec_replay_push_rt
+ * raises it after pushing a transition whose done_flags[0] != 0 (B = 1: the step that ends the episode is pushed, nothing
+ * after it).  Everything else a later step writes goes to per-step buffers the host ignores.  NULL detaches. */
+int pdec_set_episode_halt(pdec_handle any_handle, int32_t* flag);
 
 /* Batched environments (B > 1; the reference has B = 1 and ends the episode at the first blow-up, src/PDEenv.jl:226-240):
  * same-step reset of every trajectory whose done flag is raised -- y, state and action rows are overwritten by their

@@ -53,6 +53,47 @@ def test_acting_path_is_fp64_with_fp32_weights(pkg):
     assert a.dtype == torch.float64 and np.abs(a.cpu().numpy().reshape(-1) - ref.reshape(-1)).max() <= 1e-13
 
 
+@pytest.mark.parametrize("which", ["ks22", "ks200", "keller_segel", "ks22_three_layer", "fluid"])
+def test_few_column_acting_kernel_equals_the_generic_launch_sequence(pkg, which):
+    """Round 6: agent(env) for the reference's own shape (ONE trajectory: A columns; fp64 fields, Float32 networks,
+    src/PDEagent.jl:183-207) is ONE launch -- parameters promoted on the fly, no promoted copy of the actor -- instead of the
+    seven of the generic path (parameter copy, pack, a GEMM per layer, randn, noise + clamp).  Same arithmetic: the actions
+    equal, BIT FOR BIT, what the generic sequence gives through a promoted clone (pdec_mlp_copy -> pdec_randn -> pdec_policy_act),
+    with and without exploration noise, in fp64 and for fp32 states with the actor's own type."""
+    import ctypes as C
+    setup = {"ks22": lambda: pkg.KSSetup.KS22(), "ks200": lambda: pkg.KSSetup.KS200(), "keller_segel": lambda: pkg.KellerSegelSetup(),
+             "ks22_three_layer": lambda: pkg.KSSetup.KS22(drop_middle_layer=False), "fluid": lambda: pkg.FluidSetup(nx=64)}[which]()
+    ns, A = setup.state_shape
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(3), start_steps=-1)
+    pol, L = agent.policy, pkg._lib
+    m = pol.behavior_actor.model
+    na = m.dims[-1]
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float64, torch.float32):
+        state = torch.randn(A, ns, generator=g, dtype=torch.float64).to(dtype).cuda()
+        for learning in (1, 0):
+            pol._noise_seed, pol._noise_off, pol.act_noise = 11, 40, 0.7
+            out = torch.empty(A, na, dtype=dtype, device="cuda")
+            pol.act_into(state, A, dtype, out, bool(learning))
+            assert pol._noise_off == 40 + (learning and (A * na + 3) // 4)
+            # the generic launch sequence on a clone of the actor in the state's type
+            clone = m.clone(dtype=dtype, max_cols=A)
+            noise = torch.zeros(A, na, dtype=dtype, device="cuda")
+            L.check(pol.lib.pdec_randn(clone.handle, L.ptr(noise), A * na, L.dtype_code(dtype), 11, 40))
+            want = torch.empty_like(out)
+            L.check(pol.lib.pdec_policy_act(clone.handle, L.ptr(state), L.ptr(noise) if learning else None, A, 0.7, float(pol.act_limit),
+                                            L.ptr(want)))
+            torch.cuda.synchronize()
+            mfma = C.c_int(0)
+            L.check(pol.lib.pdec_mlp_acts_on_published_copy(m.handle, C.byref(mfma)))
+            if mfma.value and dtype == torch.float32:
+                # fp32 states of a 3-layer fp32 actor keep the fused MFMA acting kernel (another summation order: ~1e-7)
+                assert float((out - want).abs().max()) <= 1e-6
+                continue
+            assert torch.equal(out, want), (which, dtype, learning, float((out - want).abs().max()))
+            assert bool(torch.isfinite(out).all()) and float(out.abs().max()) <= pol.act_limit
+
+
 @pytest.mark.parametrize("B", [1, 8])
 def test_run_loop_trains_and_logs(pkg, B):
     """run(agent, env, stop, hook) with the reference's stage order; KS22 constants, short run"""

@@ -81,6 +81,77 @@ def test_training_run_reproduces_the_update_count_of_the_reference_agent(pkg, wh
     assert abs(clip[0] - rclip[0]) < 0.06 and clip[1] < 0.12 and clip[2:].max() < 0.12, (clip, rclip)
 
 
+@pytest.mark.parametrize("which", ["ks22", "ks22_one_stream", "ks22_early_ends", "keller_segel", "ks_three_layer", "fluid"])
+def test_device_episodes_are_bit_identical_to_the_stage_loop(pkg, which):
+    """VERDICT r5 item 6 (rows F1 + F2 composed; src/PDEagent.jl:175-209,237-361, src/PDEenv.jl:195-241): `run` enqueues the
+    control steps of a whole episode without reading `is_terminated(env)` back after every step -- the device's halt flag
+    (pdec_set_episode_halt) decides it, one read-back per episode -- and must leave EXACTLY what the stage loop leaves: the
+    four networks, their ADAM moments and beta powers, the four replay traces and their counters, the Philox offsets, the
+    environment's fields, hook.rewards and the best episode's rows.  KS22 (fp64 env, 2-layer nets, the register-resident
+    20 x 3 update), the same on one stream, 3-layer nets (fused acting kernel), Keller-Segel (1 334-step episodes, two species,
+    temporal stack), and KS22 with a blow-up threshold low enough that episodes END EARLY (max|y| > max_value,
+    src/PDEenv.jl:226-240: the speculatively issued later steps must leave no trace)."""
+    import ctypes as C
+    run_mod = __import__("importlib").import_module(pkg.__name__ + ".run")
+
+    def make():
+        if which == "keller_segel":
+            setup, loops, steps, decay = pkg.KellerSegelSetup(), 1, 2700, 0.6
+        elif which == "fluid":
+            setup, loops, steps, decay = pkg.FluidSetup(nx=64), 1, 700, 0.6
+        elif which == "ks22_early_ends":
+            setup, loops, steps, decay = pkg.KSSetup.KS22(max_value=4.0), 2, 400, 0.2
+        elif which == "ks_three_layer":
+            setup, loops, steps, decay = pkg.KSSetup.KS22(drop_middle_layer=False), 2, 160, 0.2
+        else:
+            setup, loops, steps, decay = pkg.KSSetup.KS22(), 2, 400, 0.2
+        s_env = torch.cuda.Stream()
+        s_upd = s_env if which == "ks22_one_stream" else torch.cuda.Stream()
+        env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
+        agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(7), noise_seed=7, stream=s_upd)
+        hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, init_seed=7)
+        return setup, env, agent, hook, loops, steps, decay
+
+    out = []
+    for dev in (True, False):
+        setup, env, agent, hook, loops, steps, decay = make()
+        hook.use_random_init = True
+        agent.policy.act_noise = setup.act_noise
+        for _ in range(loops):
+            stop = pkg.StopAfterEpisodeWithMinSteps(steps)
+            assert run_mod.device_episodes_ok(agent, env, stop, hook)
+            pkg.run(agent, env, stop, hook, device_episodes=dev)
+            agent.policy.act_noise *= decay
+        torch.cuda.synchronize()
+        out.append((env, agent, hook))
+    (ed, ad, hd), (es, as_, hs) = out
+    pd, ps, td, ts = ad.policy, as_.policy, ad.trajectory, as_.trajectory
+    assert len(hd.rewards) == len(hs.rewards) >= 3
+    if which == "ks22_early_ends":
+        full = len(hd.rewards) * run_mod._episode_steps(ed) * setup.state_shape[1]
+        assert td.n_rt < full, "no episode ended early: the halt path was not exercised"
+        assert hd.rewards_compare and len(hd.rewards_compare) < len(hd.rewards)      # some ran to te, some did not
+    assert (td.n_sa, td.n_rt, pd.update_step, pd._noise_off, pd._sample_off) == (ts.n_sa, ts.n_rt, ps.update_step, ps._noise_off, ps._sample_off)
+    for name in ("state", "action", "reward", "terminal"):
+        assert torch.equal(getattr(td, name), getattr(ts, name)), name
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        md, ms = getattr(pd, n).model, getattr(ps, n).model
+        for x, y in zip(md.params(), ms.params()):
+            assert np.array_equal(x, y), n
+        for m_ in (md, ms):
+            pass
+        assert np.array_equal(_beta_powers(pkg, getattr(pd, n)).view(np.uint64), _beta_powers(pkg, getattr(ps, n)).view(np.uint64)), n
+    assert torch.equal(ed.y, es.y) and torch.equal(ed.state, es.state) and (ed.steps, ed.time) == (es.steps, es.time)
+    assert np.array_equal(np.asarray(hd.rewards), np.asarray(hs.rewards)), np.abs(np.asarray(hd.rewards) - np.asarray(hs.rewards)).max()
+    assert (hd.bestepisode, hd.bestreward, len(hd.bestDF)) == (hs.bestepisode, hs.bestreward, len(hs.bestDF))
+    for rd, rs in zip(hd.bestDF, hs.bestDF):
+        assert rd["timestep"] == rs["timestep"]
+        for k in ("action", "p", "y", "reward"):
+            assert np.array_equal(rd[k], rs[k]), k
+    for x, y in zip(hd.bestNNA.model.params(), hs.bestNNA.model.params()):
+        assert np.array_equal(x, y)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Learning curves under the reference's train() hyper-parameters, against the reference's own hook.rewards.
 # One saved run per experiment is ONE draw of a noisy process, so the comparison is a band over seeds (set from

@@ -25,31 +25,24 @@ two = "--two-streams" in sys.argv         # update beside the env step (run(): a
 s_env, s_upd = (torch.cuda.Stream(), torch.cuda.Stream()) if two else (None, None)
 env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
 agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(0), stream=s_upd)
-hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, collect_bestDF=False)
+hook = pkg.PDEhook(min_best_episode=1, use_random_init=True, collect_bestDF="--bestdf" in sys.argv)
 pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(60), hook)          # warm-up
-nsteps = 400 if which != "fluid" else 120
+nsteps = 2000 if which == "ks22" else (4000 if which == "kseg" else 120)
 torch.cuda.synchronize()
 n0 = len(hook.rewards)
 pr = cProfile.Profile() if "--profile" in sys.argv else None
 t0 = time.perf_counter()
 if pr:
     pr.enable()
-counter = [0]
-
-
-def counting_hook(stage, agent_, env_):
-    if stage == pkg.POST_ACT_STAGE:
-        counter[0] += 1
-    return hook(stage, agent_, env_)
-
-
-pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(nsteps), counting_hook)
+dev = None if "--stage-loop" not in sys.argv else False      # --stage-loop: the per-step host loop (rounds 1 - 5)
+rt0 = agent.trajectory.n_rt
+pkg.run(agent, env, pkg.StopAfterEpisodeWithMinSteps(nsteps), hook, device_episodes=dev)
 if pr:
     pr.disable()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 eps = len(hook.rewards) - n0
-ns_done = counter[0]
+ns_done = (agent.trajectory.n_rt - rt0) // agent.trajectory.stride
 print(f"{which}: episodes {eps}, {ns_done} steps, {ns_done / dt:.0f} env-steps/s ({dt / max(1, ns_done) * 1e3:.2f} ms/step)")
 if pr:
     pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
