@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: GPU tests of more than ~10 s (learning curves over several seeds, full-size grids); part "
+                            "of the default `-m gpu` run, left out by `-m \"gpu and not slow\"`")
 
 
 @pytest.fixture(scope="session")

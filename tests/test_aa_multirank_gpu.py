@@ -330,6 +330,7 @@ def test_bench_split_update_on_one_rank():
     assert d["checks"]["finite"] and d["value"] > 0 and "split-update" in d["config"]["workload"] and "variants" not in d
 
 
+@pytest.mark.slow
 def test_self_launcher_kills_its_ranks_at_the_deadline():
     """a rank that never finishes (here: --deadline-s shorter than the import + set-up) must not hang the caller: the parent
     kills exactly its own children and exits non-zero"""

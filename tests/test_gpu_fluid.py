@@ -230,6 +230,7 @@ def test_device_initialiser_matches_oracle_ic(pkg):
     assert np.abs(f.imag).max() <= 1e-12 * np.abs(f.real).max()
 
 
+@pytest.mark.slow
 def test_config_c5_full_grid_vs_oracle(pkg):
     """BASELINE.json configs[4] at the FULL 512 x 512 grid (3/2-rule padding -> 768 x 768 transforms), 16 x 16 sensors,
     fp64: do_step with K = 2 RK4 sub-steps and one fused (env)(action) against the oracle, B = 2 (the oracle needs
@@ -260,6 +261,7 @@ def test_config_c5_full_grid_vs_oracle(pkg):
         assert np.abs(env.state[b].cpu().numpy().T - st).max() <= 1e-10 * max(1.0, np.abs(st).max())
 
 
+@pytest.mark.slow
 def test_config_c5_full_size_shard_properties(pkg):
     """configs[4] per-GPU shard at full size -- 512 x 512, B = 16, the reference's K = floor(16 nx dt) = 163 RK4 sub-steps
     of one control step (scripts/Fluid/setup/FluidSetup.jl:47) -- through size-independent properties: a single Fourier

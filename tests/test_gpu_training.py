@@ -220,6 +220,7 @@ def test_ks200_learning_curve_before_the_buffer_wraps(pkg):
     assert np.median([r[36:].min() for r, _ in wrapped]) < -8.0, [np.round(r[36:].min(), 1) for r, _ in wrapped]
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("which,loops,seeds", [("fluid8", 10, 3), ("fluid16", 6, 2), ("fluid32", 5, 2)])
 def test_fluid_learning_curves_need_moving_targets(pkg, which, loops, seeds):
     """scripts/Fluid/Fluid_{8,16,32}/saves/hook.jld2 `rewards`: 20 / 12 / 10 episodes of train(; loops = 10 / 6 / 5)
@@ -244,6 +245,7 @@ def test_fluid_learning_curves_need_moving_targets(pkg, which, loops, seeds):
     assert sum(all(band(r)) for r, _ in runs) >= seeds - 1, [np.round(r, 2) for r, _ in runs]
 
 
+@pytest.mark.slow
 def test_keller_segel_first_training_loop_needs_moving_targets(pkg):
     """scripts/Keller-Segel/Keller-Segel10_16/saves/hook.jld2 `rewards` (tests/golden/kseg_train.npz), first loop of train()
     (4 episodes x 1 334 steps at act_noise 1.2, KellerSegelSetup.jl:390-406): -7.09, -2.13, -2.77, -1.97.  A constant saturated
