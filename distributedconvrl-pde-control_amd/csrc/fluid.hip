@@ -54,6 +54,8 @@ __host__ __device__ inline int fl_line_of(int jp, int n, int p, int nl) {
 template <class T>
 struct FluidDev {
   int B, n, p, nl, TL, TLn, LS, LSn;
+  int wtile;           // W between the two inverse passes is TILE-major, [b][f][p / 8][nl][8] (the persistent x-pass reads a
+                       // tile as one contiguous block), instead of line-major [b][f][nl][p]
   T nu, inv2, scale_out, invn2;
   const T* k;          // [n] wavenumbers, [0..n/2, -n/2+1..-1] * 2 pi / L   (FluidSetup.jl:106-107)
   const C2<T>* twp;    // exp(-2 pi i m / p)
@@ -546,9 +548,20 @@ __device__ __forceinline__ void fluid_k1w_body(const FluidDev<double>& d, const 
         }
       }
       f.inverse(a);
-      Z* w = W + (((size_t)b * 2 + fld) * d.nl + s) * p;
+      if (d.wtile) {
+        // tile-major: element x of line s goes to tile x / 8, row s, column x % 8 -- 128-byte pieces that are CONTIGUOUS over
+        // the lines of a tile (consecutive waves of a workgroup write consecutive rows), so that the x-pass reads whole tiles
+        Z* w = W + ((size_t)b * 2 + fld) * d.nl * p + (size_t)s * 8;
 #pragma unroll
-      for (int jj = 0; jj < F::R; ++jj) w[l + F::LANES * jj] = a[jj];
+        for (int jj = 0; jj < F::R; ++jj) {
+          const int x = l + F::LANES * jj;
+          w[(size_t)(x >> 3) * d.nl * 8 + (x & 7)] = a[jj];
+        }
+      } else {
+        Z* w = W + (((size_t)b * 2 + fld) * d.nl + s) * p;
+#pragma unroll
+        for (int jj = 0; jj < F::R; ++jj) w[l + F::LANES * jj] = a[jj];
+      }
     }
   }
 }
@@ -702,7 +715,8 @@ __global__ __launch_bounds__(512) void fluid_k2p_kernel(FluidDev<double> d, cons
     int lv = lane;
     asm volatile("" : "+v"(lv));                         // opaque per call: the offsets below are not hoisted (and spilled)
     const int b = tile / tiles_per_b, ip0 = (tile - b * tiles_per_b) * TC;
-    const char* base = reinterpret_cast<const char*>(W + ((size_t)b * 2 + fld) * nl * p + ip0);      // wave-uniform
+    // (W is tile-major for this kernel, FluidDev::wtile: tile ip0 / 8 of a field is the contiguous block [nl][8])
+    const char* base = reinterpret_cast<const char*>(W + ((size_t)b * 2 + fld) * nl * p + (size_t)(ip0 >> 3) * nl * 8);      // wave-uniform
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
       // piece c: lines 8c .. 8c+7; this lane's element (recomputed per issue: kept in registers the offsets spill, and a
@@ -711,7 +725,7 @@ __global__ __launch_bounds__(512) void fluid_k2p_kernel(FluidDev<double> d, cons
       c = c < npieces ? c : npieces - 1;
       int sl = c * 8 + (lv >> 3);
       sl = sl < nl ? sl : nl - 1;                        // rows past nl - 1 of the last piece: never read
-      const unsigned off = (unsigned)(sl * p + ((lv & 7) ^ ((sl >> 2) & 7))) * (unsigned)sizeof(Z);
+      const unsigned off = (unsigned)(sl * 8 + ((lv & 7) ^ ((sl >> 2) & 7))) * (unsigned)sizeof(Z);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
                                        (__attribute__((address_space(3))) void*)(R + (size_t)c * 64), 16, 0, 0);
     }
@@ -746,7 +760,9 @@ __global__ __launch_bounds__(512) void fluid_k2p_kernel(FluidDev<double> d, cons
 #pragma unroll
     for (int jj = 0; jj < F::R; ++jj) a[jj] = mk<double>(-(r0[jj].x * a[jj].x + r0[jj].y * a[jj].y) * d.inv2, 0.0);
     f.forward(a);
-    // ---- chop() along x: kept modes of my column into S (S was last read two barriers ago), then whole-line stores
+    // ---- chop() along x: kept modes of my column into S (S was last read two barriers ago), then whole-line stores.
+    // (Round 6, measured: the stores issued in the middle of the NEXT tile by all waves, or at its start by waves 4 - 7 only while
+    // their SIMD partners transform, make the launch 7 - 14 us LONGER -- HISTORY.md 6.5.)
 #pragma unroll
     for (int jj = 0; jj < F::R; ++jj) {
       const int kk = fl_unpad(f.mode_index(jj), n, p);
@@ -982,8 +998,18 @@ struct FluidEnv : Env {
   }
 };
 
+// does the persistent x-pass (fluid_k2p_kernel) serve this environment?  Decided once: K1 writes W in the layout K2 reads.
+static bool k2p_eligible(const FluidEnv& E) {
+  static const char* env = getenv("PDEC_FLUID_K2P");
+  const int npw = ((E.nl + 7) / 8 + 7) / 8, nsu = E.n * 8 / 512;
+  const bool want = env ? env[0] == '1' : E.n >= 256;
+  const bool wave64 = E.wave_E != 0 && E.wave_LB == 6;        // the one-line-per-wave plans (wave-FFT kernels K1w / K2p / K3w)
+  return want && wave64 && E.p % 8 == 0 && E.cfg.ifpad && E.n * 8 % 512 == 0 && ((npw == 9 && nsu == 8) || (npw == 5 && nsu == 4));
+}
+
 static FluidDev<double> fluid_dev(const FluidEnv& E) {
   FluidDev<double> d;
+  d.wtile = k2p_eligible(E) ? 1 : 0;
   d.B = E.cfg.B; d.n = E.n; d.p = E.p; d.nl = E.nl; d.TL = E.TL; d.TLn = E.TLn;
   d.LS = E.p + 2; d.LSn = E.n + 2;
   d.nu = E.cfg.nu;
@@ -1028,12 +1054,9 @@ static int fluid_k2_launch(FluidEnv& Ev, const FluidDev<double>& d) {
   const int B = Ev.cfg.B, p = Ev.p;
   constexpr int LPW = 64 >> LB;
   if constexpr (LB == 6) {
-    static const char* env = getenv("PDEC_FLUID_K2P");
     const int npw = ((Ev.nl + 7) / 8 + 7) / 8;
-    const bool want = env ? env[0] == '1' : Ev.n >= 256;
     // instantiated: n = 512 (nl = 513 -> 9 DMA pieces per wave, 8 output elements per thread) and n = 256 (257 -> 5, 4)
-    const int nsu = Ev.n * 8 / 512;
-    if (want && p % 8 == 0 && Ev.cfg.ifpad && Ev.n * 8 % 512 == 0 && ((npw == 9 && nsu == 8) || (npw == 5 && nsu == 4))) {
+    if (d.wtile) {
       static int ncu = 0;
       if (!ncu) {
         int dev = 0;
