@@ -325,59 +325,58 @@ struct Small2Args {
   int nC, nA;              // hidden widths
 };
 
-// sum over the 64 lanes of a wave, result in every lane: four DPP steps inside each row of 16 lanes, then the four row
-// sums through v_readlane (no LDS crossbar round trips, unlike __shfl_xor = ds_bpermute_b32)
+// sum over the 64 lanes of a wave, result in every lane: four DPP steps inside each row of 16 lanes, then the four row sums
+// r0 .. r3 combined as (r0 + r1) + (r2 + r3) by two row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+// and ONE v_readlane of lane 63 -- no LDS crossbar round trips (__shfl_xor = ds_bpermute_b32), a quarter of the VALU -> SGPR
+// hazards of four readlanes.  (fp32 addition is commutative: r1 + r0 and (r3 + r2) + (r1 + r0) are the bits of the formula above.)
 __device__ __forceinline__ float s2_wave_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane^1
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane^2
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
-  const int iv = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-  return (r0 + r1) + (r2 + r3);
+  // rows outside the row mask receive `old` = 0: their values are not read again
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast:15
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast:31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <int N>
-__device__ __forceinline__ void s2_reduce(float (&v)[N], int n, float* buf, int nw, int tid) {
-  // sum v[0..n) over the workgroup; result in every thread.  buf: [nw][N] (the caller alternates two buffers)
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    if (i < n) v[i] = s2_wave_sum(v[i]);
-  if ((tid & 63) == 0)
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-      if (i < n) buf[(tid >> 6) * N + i] = v[i];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    if (i < n) {
-      float a = 0.f;
-      for (int w = 0; w < nw; ++w) a += buf[w * N + i];
-      v[i] = a;
-    }
-}
+// Cross-wave exchange buffers: [2][S2_NW][S2_ROW] floats of LDS -- a row per wave, padded to 32 bytes, always eight rows (a
+// workgroup has at most 512 threads) so that the combining reads below are unconditional vector reads issued together: one LDS
+// round trip per exchange.  (Round 5 form: a loop over the waves with one load and one wait per partial, and the buffer picked
+// through a two-pointer array that the compiler could no longer prove to be LDS -- 18 dependent FLAT loads per exchange, which
+// was two thirds of the 4.6 us an update took.)
+#define S2_NW 8
+#define S2_ROW (2 * S2_BU)
 
-// the same for two groups of n values: entries [0, n) and [H, H + n) of v (H = N / 2), one exchange
+// sum entries [0, n) and [H, H + n) of v (H = N / 2) over the workgroup; result in every thread.  buf: one of the two exchange
+// buffers (the caller alternates them); partial sums are added in wave order from 0.f, as before
 template <int N>
 __device__ __forceinline__ void s2_reduce2(float (&v)[N], int n, float* buf, int nw, int tid) {
   constexpr int H = N / 2;
+  static_assert(N <= S2_ROW, "exchange row");
 #pragma unroll
   for (int i = 0; i < N; ++i)
     if ((i < H ? i : i - H) < n) v[i] = s2_wave_sum(v[i]);
   if ((tid & 63) == 0)
 #pragma unroll
-    for (int i = 0; i < N; ++i) buf[(tid >> 6) * N + i] = v[i];
+    for (int i = 0; i < N; ++i) buf[(tid >> 6) * S2_ROW + i] = v[i];
   __syncthreads();
+  float part[S2_NW][N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    float a = 0.f;
-    if ((i < H ? i : i - H) < n)
-      for (int w = 0; w < nw; ++w) a += buf[w * N + i];
-    v[i] = a;
-  }
+  for (int w = 0; w < S2_NW; ++w)
+#pragma unroll
+    for (int i = 0; i < N; ++i) part[w][i] = buf[w * S2_ROW + i];       // rows >= nw: stale, never added
+  float a[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = 0.f;
+#pragma unroll
+  for (int w = 0; w < S2_NW; ++w)
+    if (w < nw) {                                                         // (uniform)
+#pragma unroll
+      for (int i = 0; i < N; ++i) a[i] += part[w][i];
+    }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = (i < H ? i : i - H) < n ? a[i] : 0.f;
 }
 
 // Flux ADAM (fp64 arithmetic, no FMA contraction) + Polyak of one parameter held in registers.  The two bias-correction
@@ -415,11 +414,9 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   // do not change during the launch, so the two dependent global loads (slot index, then the row) are paid once
   const int bstride = (2 * ns + 3) * Bu;    // per loop: s' [ns][Bu], s [ns][Bu], a [Bu], r [Bu], t [Bu]
   float* batch = sm;
-  float* red0 = batch + (size_t)g.loops * bstride;   // [nw][2 * BUT]
-  float* red1 = red0 + nw * 2 * BUT;
+  float* red = batch + (size_t)g.loops * bstride;    // [2][S2_NW][S2_ROW]
   // three exchanges per update, two buffers: the parity flips from one update to the next, so an exchange never reuses
   // the buffer of the exchange right before it (a fast wave cannot overwrite partials a slow wave is still summing)
-  float* redb[2] = {red0, red1};
   int rp = 0;
   const int *i_s = g.i_s, *i_rt = g.i_rt, *i_sn = g.i_sn;
   if (g.smp_on) {
@@ -499,7 +496,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       v[c] = on ? aw2t * fmaxf(zt, 0.f) : 0.f;
       v[BUT + c] = aw2 * ha[c];
     }
-    s2_reduce2<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    s2_reduce2<2 * BUT>(v, Bu, red + rp * (S2_NW * S2_ROW), nw, tid);
     rp ^= 1;
     float an[BUT], ao[BUT];
 #pragma unroll
@@ -523,7 +520,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
       v[c] = on ? cw2t * fmaxf(zt, 0.f) : 0.f;
       v[BUT + c] = cw2 * h[c];
     }
-    s2_reduce2<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    s2_reduce2<2 * BUT>(v, Bu, red + rp * (S2_NW * S2_ROW), nw, tid);
     rp ^= 1;
     float qt[BUT];
 #pragma unroll
@@ -593,7 +590,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
         if (k == ns) wns = cw1[k];
       v[BUT + c] = (on && z > 0.f) ? wns * cw2 * (-invB) : 0.f;
     }
-    s2_reduce2<2 * BUT>(v, Bu, redb[rp], nw, tid);
+    s2_reduce2<2 * BUT>(v, Bu, red + rp * (S2_NW * S2_ROW), nw, tid);
     rp ^= 1;
     {
       float s = 0.f;
@@ -755,8 +752,8 @@ static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hA
     a2.g = g;
     a2.g.lds_params = 0;
     a2.nC = C->dims[1]; a2.nA = A->dims[1];
-    const int nt = (std::max(a2.nC, a2.nA) + 63) / 64 * 64, nwv = nt / 64;
-    const size_t lds2f = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * nwv * 2 * S2_BU;   // reduction rows: at most 2 * S2_BU
+    const int nt = (std::max(a2.nC, a2.nA) + 63) / 64 * 64;
+    const size_t lds2f = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * S2_NW * S2_ROW;   // + the two exchange buffers
     a2.g.smp_lds = (int)lds2f;
     const size_t lds2 = (lds2f + tab_floats) * 4;
     ProfScope ps(C, "ddpg_small");
