@@ -660,6 +660,347 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same update for the reference's FROZEN target networks (rho == 1: the Polyak loop of src/PDEagent.jl:414-417 runs over an
+// empty parameter list) -- the KS experiments' regime -- as TWO CHAINS SIDE BY SIDE.  With targets that never move
+//   * the TD targets gamma (1 - t) Ct([s'; At(s')]) of all `loops` minibatches depend on nothing the launch changes: they are
+//     computed once, up front, all columns at a time (one tanhf stream for all of them instead of three per update);
+//   * a critic update reads the critic alone; an actor update reads the actor and the critic AFTER the critic update of the same
+//     loop.  So the critic waves (one thread per critic unit, as above) run critic update i while ONE more wave, on the SIMD the
+//     kernel above leaves idle, runs actor update i - 1 against the critic weights update i - 1 published in LDS (double
+//     buffered): a lane of that wave holds the actor's unit `lane` and walks the critic's units lane, 64 + lane, ... for the
+//     forward through the updated critic.  Two workgroup barriers per iteration (the critic's exchange, the hand-over), loops + 1
+//     iterations; per iteration each wave issues about a third of what an update costs it above.
+// Bit-identical to ddpg_small2_kernel at rho == 1: every sum is taken over the same lanes in the same order (the actor wave sums
+// critic units r * 64 + lane by the wave tree and adds the rows r in order, which is what the cross-wave exchange above does), the
+// expressions are the ones above (test_split_small_update_is_bit_identical).  Needs nA <= 64 and nC <= 448; launched for the exact
+// KS instantiation only (see the launch code).
+template <int KC, int KA, int BUT, bool EXACT>
+__global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
+  const SmallArgs& g = a_in.g;
+  extern __shared__ __align__(16) float sm[];
+  const int tid = threadIdx.x, nt = blockDim.x, nwc = (nt >> 6) - 1, wv = tid >> 6, lane = tid & 63;
+  if (g.halt && *g.halt) {
+    if (tid == 0) {
+      g.bpA.next[0] = g.bpA.cur[0]; g.bpA.next[1] = g.bpA.cur[1];
+      g.bpC.next[0] = g.bpC.cur[0]; g.bpC.next[1] = g.bpC.cur[1];
+    }
+    return;
+  }
+  const int Bu = EXACT ? BUT : g.Bu, ns = EXACT ? KA : g.ns, K0 = ns + 1, nC = a_in.nC, nA = a_in.nA;
+  const bool actor_wave = wv == nwc;
+  const bool isC = !actor_wave && tid < nC, isA = actor_wave && lane < nA;
+  const int bstride = (2 * ns + 3) * Bu, ncol = g.loops * Bu, PUBN = nwc * 64, PUBS = (KC + 2) * PUBN + 4;
+  float* batch = sm;
+  float* red = batch + (size_t)g.loops * bstride;    // [2][S2_NW][S2_ROW]
+  float* tq = red + 2 * S2_NW * S2_ROW;              // [ncol] Ct([s'; At(s')]) + b2t
+  float* tan_ = tq + ncol;                           // [ncol] a' = tanh(At(s'))
+  float* tpart = tan_ + ncol;                        // [S2_NW][ncol] wave sums of the target critic's output layer
+  float* pub = tpart + S2_NW * ncol;                 // [2][PUBS]: W1 rows k (KC of them), b1, w2 by unit, then b2
+  const int *i_s = g.i_s, *i_rt = g.i_rt, *i_sn = g.i_sn;
+  if (g.smp_on) {
+    int* tab = reinterpret_cast<int*>(sm + g.smp_lds);
+    sm_draw_slots(g, tab, tid, nt);
+    const int n = g.loops * g.Bu;
+    i_s = tab; i_rt = tab + n; i_sn = tab + 2 * n;
+    __syncthreads();
+  }
+  for (int idx = tid; idx < g.loops * ns * Bu; idx += nt) {
+    const int it = idx / (ns * Bu), rem = idx - it * (ns * Bu), k = rem / Bu, c = rem - k * Bu;
+    batch[it * bstride + rem] = g.state[(size_t)i_sn[it * Bu + c] * ns + k];
+    batch[it * bstride + ns * Bu + rem] = g.state[(size_t)i_s[it * Bu + c] * ns + k];
+  }
+  for (int idx = tid; idx < g.loops * Bu; idx += nt) {
+    const int it = idx / Bu, c = idx - it * Bu;
+    float* b = batch + it * bstride + 2 * ns * Bu;
+    b[c] = g.action[i_s[idx]];
+    b[Bu + c] = g.reward[i_rt[idx]];
+    b[2 * Bu + c] = g.terminal[i_rt[idx]];
+  }
+  // ---- this thread's unit (critic waves: critic unit tid; actor wave: actor unit lane)
+  float cw1[KC], cw1m[KC], cw1v[KC], cw1t[KC], cb1 = 0, cb1m = 0, cb1v = 0, cb1t = 0, cw2 = 0, cw2m = 0, cw2v = 0, cw2t = 0;
+  float aw1[KA], aw1m[KA], aw1v[KA], aw1t[KA], ab1 = 0, ab1m = 0, ab1v = 0, ab1t = 0, aw2 = 0, aw2m = 0, aw2v = 0, aw2t = 0;
+  const int cob1 = nC * K0, cow2 = cob1 + nC, cob2 = cow2 + nC;
+  const int aob1 = nA * ns, aow2 = aob1 + nA, aob2 = aow2 + nA;
+  float cb2 = g.C.p[cob2], cb2m = g.C.m[cob2], cb2v = g.C.v[cob2], cb2t = g.C.pt[cob2];
+  float ab2 = g.A.p[aob2], ab2m = g.A.m[aob2], ab2v = g.A.v[aob2], ab2t = g.A.pt[aob2];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    const bool ok = isC && k < K0;
+    cw1[k] = ok ? g.C.p[tid * K0 + k] : 0.f; cw1m[k] = ok ? g.C.m[tid * K0 + k] : 0.f;
+    cw1v[k] = ok ? g.C.v[tid * K0 + k] : 0.f; cw1t[k] = ok ? g.C.pt[tid * K0 + k] : 0.f;
+  }
+  if (isC) {
+    cb1 = g.C.p[cob1 + tid]; cb1m = g.C.m[cob1 + tid]; cb1v = g.C.v[cob1 + tid]; cb1t = g.C.pt[cob1 + tid];
+    cw2 = g.C.p[cow2 + tid]; cw2m = g.C.m[cow2 + tid]; cw2v = g.C.v[cow2 + tid]; cw2t = g.C.pt[cow2 + tid];
+  }
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const bool ok = isA && k < ns;
+    aw1[k] = ok ? g.A.p[lane * ns + k] : 0.f; aw1m[k] = ok ? g.A.m[lane * ns + k] : 0.f;
+    aw1v[k] = ok ? g.A.v[lane * ns + k] : 0.f; aw1t[k] = ok ? g.A.pt[lane * ns + k] : 0.f;
+  }
+  if (isA) {
+    ab1 = g.A.p[aob1 + lane]; ab1m = g.A.m[aob1 + lane]; ab1v = g.A.v[aob1 + lane]; ab1t = g.A.pt[aob1 + lane];
+    aw2 = g.A.p[aow2 + lane]; aw2m = g.A.m[aow2 + lane]; aw2v = g.A.v[aow2 + lane]; aw2t = g.A.pt[aow2 + lane];
+  }
+  double bpa0 = g.bpA.cur[0], bpa1 = g.bpA.cur[1], bpc0 = g.bpC.cur[0], bpc1 = g.bpC.cur[1];
+  const float invB = 1.f / (float)Bu;
+  float closs = 0.f, aloss = 0.f;
+  __syncthreads();                         // the batches are staged
+  // ---- TD targets of every minibatch column, once.  a' = tanh(At(s')): actor wave, one tanhf stream over the columns
+  if (actor_wave) {
+    for (int col0 = 0; col0 < ncol; col0 += 64) {
+      float mine = 0.f;
+      const int nc = min(64, ncol - col0);
+      for (int cc = 0; cc < nc; ++cc) {
+        const int col = col0 + cc, it = col / Bu, c = col - it * Bu;
+        const float* bsn = batch + it * bstride;
+        float zt = ab1t;
+#pragma unroll
+        for (int k = 0; k < KA; ++k)
+          if (k < ns) zt += aw1t[k] * bsn[k * Bu + c];
+        const float S = s2_wave_sum(isA ? aw2t * fmaxf(zt, 0.f) : 0.f);
+        if (lane == cc) mine = S;
+      }
+      if (lane < nc) tan_[col0 + lane] = tanhf((0.f + mine) + ab2t);
+    }
+  }
+  __syncthreads();
+  // qt = Ct([s'; a']): critic waves (their threads hold the target critic's units), wave sums by column
+  if (!actor_wave) {
+    for (int col = 0; col < ncol; ++col) {
+      const int it = col / Bu, c = col - it * Bu;
+      const float* bsn = batch + it * bstride;
+      const float an = tan_[col];
+      float zt = cb1t;
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+        if (k < ns) zt += cw1t[k] * bsn[k * Bu + c];
+        else if (k == ns) zt += cw1t[k] * an;
+      const float S = s2_wave_sum(isC ? cw2t * fmaxf(zt, 0.f) : 0.f);
+      if (lane == 0) tpart[wv * ncol + col] = S;
+    }
+  }
+  __syncthreads();
+  for (int col = tid; col < ncol; col += nt) {
+    float a = 0.f;
+    for (int w = 0; w < nwc; ++w) a += tpart[w * ncol + col];
+    tq[col] = a + cb2t;
+  }
+  // (the first barrier of the loop below orders tq before its first reader)
+  // ---- iteration i: critic update i (critic waves) beside actor update i - 1 (actor wave)
+  for (int i = 0; i <= g.loops; ++i) {
+    float* rb = red + (i & 1) * (S2_NW * S2_ROW);
+    float* pw = pub + (i & 1) * PUBS;                 // the critic publishes update i here
+    const float* pr = pub + ((i + 1) & 1) * PUBS;     // update i - 1, read by the actor wave
+    if (!actor_wave) {
+      if (i < g.loops) {
+        const float* bs = batch + i * bstride + ns * Bu;
+        const float* ba = bs + ns * Bu;
+        const float* br = ba + Bu;
+        const float* bt = br + Bu;
+        // ---- q = C([s; a])  (src/PDEagent.jl:392)
+        float h[BUT], v[BUT];
+#pragma unroll
+        for (int c = 0; c < BUT; ++c) {
+          float z = cb1;
+#pragma unroll
+          for (int k = 0; k < KC; ++k)
+            if (k < ns) z += cw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
+            else if (k == ns) z += cw1[k] * ba[c < Bu ? c : 0];
+          const bool on = isC && c < Bu;
+          h[c] = on ? fmaxf(z, 0.f) : 0.f;
+          v[c] = cw2 * h[c];
+        }
+#pragma unroll
+        for (int c = 0; c < BUT; ++c)
+          if (c < Bu) v[c] = s2_wave_sum(v[c]);
+        if (lane == 0)
+#pragma unroll
+          for (int c = 0; c < BUT; ++c) rb[wv * S2_ROW + c] = v[c];
+        __syncthreads();                                 // barrier 1
+        float part[S2_NW][BUT];
+#pragma unroll
+        for (int w = 0; w < S2_NW; ++w)
+#pragma unroll
+          for (int c = 0; c < BUT; ++c) part[w][c] = rb[w * S2_ROW + c];
+#pragma unroll
+        for (int c = 0; c < BUT; ++c) v[c] = 0.f;
+#pragma unroll
+        for (int w = 0; w < S2_NW; ++w)
+          if (w < nwc) {
+#pragma unroll
+            for (int c = 0; c < BUT; ++c) v[c] += part[w][c];
+          }
+        float qt[BUT], dq[BUT];
+#pragma unroll
+        for (int c = 0; c < BUT; ++c) qt[c] = c < Bu ? tq[i * Bu + c] : 0.f;
+        float rbar = 0.f;
+        for (int c = 0; c < Bu; ++c) rbar += br[c];
+        rbar *= invB;
+        float loss = 0.f, gb2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < BUT; ++c) {
+          dq[c] = 0.f;
+          if (c < Bu) {
+            const float cc = g.gamma * (1.f - bt[c]) * qt[c] - (v[c] + cb2);
+            if (g.quirk) {
+              for (int j = 0; j < Bu; ++j) loss += (br[j] + cc) * (br[j] + cc);
+            } else {
+              loss += (br[c] + cc) * (br[c] + cc);
+            }
+            dq[c] = -(2.f * invB) * ((g.quirk ? rbar : br[c]) + cc);
+            gb2 += dq[c];
+          }
+        }
+        closs = g.quirk ? loss / (float)(Bu * Bu) : loss * invB;
+        const double o1 = 1.0 / (1.0 - bpc0), o2 = 1.0 / (1.0 - bpc1);
+        float gw2 = 0.f, gb1 = 0.f, gw1[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) gw1[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < BUT; ++c)
+          if (c < Bu) {
+            gw2 = fmaf(dq[c], h[c], gw2);
+            const float dz = h[c] > 0.f ? cw2 * dq[c] : 0.f;
+            gb1 += dz;
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+              if (k < ns) gw1[k] = fmaf(dz, bs[k * Bu + c], gw1[k]);
+              else if (k == ns) gw1[k] = fmaf(dz, ba[c], gw1[k]);
+          }
+        if (isC) {
+#pragma unroll
+          for (int k = 0; k < KC; ++k)
+            if (k < K0) s2_adam(cw1[k], cw1m[k], cw1v[k], cw1t[k], gw1[k], g.eta_c, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+          s2_adam(cb1, cb1m, cb1v, cb1t, gb1, g.eta_c, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+          s2_adam(cw2, cw2m, cw2v, cw2t, gw2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+        }
+        s2_adam(cb2, cb2m, cb2v, cb2t, gb2, g.eta_c, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+        bpc0 *= g.b1;
+        bpc1 *= g.b2;
+        // publish the updated critic for the actor wave
+#pragma unroll
+        for (int k = 0; k < KC; ++k) pw[k * PUBN + tid] = cw1[k];
+        pw[KC * PUBN + tid] = cb1;
+        pw[(KC + 1) * PUBN + tid] = cw2;
+        if (tid == 0) pw[(KC + 2) * PUBN] = cb2;
+      } else {
+        __syncthreads();                                 // barrier 1 of the last iteration (the actor wave's partner)
+      }
+    } else {
+      __syncthreads();                                   // barrier 1: the critic's exchange
+      if (i >= 1) {
+        const int j = i - 1;
+        const float* bs = batch + j * bstride + ns * Bu;
+        // ---- A(s)  (src/PDEagent.jl:403)
+        float ha[BUT], ao[BUT];
+        float mine = 0.f;
+#pragma unroll
+        for (int c = 0; c < BUT; ++c) {
+          float z = ab1;
+#pragma unroll
+          for (int k = 0; k < KA; ++k)
+            if (k < ns) z += aw1[k] * bs[k * Bu + (c < Bu ? c : 0)];
+          const bool on = isA && c < Bu;
+          ha[c] = on ? fmaxf(z, 0.f) : 0.f;
+          const float S = s2_wave_sum(aw2 * ha[c]);
+          if (lane == c) mine = S;
+        }
+        {
+          const float t = tanhf((0.f + mine) + ab2);      // lane c: tanh of column c -- one stream for the Bu columns
+#pragma unroll
+          for (int c = 0; c < BUT; ++c) ao[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), c));
+        }
+        // ---- forward through the critic AFTER its update j: q on [s; A(s)] and da, rows r = units r * 64 + lane in order
+        const float pcb2 = pr[(KC + 2) * PUBN];
+        float vq[BUT], vd[BUT];
+#pragma unroll
+        for (int c = 0; c < BUT; ++c) vq[c] = vd[c] = 0.f;
+        for (int r = 0; r < nwc; ++r) {
+          const int u = r * 64 + lane;
+          float w1[KC];
+#pragma unroll
+          for (int k = 0; k < KC; ++k) w1[k] = pr[k * PUBN + u];
+          const float b1 = pr[KC * PUBN + u], w2 = pr[(KC + 1) * PUBN + u];
+#pragma unroll
+          for (int c = 0; c < BUT; ++c)
+            if (c < Bu) {
+              float z = b1;
+#pragma unroll
+              for (int k = 0; k < KC; ++k)
+                if (k < ns) z += w1[k] * bs[k * Bu + c];
+                else if (k == ns) z += w1[k] * ao[c];
+              const bool on = u < nC;
+              float wns = 0.f;
+#pragma unroll
+              for (int k = 0; k < KC; ++k)
+                if (k == ns) wns = w1[k];
+              vq[c] += s2_wave_sum(on ? w2 * fmaxf(z, 0.f) : 0.f);
+              vd[c] += s2_wave_sum((on && z > 0.f) ? wns * w2 * (-invB) : 0.f);
+            }
+        }
+        float sacc = 0.f;
+        for (int c = 0; c < Bu; ++c) sacc += vq[c] + pcb2;
+        aloss = -sacc * invB;
+        const double o1 = 1.0 / (1.0 - bpa0), o2 = 1.0 / (1.0 - bpa1);
+        float gw2 = 0.f, gb1 = 0.f, gb2 = 0.f, gw1[KA];
+#pragma unroll
+        for (int k = 0; k < KA; ++k) gw1[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < BUT; ++c)
+          if (c < Bu) {
+            const float dz2 = vd[c] * (1.f - ao[c] * ao[c]);      // tanh'
+            gb2 += dz2;
+            gw2 = fmaf(dz2, ha[c], gw2);
+            const float dz = ha[c] > 0.f ? aw2 * dz2 : 0.f;
+            gb1 += dz;
+#pragma unroll
+            for (int k = 0; k < KA; ++k)
+              if (k < ns) gw1[k] = fmaf(dz, bs[k * Bu + c], gw1[k]);
+          }
+        if (isA) {
+#pragma unroll
+          for (int k = 0; k < KA; ++k)
+            if (k < ns) s2_adam(aw1[k], aw1m[k], aw1v[k], aw1t[k], gw1[k], g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+          s2_adam(ab1, ab1m, ab1v, ab1t, gb1, g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+          s2_adam(aw2, aw2m, aw2v, aw2t, gw2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+        }
+        s2_adam(ab2, ab2m, ab2v, ab2t, gb2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+        bpa0 *= g.b1;
+        bpa1 *= g.b2;
+      }
+    }
+    __syncthreads();                                     // barrier 2: update i is published, update i - 1 has been read
+  }
+  // ---- write the learner state back (the targets keep their bits)
+  if (isC) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < K0) { g.C.p[tid * K0 + k] = cw1[k]; g.C.m[tid * K0 + k] = cw1m[k]; g.C.v[tid * K0 + k] = cw1v[k]; }
+    g.C.p[cob1 + tid] = cb1; g.C.m[cob1 + tid] = cb1m; g.C.v[cob1 + tid] = cb1v;
+    g.C.p[cow2 + tid] = cw2; g.C.m[cow2 + tid] = cw2m; g.C.v[cow2 + tid] = cw2v;
+  }
+  if (isA) {
+#pragma unroll
+    for (int k = 0; k < KA; ++k)
+      if (k < ns) { g.A.p[lane * ns + k] = aw1[k]; g.A.m[lane * ns + k] = aw1m[k]; g.A.v[lane * ns + k] = aw1v[k]; }
+    g.A.p[aob1 + lane] = ab1; g.A.m[aob1 + lane] = ab1m; g.A.v[aob1 + lane] = ab1v;
+    g.A.p[aow2 + lane] = aw2; g.A.m[aow2 + lane] = aw2m; g.A.v[aow2 + lane] = aw2v;
+  }
+  if (tid == 0) {
+    g.C.p[cob2] = cb2; g.C.m[cob2] = cb2m; g.C.v[cob2] = cb2v;
+    if (g.losses) g.losses[0] = closs;
+    g.bpC.next[0] = bpc0; g.bpC.next[1] = bpc1;
+  }
+  if (actor_wave && lane == 0) {
+    g.A.p[aob2] = ab2; g.A.m[aob2] = ab2m; g.A.v[aob2] = ab2v;
+    if (g.losses) g.losses[1] = aloss;
+    g.bpA.next[0] = bpa0; g.bpA.next[1] = bpa1;
+  }
+}
+
 // 2-layer relu/tanh actor [ns, h, 1] + relu/identity critic [ns+1, H, 1], H and h <= 512, ns <= 15, Bu <= S2_BU
 static bool small2_ok(const Mlp* A, const Mlp* C, int Bu) {
   if (getenv("PDEC_SMALL_GENERIC")) return false;
@@ -757,6 +1098,26 @@ static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hA
     a2.g.smp_lds = (int)lds2f;
     const size_t lds2 = (lds2f + tab_floats) * 4;
     ProfScope ps(C, "ddpg_small");
+    // frozen targets (the KS experiments' regime): the critic and the actor updates as two chains side by side (ddpg_small2f_kernel).
+    // Only the exact KS instantiation (ns 1, batch 3: KS22 / KS200 / KS500): there every guard folds at compile time and the
+    // backend fuses multiplies and adds the same way in both kernels, which is what makes them agree bit for bit; the bounded
+    // instantiations differ in the last place of the actor's gradient (a product fused into one kernel's sum and not the other's).
+    const char* nosplit = getenv("PDEC_SMALL_SPLIT");      // (read per launch: the identity test switches it)
+    const int nwc = (a2.nC + 63) / 64;
+    if (a2.g.rho == 1.0f && Bu == 3 && ns == 1 && a2.nA <= 64 && nwc <= 7 && !(nosplit && nosplit[0] == '0')) {
+      const int ntf = (nwc + 1) * 64, ncol = loops * Bu;
+      const size_t ldsf = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * S2_NW * S2_ROW + (size_t)ncol * (2 + S2_NW) +
+                          (size_t)2 * ((2 + 2) * nwc * 64 + 4);
+      if ((ldsf + tab_floats) * 4 <= 150 * 1024) {
+        a2.g.smp_lds = (int)ldsf;
+        hipLaunchKernelGGL((ddpg_small2f_kernel<2, 1, 3, true>), dim3(1), dim3(ntf), (ldsf + tab_floats) * 4, C->stream, a2);
+        PDEC_HIP(hipGetLastError());
+        bp_done(A);
+        bp_done(C);
+        A->fw_dirty = C->fw_dirty = At->fw_dirty = Ct->fw_dirty = true;
+        return PDEC_OK;
+      }
+    }
 #define S2_LAUNCH(KC, KA, BUT, EX) hipLaunchKernelGGL((ddpg_small2_kernel<KC, KA, BUT, EX>), dim3(1), dim3(nt), lds2, C->stream, a2)
     if (Bu == 3 && ns == 1) S2_LAUNCH(2, 1, 3, true);            // KS22 / KS200 / KS500
     else if (Bu == 3 && ns == 12) S2_LAUNCH(13, 12, 3, true);    // Keller-Segel10_16

@@ -511,6 +511,47 @@ def test_small_update_leaves_frozen_targets_untouched(pkg, which):
         assert all(np.isfinite(x).all() for x in after)
 
 
+@pytest.mark.parametrize("which", ["KS22", "KS200"])
+def test_split_small_update_is_bit_identical(pkg, which, monkeypatch):
+    """Frozen targets (the KS experiments' regime): the 20 x 3 update with the critic and the actor updates as two chains side
+    by side (ddpg_small2f_kernel: TD targets of all minibatches up front, actor update i - 1 on one more wave beside critic update
+    i) == the one-chain kernel (PDEC_SMALL_SPLIT=0), bit for bit: parameters, ADAM moments, beta powers, losses, after three
+    launches on a wrapped buffer."""
+    setup, kw = (pkg.KSSetup.KS22() if which == "KS22" else pkg.KSSetup.KS200()), {}
+    ns, A = setup.state_shape
+    agents = [pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=320, **kw) for _ in range(2)]
+    g = torch.Generator()
+    for ag in agents:
+        tr = ag.trajectory
+        g.manual_seed(3)
+        for step in range(55):
+            tr.push_sa(torch.randn(A, ns, generator=g).cuda(), (torch.rand(A, 1, generator=g) * 2 - 1).cuda())
+            tr.push_rt(-torch.rand(A, generator=g).cuda(), (torch.rand(A, generator=g) < 0.1).float().cuda())
+        tr.push_sa(torch.randn(A, ns, generator=g).cuda(), None)
+    for ag, split in zip(agents, ("1", "0")):
+        monkeypatch.setenv("PDEC_SMALL_SPLIT", split)
+        pol = ag.policy
+        assert pol.small_update_ok() and pol.rho_effective == 1.0
+        pol._sample_seed, pol._sample_off = 4242, 17
+        for _ in range(3):
+            pol.update_small_rng(ag.trajectory)
+        torch.cuda.synchronize()
+    p0, p1 = agents[0].policy, agents[1].policy
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        m0, m1 = getattr(p0, n).model, getattr(p1, n).model
+        for x, y in zip(m0.params(), m1.params()):
+            assert np.array_equal(x, y), n
+        if n.startswith("behavior"):
+            from importlib import import_module
+            ck = import_module(pkg.__name__ + ".checkpoint")
+            for x, y in zip(ck._adam_state(m0), ck._adam_state(m1)):          # m, v, beta powers
+                assert np.array_equal(x, y), n
+    assert p0.losses() == p1.losses()
+    # and the update did something
+    fresh = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=320, **kw).policy
+    assert not np.array_equal(fresh.behavior_critic.model.params()[0], p0.behavior_critic.model.params()[0])
+
+
 def test_random_init_kernels_match_the_oracle_stream(pkg):
     """pdec_env_random_init (generate_random_init of KSSetup.jl:288-298 / KellerSegelSetup.jl:373-384 as a kernel) against
     the oracle's formulas evaluated with the coefficients of the same Philox stream (oracle/rng.py)"""
