@@ -992,10 +992,12 @@ struct SmallActArgs {
   uint64_t* ctr_next;
   uint64_t ctr_inc;
 };
+// the kernel's body; returns the LDS buffer that holds the finished actions as element i = column * outputs + row (what `out`
+// receives), for a caller that goes on with them inside the same launch (step_glue_kernel)
 template <class T, class TP>
-__global__ __launch_bounds__(256) void small_act_kernel(SmallActArgs g, const T* __restrict__ state, T* __restrict__ out) {
-  extern __shared__ __align__(16) unsigned char small_act_smem[];
-  T* X0 = reinterpret_cast<T*>(small_act_smem);
+__device__ __forceinline__ T* small_act_body(const SmallActArgs& g, const T* __restrict__ state, T* __restrict__ out,
+                                             unsigned char* smem) {
+  T* X0 = reinterpret_cast<T*>(smem);
   T* X1 = X0 + (size_t)g.maxw * g.cols;
   const TP* p = static_cast<const TP*>(g.p);
   const int tid = threadIdx.x, cols = g.cols;
@@ -1043,6 +1045,73 @@ __global__ __launch_bounds__(256) void small_act_kernel(SmallActArgs g, const T*
     }
     v = v < -lim ? -lim : (v > lim ? lim : v);
     out[i] = v;
+    xout[i] = v;
+  }
+  return xout;
+}
+template <class T, class TP>
+__global__ __launch_bounds__(256) void small_act_kernel(SmallActArgs g, const T* __restrict__ state, T* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char small_act_smem[];
+  (void)small_act_body<T, TP>(g, state, out, small_act_smem);
+}
+
+// ---- the glue between two control steps of a single-trajectory training loop, ONE launch instead of three (round 6):
+//   POST_ACT push of the step that just ran (reward, terminal; src/PDEagent.jl:276-289; raises the episode halt flag when that
+//   step ended the episode -- replay_push_rt_kernel), agent(env) for the next step (small_act_kernel; or the zero action of the
+//   start policy), PRE_ACT push of the next step's (state, action) (:254-274; replay_push2_kernel: skipped once the episode has
+//   ended).  Same arithmetic and the same stores as the three launches; each of them was ~5 us of launch latency on the chain
+//   act -> push -> update / env step -> push of the reference-shaped loop.
+struct StepGlueArgs {
+  float *tr, *tt;              // POST_ACT push: reward / terminal traces, capacity cap_rt, first slot start_rt, n_rt values (0: none)
+  const void* r;
+  const int32_t* done;
+  int cols_per_traj, force;
+  long long cap_rt, start_rt, n_rt;
+  int act_mode;                // 0: no acting, 1: the actor, 2: the zero action
+  SmallActArgs act;
+  const void* state;           // [cols][ns] of the environment's type: acting input and the PRE_ACT push's state rows
+  void* out;                   // [cols][na]
+  float *ts, *ta;              // PRE_ACT push: state / action traces, capacity cap_sa rows, first row start_sa, n_sa rows (0: none)
+  int ns, na;
+  long long cap_sa, start_sa, n_sa;
+  int* halt;
+};
+template <class T, class TP>
+__global__ __launch_bounds__(256) void step_glue_kernel(StepGlueArgs g) {
+  extern __shared__ __align__(16) unsigned char small_act_smem[];
+  const int tid = threadIdx.x;
+  const bool was = g.halt && *g.halt;
+  const bool ended = was || (g.halt && g.n_rt && g.done && g.done[0] != 0);
+  if (g.n_rt && !was) {
+    const T* r = static_cast<const T*>(g.r);
+    for (long long i = tid; i < g.n_rt; i += 256) {
+      const long long slot = (g.start_rt + i) % g.cap_rt;
+      g.tr[slot] = (float)r[i];
+      g.tt[slot] = (g.force || (g.done && g.done[i / g.cols_per_traj] != 0)) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();                    // every thread has read *halt before one of them writes it
+  if (tid == 0 && g.halt && !was && ended) *g.halt = 1;
+  const T* state = static_cast<const T*>(g.state);
+  T* out = static_cast<T*>(g.out);
+  const T* acts = nullptr;            // the actions of this launch in LDS, element row * na + c
+  if (g.act_mode == 1) {
+    acts = small_act_body<T, TP>(g.act, state, out, small_act_smem);
+  } else if (g.act_mode == 2) {
+    for (long long i = tid; i < (long long)g.act.cols * g.na; i += 256) out[i] = (T)0;
+  }
+  if (g.n_sa && !ended) {
+    __syncthreads();                  // the actions are in LDS
+    const long long na_ = g.n_sa * g.ns, nb_ = g.n_sa * g.na;
+    for (long long i = tid; i < na_ + nb_; i += 256) {
+      if (i < na_) {
+        const long long row = i / g.ns, c = i - row * g.ns;
+        g.ts[((g.start_sa + row) % g.cap_sa) * g.ns + c] = (float)state[i];
+      } else {
+        const long long j = i - na_, row = j / g.na, c = j - row * g.na;
+        g.ta[((g.start_sa + row) % g.cap_sa) * g.na + c] = acts ? (float)acts[j] : 0.f;
+      }
+    }
   }
 }
 
@@ -1127,6 +1196,52 @@ int pdec_policy_act_rng_as(pdec_handle actor, int state_dtype, const void* state
   PDEC_REQUIRE(state && actions_out, "pdec_policy_act_rng_as: null");
   *served = 1;
   return small_act(M, state_dtype, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, nullptr, nullptr, 0);
+}
+
+int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, const void* reward, const int32_t* done_flags,
+                   int cols_per_traj, int force_terminal, void* reward_trace, void* terminal_trace, int64_t capacity,
+                   int64_t start_rt, int64_t n_rt, int act_mode, const void* state, int cols, double act_noise, double act_limit,
+                   uint64_t seed, uint64_t offset, void* actions_out, void* state_trace, void* action_trace,
+                   int64_t capacity_rows, int64_t start_sa, int64_t n_sa, int* served) {
+  GET_MLP(M, actor);
+  Object* o = lookup(trajectory_handle);
+  if (!o) { set_error("pdec_step_glue: bad trajectory handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(served, "pdec_step_glue: null");
+  PDEC_REQUIRE(dtype == PDEC_F32 || dtype == PDEC_F64, "pdec_step_glue: bad dtype %d", dtype);
+  PDEC_REQUIRE(act_mode >= 0 && act_mode <= 2 && n_rt >= 0 && n_sa >= 0, "pdec_step_glue: bad argument");
+  *served = 0;
+  // served where the three launches it stands for would be the single-workgroup ones: the few-column acting kernel of
+  // pdec_policy_act_rng_as (state of another type than the networks), single-block pushes, one stream
+  if (o->stream != M->stream || n_rt > 256 || (act_mode == 1 && (!small_act_ok(M, dtype, cols) || M->dtype == dtype))) return PDEC_OK;
+  PDEC_REQUIRE(!n_rt || (reward && reward_trace && terminal_trace && capacity >= 1 && n_rt <= capacity && cols_per_traj >= 1 && start_rt >= 0),
+               "pdec_step_glue: bad POST_ACT push");
+  PDEC_REQUIRE(!n_sa || (state && state_trace && action_trace && capacity_rows >= 1 && n_sa <= capacity_rows && start_sa >= 0),
+               "pdec_step_glue: bad PRE_ACT push");
+  PDEC_REQUIRE(act_mode == 0 || (actions_out && (act_mode == 2 || (state && cols >= 1))), "pdec_step_glue: bad acting arguments");
+  PDEC_REQUIRE(act_mode == 0 || !n_sa || n_sa == cols, "pdec_step_glue: the PRE_ACT push takes the acting call's columns");
+  StepGlueArgs g{};
+  g.tr = (float*)reward_trace; g.tt = (float*)terminal_trace; g.r = reward; g.done = done_flags;
+  g.cols_per_traj = cols_per_traj; g.force = force_terminal; g.cap_rt = capacity; g.start_rt = start_rt; g.n_rt = n_rt;
+  g.act_mode = act_mode; g.state = state; g.out = actions_out;
+  g.ts = (float*)state_trace; g.ta = (float*)action_trace; g.ns = M->dims[0]; g.na = M->dims[M->L];
+  g.cap_sa = capacity_rows; g.start_sa = start_sa; g.n_sa = n_sa;
+  g.halt = o->halt;
+  SmallActArgs& a = g.act;
+  a.L = M->L; a.cols = cols; a.learning = 1;
+  a.maxw = 1;
+  for (int l = 0; l <= M->L; ++l) { a.dims[l] = M->dims[l]; a.maxw = std::max(a.maxw, M->dims[l]); }
+  for (int l = 0; l < M->L; ++l) { a.acts[l] = M->acts[l]; a.woff[l] = (int)M->w_off[l]; a.boff[l] = (int)M->b_off[l]; }
+  a.nrows = M->noise_rows < 0 ? M->dims[M->L] : M->noise_rows;
+  a.p = M->params.p;
+  a.act_noise = act_noise; a.lim = act_limit; a.seed = seed; a.offset = offset;
+  const size_t lds = act_mode == 1 ? (size_t)2 * a.maxw * cols * dtype_size(dtype) : 16;
+  *served = 1;
+  ProfScope ps(M, "step_glue");
+  if (dtype == PDEC_F64 && M->dtype == PDEC_F32) hipLaunchKernelGGL((step_glue_kernel<double, float>), dim3(1), dim3(256), lds, M->stream, g);
+  else if (dtype == PDEC_F64) hipLaunchKernelGGL((step_glue_kernel<double, double>), dim3(1), dim3(256), lds, M->stream, g);
+  else hipLaunchKernelGGL((step_glue_kernel<float, float>), dim3(1), dim3(256), lds, M->stream, g);
+  PDEC_HIP(hipGetLastError());
+  return PDEC_OK;
 }
 
 static int ensure_noise_ctr(Mlp* M) {

@@ -157,6 +157,36 @@ def _episode_steps(env):
             return n
 
 
+def _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt):
+    """[POST_ACT push of step t - 1] + agent(env) + PRE_ACT push of step t as one launch (pdec_step_glue); False = not served,
+    nothing enqueued, no counter moved"""
+    import ctypes as C
+
+    from . import _lib
+    if getattr(tr, "_h", None) is None or getattr(pol, "_glue_off", False):
+        return False
+    m = pol.behavior_actor.model
+    P, na, ns = _lib.ptr, m.dims[-1], tr.state.shape[1]
+    a_t = logs.action[t + 1]
+    served = C.c_int(0)
+    cap1 = tr.capacity + tr.stride
+    n_rt = cols if pending_rt else 0
+    _lib.check(lib.pdec_step_glue(
+        m.handle, tr._h, _lib.dtype_code(env.dtype),
+        P(logs.reward[t - 1].view(-1)) if pending_rt else None, P(logs.done[t - 1:t]) if pending_rt else None, int(A), 0,
+        P(tr.reward), P(tr.terminal), tr.capacity, tr.n_rt % tr.capacity, n_rt,
+        1 if acting else 2, P(logs.state[t]), cols, float(pol.act_noise), float(pol.act_limit), pol._noise_seed, pol._noise_off,
+        P(a_t), P(tr.state), P(tr.action), cap1, tr.n_sa % cap1, cols, C.byref(served)))
+    if not served.value:
+        pol._glue_off = True          # (the answer depends on shapes and streams only)
+        return False
+    tr.n_rt += n_rt
+    tr.n_sa += cols
+    if acting:
+        pol._noise_off += (cols * na + 3) // 4
+    return True
+
+
 def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
     """RL.jl's run loop with every episode issued in one go (module docstring of run / device_episodes_ok).  Stream protocol of
     the overlapped loop: acting kernel, PRE_ACT push and the update on the networks' stream, the env step on the environment's
@@ -174,6 +204,7 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
     from .env import _on_stream
 
     pol, tr, lib = agent.policy, agent.trajectory, env.lib
+    pol._glue_off = False                     # ask the library once per run whether it serves the one-launch glue
     two = s_env.cuda_stream != s_upd.cuda_stream
     ns, A = env.setup.state_shape
     cols, na = env.B * A, env._ashape[-1]
@@ -211,14 +242,21 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
         _lib.check(lib.pdec_set_episode_halt(tr._h, P(logs.halt)))
         try:
             with _on_stream(s_upd):
+                pending_rt = False           # the POST_ACT push of step t - 1 rides on step t's glue launch
                 for t in range(T):
                     pol.update_step += 1
                     a_t = logs.action[t + 1]
-                    if pol.update_step > pol.start_steps:                      # agent(env): src/PDEagent.jl:175-209
-                        pol.act_into(logs.state[t], cols, env.dtype, a_t.view(cols, na))
-                    else:
-                        a_t.zero_()                                            # ZeroPolicy
-                    tr.push_sa(logs.state[t].view(cols, ns), a_t.view(cols, na))          # PRE_ACT :254-274
+                    acting = pol.update_step > pol.start_steps
+                    # POST_ACT push of step t - 1 (:276-289), agent(env) (:175-209; ZeroPolicy: the zero action), PRE_ACT push
+                    # (:254-274): ONE launch where the library serves it (pdec_step_glue), the three calls otherwise
+                    if not _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt):
+                        if pending_rt:
+                            tr.push_rt_flags(logs.reward[t - 1].view(-1), logs.done[t - 1:t], A, False)
+                        if acting:
+                            pol.act_into(logs.state[t], cols, env.dtype, a_t.view(cols, na))
+                        else:
+                            a_t.zero_()
+                        tr.push_sa(logs.state[t].view(cols, ns), a_t.view(cols, na))
                     if two:
                         ev_act.record(s_upd)
                         s_env.wait_event(ev_act)
@@ -228,8 +266,9 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                     if two:
                         ev_env.record(s_env)
                         s_upd.wait_event(ev_env)
-                    tr.push_rt_flags(logs.reward[t].view(-1), logs.done[t:t + 1], A, t == T - 1)      # POST_ACT :276-289
+                    pending_rt = True
                     marks.append((pol._noise_off, pol._sample_off))
+                tr.push_rt_flags(logs.reward[T - 1].view(-1), logs.done[T - 1:T], A, True)      # the last step's: a time-out
                 join()
                 # the per-step episode reward of PDEhook (src/PDEhook.jl:51-63): mean over the actuators, summed over the steps
                 means = logs.reward.reshape(T, -1).mean(dim=1)

@@ -297,6 +297,19 @@ int pdec_policy_act_rng(pdec_handle actor, const void* state, int cols, double a
  * clone of the actor in `state_dtype` (pdec_mlp_copy + pdec_policy_act_rng).  Same arithmetic, bit for bit, either way. */
 int pdec_policy_act_rng_as(pdec_handle actor, int state_dtype, const void* state, int cols, double act_noise, double act_limit,
                            int learning, uint64_t seed, uint64_t offset, void* actions_out, int* served);
+/* The glue between two control steps of a single-trajectory training loop in ONE launch (src/PDEagent.jl:276-289, :175-209,
+ * :254-274 in the order RL.jl's run loop calls them): pdec_replay_push_rt of the step that just ran (n_rt == 0: none), then
+ * agent(env) for the next step -- act_mode 1: pdec_policy_act_rng_as on `state` [cols][ns] of type `dtype` with learning = 1;
+ * 2: the zero action of the start policy; 0: none --, then pdec_replay_push_sa of (state, that action) (n_sa == 0: none; the
+ * action rows are zero when act_mode == 0).  The episode halt flag of `trajectory_handle` (pdec_set_episode_halt) is honoured
+ * and raised as by the three calls.  *served = 0 and nothing enqueued when the case is not the single-workgroup one (the caller
+ * then makes the three calls): the actor's and the trajectory handle's streams differ, the acting call would not be served by
+ * pdec_policy_act_rng_as, or a push does not fit one block.  Same stores, bit for bit. */
+int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, const void* reward, const int32_t* done_flags,
+                   int cols_per_traj, int force_terminal, void* reward_trace, void* terminal_trace, int64_t capacity,
+                   int64_t start_rt, int64_t n_rt, int act_mode, const void* state, int cols, double act_noise, double act_limit,
+                   uint64_t seed, uint64_t offset, void* actions_out, void* state_trace, void* action_trace,
+                   int64_t capacity_rows, int64_t start_sa, int64_t n_sa, int* served);
 /* the same with the noise counter kept ON THE DEVICE (one per actor handle): the kernel reads the current counter and
  * one of its threads stores the advanced value (+ ceil(cols*na/4) when learning), so no launch argument depends on how
  * many calls came before -- the form a captured HIP graph of the control step replays (pdec_capture_begin).
