@@ -75,7 +75,7 @@ SIGNATURES = {
     "pdec_policy_act_rng": [Handle, _vp, _i, _d, _d, _i, _u64, _u64, _vp],
     "pdec_policy_act_rng_as": [Handle, _i, _vp, _i, _d, _d, _i, _u64, _u64, _vp, C.POINTER(_i)],
     "pdec_step_glue": [Handle, Handle, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _i64, _i64, _i, _vp, _i, _d, _d, _u64, _u64, _vp, _vp,
-                       _vp, _i64, _i64, _i64, C.POINTER(_i)],
+                       _vp, _i64, _i64, _i64, Handle, C.POINTER(_i)],
     "pdec_ddpg_update_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _vp],
     "pdec_ddpg_update_small": [Handle] * 4 + [_vp] * 7 + [_i, _i, _d, _d, _i, _d, _d, _vp],
     "pdec_ddpg_update_critic_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _vp],

@@ -119,6 +119,8 @@ T* lookup_as(pdec_handle h, Kind k) {
   return static_cast<T*>(o);
 }
 
+hipEvent_t event_native(pdec_handle ev);      // replay.hip: the HIP event of an event handle, nullptr otherwise
+
 // wave priority from a launch argument (s_setprio takes an immediate)
 __device__ __forceinline__ void set_wave_prio(int p) {
   if (p == 1) __builtin_amdgcn_s_setprio(1);

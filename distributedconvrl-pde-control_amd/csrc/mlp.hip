@@ -1202,7 +1202,7 @@ int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, 
                    int cols_per_traj, int force_terminal, void* reward_trace, void* terminal_trace, int64_t capacity,
                    int64_t start_rt, int64_t n_rt, int act_mode, const void* state, int cols, double act_noise, double act_limit,
                    uint64_t seed, uint64_t offset, void* actions_out, void* state_trace, void* action_trace,
-                   int64_t capacity_rows, int64_t start_sa, int64_t n_sa, int* served) {
+                   int64_t capacity_rows, int64_t start_sa, int64_t n_sa, pdec_handle done_event, int* served) {
   GET_MLP(M, actor);
   Object* o = lookup(trajectory_handle);
   if (!o) { set_error("pdec_step_glue: bad trajectory handle"); return PDEC_E_HANDLE; }
@@ -1235,11 +1235,17 @@ int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, 
   a.p = M->params.p;
   a.act_noise = act_noise; a.lim = act_limit; a.seed = seed; a.offset = offset;
   const size_t lds = act_mode == 1 ? (size_t)2 * a.maxw * cols * dtype_size(dtype) : 16;
+  hipEvent_t ev = nullptr;
+  if (done_event) {
+    ev = pdec::event_native(done_event);
+    PDEC_REQUIRE(ev, "pdec_step_glue: bad event handle");
+  }
   *served = 1;
   ProfScope ps(M, "step_glue");
-  if (dtype == PDEC_F64 && M->dtype == PDEC_F32) hipLaunchKernelGGL((step_glue_kernel<double, float>), dim3(1), dim3(256), lds, M->stream, g);
-  else if (dtype == PDEC_F64) hipLaunchKernelGGL((step_glue_kernel<double, double>), dim3(1), dim3(256), lds, M->stream, g);
-  else hipLaunchKernelGGL((step_glue_kernel<float, float>), dim3(1), dim3(256), lds, M->stream, g);
+  // (done_event rides on the launch as the completion event of its dispatch packet, like pdec_mlp_set_stop_event's)
+  if (dtype == PDEC_F64 && M->dtype == PDEC_F32) hipExtLaunchKernelGGL((step_glue_kernel<double, float>), dim3(1), dim3(256), lds, M->stream, nullptr, ev, 0, g);
+  else if (dtype == PDEC_F64) hipExtLaunchKernelGGL((step_glue_kernel<double, double>), dim3(1), dim3(256), lds, M->stream, nullptr, ev, 0, g);
+  else hipExtLaunchKernelGGL((step_glue_kernel<float, float>), dim3(1), dim3(256), lds, M->stream, nullptr, ev, 0, g);
   PDEC_HIP(hipGetLastError());
   return PDEC_OK;
 }

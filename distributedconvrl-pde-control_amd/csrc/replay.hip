@@ -192,6 +192,12 @@ struct Event : Object {
   }
 };
 
+// the HIP event behind an event handle (nullptr: not an event) -- for launches in other translation units that carry one
+hipEvent_t event_native(pdec_handle ev) {
+  Event* e = lookup_as<Event>(ev, Kind::Event);
+  return e ? e->ev : nullptr;
+}
+
 extern std::vector<int*>* g_flip_log;
 
 struct Graph : Object {

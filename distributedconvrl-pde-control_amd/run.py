@@ -157,7 +157,7 @@ def _episode_steps(env):
             return n
 
 
-def _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt):
+def _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt, done_event=None):
     """[POST_ACT push of step t - 1] + agent(env) + PRE_ACT push of step t as one launch (pdec_step_glue); False = not served,
     nothing enqueued, no counter moved"""
     import ctypes as C
@@ -176,7 +176,8 @@ def _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt):
         P(logs.reward[t - 1].view(-1)) if pending_rt else None, P(logs.done[t - 1:t]) if pending_rt else None, int(A), 0,
         P(tr.reward), P(tr.terminal), tr.capacity, tr.n_rt % tr.capacity, n_rt,
         1 if acting else 2, P(logs.state[t]), cols, float(pol.act_noise), float(pol.act_limit), pol._noise_seed, pol._noise_off,
-        P(a_t), P(tr.state), P(tr.action), cap1, tr.n_sa % cap1, cols, C.byref(served)))
+        P(a_t), P(tr.state), P(tr.action), cap1, tr.n_sa % cap1, cols, done_event.h if done_event is not None else _lib.Handle(0),
+        C.byref(served)))
     if not served.value:
         pol._glue_off = True          # (the answer depends on shapes and streams only)
         return False
@@ -213,7 +214,8 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
     if logs is None or logs.T != T:
         with _on_stream(s_env):
             logs = env._episode_logs = _EpisodeLogs(env, T)
-    ev_act, ev_env = torch.cuda.Event(), torch.cuda.Event()
+    from .pipeline import _Event
+    ev_act, ev_env = _Event(lib), _Event(lib)      # device-scope events: the hand-offs are on every step's chain
     P = _lib.ptr
     np_dt = np.float64 if env.dtype == torch.float64 else np.float32
 
@@ -249,7 +251,9 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                     acting = pol.update_step > pol.start_steps
                     # POST_ACT push of step t - 1 (:276-289), agent(env) (:175-209; ZeroPolicy: the zero action), PRE_ACT push
                     # (:254-274): ONE launch where the library serves it (pdec_step_glue), the three calls otherwise
-                    if not _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt):
+                    # (the event the env step waits for rides on the glue launch: no record packet on the update's stream)
+                    glued = _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt, ev_act if two else None)
+                    if not glued:
                         if pending_rt:
                             tr.push_rt_flags(logs.reward[t - 1].view(-1), logs.done[t - 1:t], A, False)
                         if acting:
@@ -258,14 +262,15 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                             a_t.zero_()
                         tr.push_sa(logs.state[t].view(cols, ns), a_t.view(cols, na))
                     if two:
-                        ev_act.record(s_upd)
-                        s_env.wait_event(ev_act)
+                        if not glued:
+                            ev_act.record(s_upd)
+                        ev_act.wait(s_env)
                     agent._maybe_update()                                      # :342-361
                     _lib.check(lib.pdec_env_step(env.handle, P(logs.y[t]), P(a_t), P(logs.action[t]), P(logs.state[t]), P(logs.y[t + 1]),
                                                  P(logs.p[t]), P(logs.state[t + 1]), P(logs.reward[t]), P(logs.done[t:t + 1])))
                     if two:
                         ev_env.record(s_env)
-                        s_upd.wait_event(ev_env)
+                        ev_env.wait(s_upd)
                     pending_rt = True
                     marks.append((pol._noise_off, pol._sample_off))
                 tr.push_rt_flags(logs.reward[T - 1].view(-1), logs.done[T - 1:T], A, True)      # the last step's: a time-out

@@ -304,12 +304,14 @@ int pdec_policy_act_rng_as(pdec_handle actor, int state_dtype, const void* state
  * action rows are zero when act_mode == 0).  The episode halt flag of `trajectory_handle` (pdec_set_episode_halt) is honoured
  * and raised as by the three calls.  *served = 0 and nothing enqueued when the case is not the single-workgroup one (the caller
  * then makes the three calls): the actor's and the trajectory handle's streams differ, the acting call would not be served by
- * pdec_policy_act_rng_as, or a push does not fit one block.  Same stores, bit for bit. */
+ * pdec_policy_act_rng_as, or a push does not fit one block.  Same stores, bit for bit.  done_event (0: none): an event of
+ * pdec_event_create that the launch carries as its own completion event -- what pdec_event_record right behind the call would
+ * give, without the record's packet in the stream (cf. pdec_mlp_set_stop_event). */
 int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, const void* reward, const int32_t* done_flags,
                    int cols_per_traj, int force_terminal, void* reward_trace, void* terminal_trace, int64_t capacity,
                    int64_t start_rt, int64_t n_rt, int act_mode, const void* state, int cols, double act_noise, double act_limit,
                    uint64_t seed, uint64_t offset, void* actions_out, void* state_trace, void* action_trace,
-                   int64_t capacity_rows, int64_t start_sa, int64_t n_sa, int* served);
+                   int64_t capacity_rows, int64_t start_sa, int64_t n_sa, pdec_handle done_event, int* served);
 /* the same with the noise counter kept ON THE DEVICE (one per actor handle): the kernel reads the current counter and
  * one of its threads stores the advanced value (+ ceil(cols*na/4) when learning), so no launch argument depends on how
  * many calls came before -- the form a captured HIP graph of the control step replays (pdec_capture_begin).
