@@ -675,11 +675,13 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
 // critic units r * 64 + lane by the wave tree and adds the rows r in order, which is what the cross-wave exchange above does), the
 // expressions are the ones above (test_split_small_update_is_bit_identical).  Needs nA <= 64 and nC <= 448; launched for the exact
 // KS instantiation only (see the launch code).
-template <int KC, int KA, int BUT, bool EXACT>
+// NWC: the number of critic waves, a compile-time constant (3 for the KS nets' 140 critic units): the row loop of the actor wave
+// unrolls and its 18 wave sums interleave
+template <int KC, int KA, int BUT, bool EXACT, int NWC>
 __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
   const SmallArgs& g = a_in.g;
   extern __shared__ __align__(16) float sm[];
-  const int tid = threadIdx.x, nt = blockDim.x, nwc = (nt >> 6) - 1, wv = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, nt = blockDim.x, nwc = NWC, wv = tid >> 6, lane = tid & 63;
   if (g.halt && *g.halt) {
     if (tid == 0) {
       g.bpA.next[0] = g.bpA.cur[0]; g.bpA.next[1] = g.bpA.cur[1];
@@ -748,20 +750,29 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
   const float invB = 1.f / (float)Bu;
   float closs = 0.f, aloss = 0.f;
   __syncthreads();                         // the batches are staged
-  // ---- TD targets of every minibatch column, once.  a' = tanh(At(s')): actor wave, one tanhf stream over the columns
+  // ---- TD targets of every minibatch column, once.  a' = tanh(At(s')): actor wave, one tanhf stream over the columns.
+  // Columns go four at a time: their wave sums are independent dependency chains (six DPP adds with hazard waits each) that
+  // the scheduler interleaves inside one block -- one column per trip cost 15 us of the launch, a quarter of it.
+  constexpr int PG = 4;
   if (actor_wave) {
     for (int col0 = 0; col0 < ncol; col0 += 64) {
       float mine = 0.f;
       const int nc = min(64, ncol - col0);
-      for (int cc = 0; cc < nc; ++cc) {
-        const int col = col0 + cc, it = col / Bu, c = col - it * Bu;
-        const float* bsn = batch + it * bstride;
-        float zt = ab1t;
+      for (int cc0 = 0; cc0 < nc; cc0 += PG) {
+        float S[PG];
 #pragma unroll
-        for (int k = 0; k < KA; ++k)
-          if (k < ns) zt += aw1t[k] * bsn[k * Bu + c];
-        const float S = s2_wave_sum(isA ? aw2t * fmaxf(zt, 0.f) : 0.f);
-        if (lane == cc) mine = S;
+        for (int u = 0; u < PG; ++u) {
+          const int col = min(col0 + cc0 + u, ncol - 1), it = col / Bu, c = col - it * Bu;
+          const float* bsn = batch + it * bstride;
+          float zt = ab1t;
+#pragma unroll
+          for (int k = 0; k < KA; ++k)
+            if (k < ns) zt += aw1t[k] * bsn[k * Bu + c];
+          S[u] = s2_wave_sum(isA ? aw2t * fmaxf(zt, 0.f) : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PG; ++u)
+          if (lane == cc0 + u) mine = S[u];
       }
       if (lane < nc) tan_[col0 + lane] = tanhf((0.f + mine) + ab2t);
     }
@@ -769,17 +780,24 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
   __syncthreads();
   // qt = Ct([s'; a']): critic waves (their threads hold the target critic's units), wave sums by column
   if (!actor_wave) {
-    for (int col = 0; col < ncol; ++col) {
-      const int it = col / Bu, c = col - it * Bu;
-      const float* bsn = batch + it * bstride;
-      const float an = tan_[col];
-      float zt = cb1t;
+    for (int col0 = 0; col0 < ncol; col0 += PG) {
+      float S[PG];
 #pragma unroll
-      for (int k = 0; k < KC; ++k)
-        if (k < ns) zt += cw1t[k] * bsn[k * Bu + c];
-        else if (k == ns) zt += cw1t[k] * an;
-      const float S = s2_wave_sum(isC ? cw2t * fmaxf(zt, 0.f) : 0.f);
-      if (lane == 0) tpart[wv * ncol + col] = S;
+      for (int u = 0; u < PG; ++u) {
+        const int col = min(col0 + u, ncol - 1), it = col / Bu, c = col - it * Bu;
+        const float* bsn = batch + it * bstride;
+        const float an = tan_[col];
+        float zt = cb1t;
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+          if (k < ns) zt += cw1t[k] * bsn[k * Bu + c];
+          else if (k == ns) zt += cw1t[k] * an;
+        S[u] = s2_wave_sum(isC ? cw2t * fmaxf(zt, 0.f) : 0.f);
+      }
+      if (lane == 0)
+#pragma unroll
+        for (int u = 0; u < PG; ++u)
+          if (col0 + u < ncol) tpart[wv * ncol + col0 + u] = S[u];
     }
   }
   __syncthreads();
@@ -918,7 +936,8 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
         float vq[BUT], vd[BUT];
 #pragma unroll
         for (int c = 0; c < BUT; ++c) vq[c] = vd[c] = 0.f;
-        for (int r = 0; r < nwc; ++r) {
+#pragma unroll
+        for (int r = 0; r < NWC; ++r) {
           const int u = r * 64 + lane;
           float w1[KC];
 #pragma unroll
@@ -1099,18 +1118,18 @@ static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hA
     const size_t lds2 = (lds2f + tab_floats) * 4;
     ProfScope ps(C, "ddpg_small");
     // frozen targets (the KS experiments' regime): the critic and the actor updates as two chains side by side (ddpg_small2f_kernel).
-    // Only the exact KS instantiation (ns 1, batch 3: KS22 / KS200 / KS500): there every guard folds at compile time and the
+    // Only the exact KS instantiation (ns 1, batch 3, 129 - 192 critic units: KS22 / KS200 / KS500): there every guard folds at compile time and the
     // backend fuses multiplies and adds the same way in both kernels, which is what makes them agree bit for bit; the bounded
     // instantiations differ in the last place of the actor's gradient (a product fused into one kernel's sum and not the other's).
     const char* nosplit = getenv("PDEC_SMALL_SPLIT");      // (read per launch: the identity test switches it)
     const int nwc = (a2.nC + 63) / 64;
-    if (a2.g.rho == 1.0f && Bu == 3 && ns == 1 && a2.nA <= 64 && nwc <= 7 && !(nosplit && nosplit[0] == '0')) {
+    if (a2.g.rho == 1.0f && Bu == 3 && ns == 1 && a2.nA <= 64 && nwc == 3 && !(nosplit && nosplit[0] == '0')) {
       const int ntf = (nwc + 1) * 64, ncol = loops * Bu;
       const size_t ldsf = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * S2_NW * S2_ROW + (size_t)ncol * (2 + S2_NW) +
                           (size_t)2 * ((2 + 2) * nwc * 64 + 4);
       if ((ldsf + tab_floats) * 4 <= 150 * 1024) {
         a2.g.smp_lds = (int)ldsf;
-        hipLaunchKernelGGL((ddpg_small2f_kernel<2, 1, 3, true>), dim3(1), dim3(ntf), (ldsf + tab_floats) * 4, C->stream, a2);
+        hipLaunchKernelGGL((ddpg_small2f_kernel<2, 1, 3, true, 3>), dim3(1), dim3(ntf), (ldsf + tab_floats) * 4, C->stream, a2);
         PDEC_HIP(hipGetLastError());
         bp_done(A);
         bp_done(C);
