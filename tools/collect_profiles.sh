@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the per-round profile artifacts on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r03z [c2|c4|c5|all]   -> gpurun_out/<tag>_*; copy what is to be judged into profiles/
+#   bash tools/collect_profiles.sh r03z [c2|c4|c5|b1|all]   -> gpurun_out/<tag>_*; copy what is to be judged into profiles/
 set -u
 TAG=${1:-rXX}
 WHAT=${2:-all}
@@ -61,6 +61,14 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "c5" ]; then
   unset PDEC_FLUID_SPLIT
   python bench.py --config C5 2>/dev/null | tail -1 > $O/${TAG}_c5_bench.json
   PDEC_BENCH_BACKEND=gloo python bench.py --config C5 --gpus 2 --batch 4 --nx 128 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_c5_bench_n2_gloo_one_gpu_128.json
+fi
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "b1" ]; then
+  # the reference-shaped single-trajectory training loop (KS22: B = 1, 20 x 3 updates per step) through run(): rate, then the kernel
+  # statistics of the same command
+  for w in ks22 kseg fluid; do python3 tools/b1_probe.py $w --two-streams 2>/dev/null | tail -3; done > $O/${TAG}_b1_probe.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_b1trace -- python3 tools/b1_probe.py ks22 --two-streams > /dev/null 2> $O/${TAG}_b1_rocprof.log
+  cp $(ls $O/${TAG}_b1trace/*/*kernel_stats.csv | head -1) $O/${TAG}_b1_ks22_kernel_stats.csv
+  rm -rf $O/${TAG}_b1trace
 fi
 # the driver's own command last (headline + variants + CPU baselines): the PMC traffic files this build's lines cite must be
 # in profiles/ for roofline.traffic -- copy gpurun_out/${TAG}_*pmc_traffic.json there and re-run `python bench.py` if they were not
