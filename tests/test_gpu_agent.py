@@ -552,6 +552,67 @@ def test_split_small_update_is_bit_identical(pkg, which, monkeypatch):
     assert not np.array_equal(fresh.behavior_critic.model.params()[0], p0.behavior_critic.model.params()[0])
 
 
+@pytest.mark.parametrize("case", ["mid_episode", "zero_policy", "episode_ends_here", "episode_ended_before"])
+def test_step_glue_equals_the_three_launches(pkg, case):
+    """pdec_step_glue (POST_ACT push of step t - 1 + agent(env) + PRE_ACT push of step t in ONE launch) == the three calls the
+    stage loop makes (replay_push_rt, the acting kernel, replay_push_sa): same traces, same action, same halt flag -- in the
+    middle of an episode, under the start policy's zero action, when step t - 1 ended the episode (its terminal transition is
+    pushed, the flag raised, the PRE_ACT push skipped) and when the episode had ended before (nothing pushed)."""
+    import ctypes as C
+    from importlib import import_module
+    from types import SimpleNamespace
+    runmod, L = import_module(pkg.__name__ + ".run"), pkg._lib
+    setup = pkg.KSSetup.KS22()
+    ns, A = setup.state_shape
+    out = []
+    for glue in (True, False):
+        agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=320)
+        pol, tr = agent.policy, agent.trajectory
+        g = torch.Generator().manual_seed(11)
+        for _ in range(7):
+            tr.push_sa(torch.randn(A, ns, generator=g).cuda(), (torch.rand(A, 1, generator=g) * 2 - 1).cuda())
+            tr.push_rt(-torch.rand(A, generator=g).cuda(), torch.zeros(A).cuda())
+        tr.push_sa(torch.randn(A, ns, generator=g).cuda(), (torch.rand(A, 1, generator=g) * 2 - 1).cuda())     # step t - 1's (s, a)
+        dt = torch.float64
+        logs = SimpleNamespace(state=torch.randn(3, A, ns, generator=g).to(dt).cuda(), action=torch.zeros(3, A, 1, dtype=dt).cuda(),
+                               reward=-torch.rand(3, 1, A, generator=g).to(dt).cuda(), done=torch.zeros(3, dtype=torch.int32).cuda())
+        halt = torch.zeros(1, dtype=torch.int32).cuda()
+        if case == "episode_ends_here":
+            logs.done[0] = 1
+        if case == "episode_ended_before":
+            halt[0] = 1
+        pol._noise_seed, pol._noise_off = 99, 5
+        env = SimpleNamespace(dtype=dt)
+        acting = case != "zero_policy"
+        t = 1
+        lib = pol.behavior_actor.model.lib
+        L.check(lib.pdec_set_episode_halt(tr._h, L.ptr(halt)))
+        try:
+            if glue:
+                pol._glue_off = False
+                assert runmod._step_glue(lib, pol, tr, env, logs, t, A, A, acting, True)
+            else:
+                tr.push_rt_flags(logs.reward[t - 1].view(-1), logs.done[t - 1:t], A, False)
+                a_t = logs.action[t + 1]
+                if acting:
+                    pol.act_into(logs.state[t], A, dt, a_t.view(A, 1))
+                else:
+                    a_t.zero_()
+                tr.push_sa(logs.state[t].view(A, ns), a_t.view(A, 1))
+        finally:
+            torch.cuda.synchronize()
+            L.check(lib.pdec_set_episode_halt(tr._h, None))
+        out.append(dict(state=tr.state.cpu().numpy().copy(), action=tr.action.cpu().numpy().copy(), reward=tr.reward.cpu().numpy().copy(),
+                        terminal=tr.terminal.cpu().numpy().copy(), a=logs.action.cpu().numpy().copy(), halt=int(halt.item()),
+                        noise=pol._noise_off, n_sa=tr.n_sa, n_rt=tr.n_rt))
+    a, b = out
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["halt"] == (1 if case.startswith("episode_end") else 0)
+    if acting:
+        assert np.abs(a["a"][2]).max() > 0 and a["noise"] == 5 + (A + 3) // 4
+
+
 def test_random_init_kernels_match_the_oracle_stream(pkg):
     """pdec_env_random_init (generate_random_init of KSSetup.jl:288-298 / KellerSegelSetup.jl:373-384 as a kernel) against
     the oracle's formulas evaluated with the coefficients of the same Philox stream (oracle/rng.py)"""
