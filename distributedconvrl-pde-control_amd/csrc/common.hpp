@@ -45,6 +45,43 @@ struct ProfEntry {
   int reps = 1;   // launches bracketed by each event pair (replay timing, see ProfScope::reps)
 };
 
+// pdec_set_launch_sync: a device-side hand-over between two single-workgroup launches that sit on DIFFERENT streams.  The
+// consumer launch spins (one thread, sleeping between polls, bounded by SYNC_TIMEOUT_TICKS of the 100-MHz counter) until
+// *wait >= wait_val before it touches its inputs; the producer launch stores done_val to *done when its outputs are written
+// (agent-scope release / acquire: the two workgroups may run on different XCDs).  A stream-level event pair costs the chain of
+// the single-trajectory training loop ~11 us per hop (signal -> barrier packet of the other queue -> dispatch); this ~2 - 3 us.
+struct LaunchSync {
+  const long long* wait = nullptr;
+  long long wait_val = 0;
+  long long* done = nullptr;
+  long long done_val = 0;
+  int* timeouts = nullptr;       // device counter of waits that gave up (pdec_launch_sync_timeouts)
+};
+#define PDEC_SYNC_TIMEOUT_TICKS 30000000ull      // 0.3 s: a hand-over that has not come by then never will
+
+// every thread of the workgroup calls it before the launch's first read of what the producer writes
+__device__ __forceinline__ void launch_sync_wait(const LaunchSync& s) {
+  if (!s.wait) return;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(s.wait, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < s.wait_val) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > PDEC_SYNC_TIMEOUT_TICKS) {     // the exit every wait reaches
+        if (s.timeouts) atomicAdd(s.timeouts, 1);
+        break;
+      }
+    }
+    __builtin_amdgcn_s_dcache_inv();
+  }
+  __syncthreads();
+}
+// every thread calls it behind the launch's last store
+__device__ __forceinline__ void launch_sync_done(const LaunchSync& s) {
+  if (!s.done) return;
+  __syncthreads();               // the workgroup's stores have left for L2
+  if (threadIdx.x == 0) __hip_atomic_store(s.done, s.done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct Object {
   Kind kind;
   hipStream_t stream = nullptr;
@@ -57,6 +94,8 @@ struct Object {
   // change persistent learner state through this handle -- replay pushes, the small-batch DDPG update -- do nothing once it is
   // raised, and the POST_ACT push raises it when the environment reported the end of the episode (B = 1)
   int* halt = nullptr;
+  // pdec_set_launch_sync: one-shot, consumed (and cleared) by the next launch through this handle that supports it
+  LaunchSync sync;
   explicit Object(Kind k) : kind(k) {}
   virtual ~Object();
 };
@@ -120,6 +159,7 @@ T* lookup_as(pdec_handle h, Kind k) {
 }
 
 hipEvent_t event_native(pdec_handle ev);      // replay.hip: the HIP event of an event handle, nullptr otherwise
+int* launch_sync_timeout_counter();            // replay.hip: the device counter behind pdec_launch_sync_timeouts (nullptr: allocation failed)
 
 // wave priority from a launch argument (s_setprio takes an immediate)
 __device__ __forceinline__ void set_wave_prio(int p) {

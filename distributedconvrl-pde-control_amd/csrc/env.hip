@@ -841,7 +841,9 @@ template <class T> using FftFixed240 = FftFixed<T, 240, 4, 4, 5, 3, 4, 1>;
 template <class T> using FftFixed600 = FftFixed<T, 600, 5, 4, 5, 5, 2, 3>;
 
 // SHARE (pdec_env_set_simd_sharing; fp32 single-wave engine only): the 64-VGPR form of the kernel, see below
-template <class T, class ENG, bool FUSED, bool SHARE = false>
+// SYNC (pdec_set_launch_sync; single-workgroup launches of the reference's own shapes): wait for the producer of the action
+// before anything is read, signal behind the last store -- a separate instantiation, so that the batched kernels keep their code
+template <class T, class ENG, bool FUSED, bool SHARE = false, bool SYNC = false>
 __global__ void __launch_bounds__(ENG::kThreads, SHARE ? 8 : 1) ks_env_step_kernel(EnvDev<T> e, const T* __restrict__ y_in, const T* __restrict__ p_in,
                                    const T* __restrict__ action, const T* __restrict__ action_prev,
                                    const T* __restrict__ state_prev, T* __restrict__ y_out,
@@ -849,6 +851,7 @@ __global__ void __launch_bounds__(ENG::kThreads, SHARE ? 8 : 1) ks_env_step_kern
                                    T* __restrict__ reward_out, int32_t* __restrict__ done) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = e.N, tid = threadIdx.x, nt = blockDim.x;
+  if constexpr (SYNC) launch_sync_wait(e.sync);
   // This kernel is a long dependent chain (63 FFTs) issued by very few waves.  Beside the f32-MFMA update passes (which
   // execute on the vector unit) each of its instructions waits for an MFMA to drain (~2.7x slower), and their eight waves
   // per workgroup wait for each other at barriers; on its own it runs at priority 1, below the passes at 2 (r02f).
@@ -1088,6 +1091,7 @@ __global__ void __launch_bounds__(ENG::kThreads, SHARE ? 8 : 1) ks_env_step_kern
       }
     }
   }
+  if constexpr (SYNC) launch_sync_done(e.sync);
 }
 
 // ------------------------------------------------------------------ persistent KS rollout (row F2)
@@ -2082,6 +2086,29 @@ static int launch_step(Env& E, bool fused, int mode, const void* y_in, const voi
                        void* state_out, void* reward_out, int32_t* done) {
   EnvDev<T> e = make_dev<T>(E);
   const pdec_env_cfg& c = E.cfg;
+  const LaunchSync sync = E.sync;
+  E.sync = LaunchSync{};
+  if (sync.wait || sync.done) {        // served by the SYNC instantiations below, refused everywhere else
+    const bool ok = c.pde_kind == PDEC_PDE_KS_CNAB2 && fused && c.B <= 2 && sizeof(T) == 8 && (E.r4_log == 7 || E.r4_log == 8 || E.r4_log == 9) &&
+                    !(E.prof && E.prof_reps > 1);
+    PDEC_REQUIRE(ok, "pdec_env_step: a launch sync is set (pdec_set_launch_sync) and this step is not the fused single-workgroup fp64 "
+                     "KS step of 192 / 240 / 600 cells");
+    if constexpr (sizeof(T) == 8) {
+      e.sync = sync;
+      const dim3 grid1(1), block1(E.nthreads);
+      ProfScope ps(&E, "ks_env_step");
+#define KS_SYNC_LAUNCH(ENG)                                                                                                       \
+  hipLaunchKernelGGL((ks_env_step_kernel<T, ENG, true, false, true>), grid1, block1, E.lds_bytes, E.stream, e, (const T*)y_in,   \
+                     (const T*)p, (const T*)action, (const T*)action_prev, (const T*)state_prev, (T*)y_out, (T*)p_out,           \
+                     (T*)state_out, (T*)reward_out, done)
+      if (E.r4_log == 7) KS_SYNC_LAUNCH(FftFixed192<T>);
+      else if (E.r4_log == 8) KS_SYNC_LAUNCH(FftFixed240<T>);
+      else KS_SYNC_LAUNCH(FftFixed600<T>);
+#undef KS_SYNC_LAUNCH
+      PDEC_HIP(hipGetLastError());
+      return PDEC_OK;
+    }
+  }
   if (c.pde_kind == PDEC_PDE_KS_CNAB2) {
     dim3 grid((c.B + 1) / 2), block(E.nthreads);
     // replay is safe when the step does not run in place (y_out != y_in)

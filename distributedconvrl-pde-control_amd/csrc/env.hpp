@@ -29,6 +29,7 @@ struct EnvDev {
   const C2<T>* dhat;     // h * fft(mu cos(...))
   const C2<T>* tw;       // exp(-2 pi i k/N)
   FftPlan fft;
+  LaunchSync sync;       // pdec_set_launch_sync (SYNC instantiations of the fused KS step only)
 };
 
 struct Env : Object {

@@ -1075,11 +1075,13 @@ struct StepGlueArgs {
   int ns, na;
   long long cap_sa, start_sa, n_sa;
   int* halt;
+  LaunchSync sync;             // pdec_set_launch_sync on the actor's handle: wait before the first read, signal behind the last store
 };
 template <class T, class TP>
 __global__ __launch_bounds__(256) void step_glue_kernel(StepGlueArgs g) {
   extern __shared__ __align__(16) unsigned char small_act_smem[];
   const int tid = threadIdx.x;
+  launch_sync_wait(g.sync);           // (the env step that wrote reward / done / state, on another stream)
   const bool was = g.halt && *g.halt;
   const bool ended = was || (g.halt && g.n_rt && g.done && g.done[0] != 0);
   if (g.n_rt && !was) {
@@ -1113,6 +1115,7 @@ __global__ __launch_bounds__(256) void step_glue_kernel(StepGlueArgs g) {
       }
     }
   }
+  launch_sync_done(g.sync);
 }
 
 // does the single-launch form serve this actor at `cols` columns of type `dtype`?  (the fused MFMA acting kernels keep fp32
@@ -1198,6 +1201,19 @@ int pdec_policy_act_rng_as(pdec_handle actor, int state_dtype, const void* state
   return small_act(M, state_dtype, state, cols, act_noise, act_limit, learning, seed, offset, actions_out, nullptr, nullptr, 0);
 }
 
+// does pdec_step_glue serve this case (see there)?
+static bool step_glue_served(const Mlp* M, const Object* o, int dtype, int act_mode, int cols, int64_t n_rt) {
+  return o->stream == M->stream && n_rt <= 256 && !(act_mode == 1 && (!small_act_ok(M, dtype, cols) || M->dtype == dtype));
+}
+int pdec_step_glue_served(pdec_handle actor, pdec_handle trajectory_handle, int dtype, int act_mode, int cols, int64_t n_rt, int* served) {
+  GET_MLP(M, actor);
+  Object* o = lookup(trajectory_handle);
+  if (!o) { set_error("pdec_step_glue_served: bad trajectory handle"); return PDEC_E_HANDLE; }
+  PDEC_REQUIRE(served && (dtype == PDEC_F32 || dtype == PDEC_F64), "pdec_step_glue_served: bad argument");
+  *served = step_glue_served(M, o, dtype, act_mode, cols, n_rt) ? 1 : 0;
+  return PDEC_OK;
+}
+
 int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, const void* reward, const int32_t* done_flags,
                    int cols_per_traj, int force_terminal, void* reward_trace, void* terminal_trace, int64_t capacity,
                    int64_t start_rt, int64_t n_rt, int act_mode, const void* state, int cols, double act_noise, double act_limit,
@@ -1212,7 +1228,12 @@ int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, 
   *served = 0;
   // served where the three launches it stands for would be the single-workgroup ones: the few-column acting kernel of
   // pdec_policy_act_rng_as (state of another type than the networks), single-block pushes, one stream
-  if (o->stream != M->stream || n_rt > 256 || (act_mode == 1 && (!small_act_ok(M, dtype, cols) || M->dtype == dtype))) return PDEC_OK;
+  if (!step_glue_served(M, o, dtype, act_mode, cols, n_rt)) {
+    const bool had = M->sync.wait || M->sync.done;
+    M->sync = LaunchSync{};
+    PDEC_REQUIRE(!had, "pdec_step_glue: a launch sync is set (pdec_set_launch_sync) and this case is not served");
+    return PDEC_OK;
+  }
   PDEC_REQUIRE(!n_rt || (reward && reward_trace && terminal_trace && capacity >= 1 && n_rt <= capacity && cols_per_traj >= 1 && start_rt >= 0),
                "pdec_step_glue: bad POST_ACT push");
   PDEC_REQUIRE(!n_sa || (state && state_trace && action_trace && capacity_rows >= 1 && n_sa <= capacity_rows && start_sa >= 0),
@@ -1226,6 +1247,8 @@ int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, 
   g.ts = (float*)state_trace; g.ta = (float*)action_trace; g.ns = M->dims[0]; g.na = M->dims[M->L];
   g.cap_sa = capacity_rows; g.start_sa = start_sa; g.n_sa = n_sa;
   g.halt = o->halt;
+  g.sync = M->sync;
+  M->sync = LaunchSync{};
   SmallActArgs& a = g.act;
   a.L = M->L; a.cols = cols; a.learning = 1;
   a.maxw = 1;

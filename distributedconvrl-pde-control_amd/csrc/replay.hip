@@ -192,6 +192,17 @@ struct Event : Object {
   }
 };
 
+int* launch_sync_timeout_counter() {
+  static int* ctr = [] {
+    int* p = nullptr;
+    if (hipMalloc(&p, sizeof(int)) != hipSuccess) return (int*)nullptr;
+    const int zero = 0;
+    if (hipMemcpy(p, &zero, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return (int*)nullptr;
+    return p;
+  }();
+  return ctr;
+}
+
 // the HIP event behind an event handle (nullptr: not an event) -- for launches in other translation units that carry one
 hipEvent_t event_native(pdec_handle ev) {
   Event* e = lookup_as<Event>(ev, Kind::Event);
@@ -267,6 +278,27 @@ int pdec_set_episode_halt(pdec_handle any_handle, int32_t* flag) {
   Object* o = lookup(any_handle);
   if (!o) { set_error("pdec_set_episode_halt: bad handle"); return PDEC_E_HANDLE; }
   o->halt = flag;
+  return PDEC_OK;
+}
+
+// Device-side hand-over for the NEXT launch through `handle` that supports it (pdec_step_glue through the actor's handle; the
+// fused single-workgroup KS env step through the environment's): see LaunchSync in common.hpp.  A launch path that does not
+// support it fails with PDEC_E_INVALID instead of ignoring it (the other side would wait for nothing).
+int pdec_set_launch_sync(pdec_handle handle, const int64_t* wait_flag, int64_t wait_value, int64_t* done_flag, int64_t done_value) {
+  Object* o = lookup(handle);
+  if (!o) { set_error("pdec_set_launch_sync: bad handle"); return PDEC_E_HANDLE; }
+  o->sync.wait = reinterpret_cast<const long long*>(wait_flag); o->sync.wait_val = wait_value;
+  o->sync.done = reinterpret_cast<long long*>(done_flag); o->sync.done_val = done_value;
+  o->sync.timeouts = (wait_flag || done_flag) ? launch_sync_timeout_counter() : nullptr;
+  return PDEC_OK;
+}
+
+// waits that gave up since the library was loaded (each one a hand-over that never came: a caller's protocol error)
+int pdec_launch_sync_timeouts(int* n) {
+  PDEC_REQUIRE(n, "pdec_launch_sync_timeouts: null");
+  int* c = launch_sync_timeout_counter();
+  PDEC_REQUIRE(c, "pdec_launch_sync_timeouts: no device counter");
+  PDEC_HIP(hipMemcpy(n, c, sizeof(int), hipMemcpyDeviceToHost));
   return PDEC_OK;
 }
 

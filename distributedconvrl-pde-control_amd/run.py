@@ -157,6 +157,14 @@ def _episode_steps(env):
             return n
 
 
+def _launch_sync_ok(env):
+    """the fused fp64 KS step of one trajectory with 192 / 240 / 600 cells: the launch that honours pdec_set_launch_sync"""
+    import torch
+    s = env.setup
+    return (getattr(s, "integrator", None) == "cnab2" and getattr(s, "nx", 0) in (192, 240, 600) and env.B == 1
+            and env.dtype == torch.float64 and not getattr(s, "memory_size", 0))
+
+
 def _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt, done_event=None):
     """[POST_ACT push of step t - 1] + agent(env) + PRE_ACT push of step t as one launch (pdec_step_glue); False = not served,
     nothing enqueued, no counter moved"""
@@ -217,6 +225,18 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
     from .pipeline import _Event
     ev_act, ev_env = _Event(lib), _Event(lib)      # device-scope events: the hand-offs are on every step's chain
     P = _lib.ptr
+    # device-side hand-overs (see the step loop): flags [glue, env step] and the sequence number of the step they count
+    sync, seq = None, [0]
+    if two and _launch_sync_ok(env) and getattr(tr, "_h", None) is not None:
+        ok = C.c_int(0)
+        _lib.check(lib.pdec_step_glue_served(pol.behavior_actor.model.handle, tr._h, _lib.dtype_code(env.dtype), 1, cols, cols,
+                                             C.byref(ok)))
+        if ok.value:
+            with _on_stream(s_env):
+                sync = torch.zeros(2, dtype=torch.int64, device=env.device)
+            nto = C.c_int(0)
+            _lib.check(lib.pdec_launch_sync_timeouts(C.byref(nto)))
+            timeouts0 = [nto.value]
     np_dt = np.float64 if env.dtype == torch.float64 else np.float32
 
     def join():
@@ -251,8 +271,16 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                     acting = pol.update_step > pol.start_steps
                     # POST_ACT push of step t - 1 (:276-289), agent(env) (:175-209; ZeroPolicy: the zero action), PRE_ACT push
                     # (:254-274): ONE launch where the library serves it (pdec_step_glue), the three calls otherwise
-                    # (the event the env step waits for rides on the glue launch: no record packet on the update's stream)
-                    glued = _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt, ev_act if two else None)
+                    # Hand-overs between the two streams: where the library serves both ends (the glue launch and the fused fp64
+                    # KS step) they happen INSIDE the kernels -- the glue waits for env step t - 1's flag and raises its own,
+                    # which env step t waits for (pdec_set_launch_sync; ~11 us per stream-level hop otherwise) --; else the
+                    # event the env step waits for rides on the glue launch (no record packet on the update's stream)
+                    if sync is not None:
+                        seq[0] += 1
+                        _lib.check(lib.pdec_set_launch_sync(pol.behavior_actor.model.handle,
+                                                            P(sync[1:2]) if pending_rt else None, seq[0] - 1, P(sync[0:1]), seq[0]))
+                    glued = _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt,
+                                       ev_act if (two and sync is None) else None)
                     if not glued:
                         if pending_rt:
                             tr.push_rt_flags(logs.reward[t - 1].view(-1), logs.done[t - 1:t], A, False)
@@ -261,14 +289,16 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                         else:
                             a_t.zero_()
                         tr.push_sa(logs.state[t].view(cols, ns), a_t.view(cols, na))
-                    if two:
+                    if two and sync is None:
                         if not glued:
                             ev_act.record(s_upd)
                         ev_act.wait(s_env)
                     agent._maybe_update()                                      # :342-361
+                    if sync is not None:
+                        _lib.check(lib.pdec_set_launch_sync(env.handle, P(sync[0:1]), seq[0], P(sync[1:2]), seq[0]))
                     _lib.check(lib.pdec_env_step(env.handle, P(logs.y[t]), P(a_t), P(logs.action[t]), P(logs.state[t]), P(logs.y[t + 1]),
                                                  P(logs.p[t]), P(logs.state[t + 1]), P(logs.reward[t]), P(logs.done[t:t + 1])))
-                    if two:
+                    if two and (sync is None or t == T - 1):                   # (the last step's push is a launch of its own)
                         ev_env.record(s_env)
                         ev_env.wait(s_upd)
                     pending_rt = True
@@ -280,6 +310,12 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                 flags = logs.done.cpu().numpy()                                # the one read-back (waits for the whole episode)
         finally:
             _lib.check(lib.pdec_set_episode_halt(tr._h, None))
+        if sync is not None:               # a hand-over that never came (0.3 s each) means the results are not the stage loop's
+            nto = C.c_int(0)
+            _lib.check(lib.pdec_launch_sync_timeouts(C.byref(nto)))
+            if nto.value != timeouts0[0]:
+                timeouts0[0] = nto.value
+                raise RuntimeError("run(device_episodes): a device-side hand-over between the glue launch and the env step timed out")
         bad = np.flatnonzero(flags)
         n = int(bad[0]) + 1 if bad.size and bad[0] < T - 1 else T
         # ---- settle the host state at n executed steps

@@ -312,6 +312,8 @@ int pdec_step_glue(pdec_handle actor, pdec_handle trajectory_handle, int dtype, 
                    int64_t start_rt, int64_t n_rt, int act_mode, const void* state, int cols, double act_noise, double act_limit,
                    uint64_t seed, uint64_t offset, void* actions_out, void* state_trace, void* action_trace,
                    int64_t capacity_rows, int64_t start_sa, int64_t n_sa, pdec_handle done_event, int* served);
+/* would pdec_step_glue serve (act_mode, cols columns of type dtype, a POST_ACT push of n_rt values)?  Nothing is enqueued. */
+int pdec_step_glue_served(pdec_handle actor, pdec_handle trajectory_handle, int dtype, int act_mode, int cols, int64_t n_rt, int* served);
 /* the same with the noise counter kept ON THE DEVICE (one per actor handle): the kernel reads the current counter and
  * one of its threads stores the advanced value (+ ceil(cols*na/4) when learning), so no launch argument depends on how
  * many calls came before -- the form a captured HIP graph of the control step replays (pdec_capture_begin).
@@ -493,6 +495,17 @@ int pdec_mlp_flush_stop_event(pdec_handle mlp);
 int pdec_event_create(pdec_handle* ev);
 int pdec_event_record(pdec_handle ev, void* hip_stream);
 int pdec_stream_wait_event(void* hip_stream, pdec_handle ev);
+
+/* A device-side hand-over between two single-workgroup launches on DIFFERENT streams, for the NEXT launch through `handle`
+ * that supports it -- pdec_step_glue (the actor's handle) and the fused fp64 KS step of one trajectory with 192 / 240 / 600 cells
+ * in pdec_env_step (the environment's handle), the two launches that alternate on the chain of the reference-shaped training loop
+ * (src/PDEenv.jl:195-241 and src/PDEagent.jl:175-289 in RL.jl's run order): the launch waits inside the kernel until
+ * *wait_flag >= wait_value before it reads anything (NULL: no wait; the wait gives up after 0.3 s and counts a timeout) and
+ * stores done_value to *done_flag behind its last store (NULL: no signal).  Flags: device int64, zeroed by the caller, values
+ * increasing.  One-shot: cleared by the launch.  PDEC_E_INVALID from a launch that cannot honour a pending one. */
+int pdec_set_launch_sync(pdec_handle handle, const int64_t* wait_flag, int64_t wait_value, int64_t* done_flag, int64_t done_value);
+/* waits that gave up since the library was loaded (synchronous read) */
+int pdec_launch_sync_timeouts(int* n);
 
 /* ---------------------------------------------------------------- multi-GPU ---------- */
 /* One RCCL communicator per process (one process per GPU).  unique_id: 128 bytes from

@@ -613,6 +613,74 @@ def test_step_glue_equals_the_three_launches(pkg, case):
         assert np.abs(a["a"][2]).max() > 0 and a["noise"] == 5 + (A + 3) // 4
 
 
+def test_launch_sync_hand_over_refusal_and_timeout(pkg):
+    """pdec_set_launch_sync (device-side hand-over between the glue launch and the fused fp64 KS step of one trajectory):
+    (a) producer and consumer on two streams: the env step waits INSIDE the kernel for the flag the glue launch raises and
+    raises its own; (b) a launch that cannot honour a pending sync refuses (PDEC_E_INVALID) instead of ignoring it; (c) a wait
+    whose hand-over never comes gives up after 0.3 s, counts a timeout, and the launch still completes."""
+    import ctypes as C
+    import time
+    L = pkg._lib
+    setup = pkg.KSSetup.KS22()
+    ns, A = setup.state_shape
+    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
+    env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
+    agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=320, stream=s_upd)
+    pol, tr, lib = agent.policy, agent.trajectory, env.lib
+    m = pol.behavior_actor.model
+    flags = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    n0 = C.c_int(0)
+    L.check(lib.pdec_launch_sync_timeouts(C.byref(n0)))
+    # (a) env step first in issue order, on its own stream: it can only proceed once the glue launch (issued later) has signalled
+    y1, st1 = torch.empty_like(env.y), torch.empty_like(env.state)
+    p1, r1 = torch.empty_like(env.p), torch.empty_like(env.reward)
+    done = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    a_t = torch.zeros(1, A, 1, dtype=torch.float64, device="cuda:0")
+    a_prev = torch.zeros_like(a_t)
+    P = L.ptr
+    with torch.cuda.stream(s_env):
+        L.check(lib.pdec_set_launch_sync(env.handle, P(flags[0:1]), 1, P(flags[1:2]), 1))
+        L.check(lib.pdec_env_step(env.handle, P(env.y), P(a_t), P(a_prev), P(env.state), P(y1), P(p1), P(st1), P(r1), P(done)))
+    time.sleep(0.02)
+    assert int(flags[1].item()) == 0                      # still waiting (flags read on the null stream)
+    served = C.c_int(0)
+    pol._noise_seed, pol._noise_off = 3, 0
+    with torch.cuda.stream(s_upd):
+        L.check(lib.pdec_set_launch_sync(m.handle, None, 0, P(flags[0:1]), 1))
+        cap1 = tr.capacity + tr.stride
+        L.check(lib.pdec_step_glue(m.handle, tr._h, L.dtype_code(torch.float64), None, None, A, 0, P(tr.reward), P(tr.terminal),
+                                   tr.capacity, 0, 0, 1, P(env.state), A, float(pol.act_noise), float(pol.act_limit), 3, 0, P(a_t),
+                                   P(tr.state), P(tr.action), cap1, 0, A, L.Handle(0), C.byref(served)))
+    assert served.value == 1
+    torch.cuda.synchronize()
+    assert flags.tolist() == [1, 1]
+    # the step saw the action the glue launch wrote: same result as an ordinary step on that action
+    y2, st2, p2, r2 = torch.empty_like(env.y), torch.empty_like(env.state), torch.empty_like(env.p), torch.empty_like(env.reward)
+    with torch.cuda.stream(s_env):
+        L.check(lib.pdec_env_step(env.handle, P(env.y), P(a_t), P(a_prev), P(env.state), P(y2), P(p2), P(st2), P(r2), P(done)))
+    torch.cuda.synchronize()
+    assert float(a_t.abs().max()) > 0 and torch.equal(y1, y2) and torch.equal(st1, st2) and torch.equal(r1, r2)
+    # (b) a batched fp32 step is not the launch that honours it
+    env32 = pkg.PDEenv(pkg.KSSetup.bench_C2(256), B=4, dtype=torch.float32)
+    L.check(lib.pdec_set_launch_sync(env32.handle, P(flags[0:1]), 1, None, 0))
+    with pytest.raises(pkg.PdecError, match="launch sync"):
+        env32(torch.zeros(env32._ashape, dtype=torch.float32, device="cuda:0"))
+    env32(torch.zeros(env32._ashape, dtype=torch.float32, device="cuda:0"))          # (cleared: the next step is ordinary)
+    # (c) nobody raises the flag to 7: the wait gives up, the launch completes
+    t0 = time.perf_counter()
+    with torch.cuda.stream(s_upd):
+        L.check(lib.pdec_set_launch_sync(m.handle, P(flags[0:1]), 7, None, 0))
+        L.check(lib.pdec_step_glue(m.handle, tr._h, L.dtype_code(torch.float64), None, None, A, 0, P(tr.reward), P(tr.terminal),
+                                   tr.capacity, 0, 0, 2, P(env.state), A, 0.0, 1.0, 3, 0, P(a_t), P(tr.state), P(tr.action), cap1, 0, A,
+                                   L.Handle(0), C.byref(served)))
+    torch.cuda.synchronize()
+    assert 0.25 < time.perf_counter() - t0 < 2.0
+    n1 = C.c_int(0)
+    L.check(lib.pdec_launch_sync_timeouts(C.byref(n1)))
+    assert n1.value == n0.value + 1 and float(a_t.abs().max()) == 0.0
+
+
 def test_random_init_kernels_match_the_oracle_stream(pkg):
     """pdec_env_random_init (generate_random_init of KSSetup.jl:288-298 / KellerSegelSetup.jl:373-384 as a kernel) against
     the oracle's formulas evaluated with the coefficients of the same Philox stream (oracle/rng.py)"""
