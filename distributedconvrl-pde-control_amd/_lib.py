@@ -77,6 +77,7 @@ SIGNATURES = {
     "pdec_step_glue_served": [Handle, Handle, _i, _i, _i, _i64, C.POINTER(_i)],
     "pdec_set_launch_sync": [Handle, _vp, _i64, _vp, _i64],
     "pdec_launch_sync_timeouts": [C.POINTER(_i)],
+    "pdec_streams_run_side_by_side": [_vp, _vp, C.POINTER(_i)],
     "pdec_step_glue": [Handle, Handle, _i, _vp, _vp, _i, _i, _vp, _vp, _i64, _i64, _i64, _i, _vp, _i, _d, _d, _u64, _u64, _vp, _vp,
                        _vp, _i64, _i64, _i64, Handle, C.POINTER(_i)],
     "pdec_ddpg_update_async": [Handle] * 4 + [_vp] * 5 + [_i, _d, _d, _i, _d, _d, _vp],

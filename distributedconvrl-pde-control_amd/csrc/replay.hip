@@ -192,6 +192,17 @@ struct Event : Object {
   }
 };
 
+__global__ void sync_probe_wait_kernel(const long long* flag, long long* seen, unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  long long ok = 0;
+  while (!(ok = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= 1)) {
+    __builtin_amdgcn_s_sleep(8);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) break;      // the exit the wait always reaches
+  }
+  *seen = ok;
+}
+__global__ void sync_probe_set_kernel(long long* flag) { __hip_atomic_store(flag, 1ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 int* launch_sync_timeout_counter() {
   static int* ctr = [] {
     int* p = nullptr;
@@ -290,6 +301,30 @@ int pdec_set_launch_sync(pdec_handle handle, const int64_t* wait_flag, int64_t w
   o->sync.wait = reinterpret_cast<const long long*>(wait_flag); o->sync.wait_val = wait_value;
   o->sync.done = reinterpret_cast<long long*>(done_flag); o->sync.done_val = done_value;
   o->sync.timeouts = (wait_flag || done_flag) ? launch_sync_timeout_counter() : nullptr;
+  return PDEC_OK;
+}
+
+// Do two streams run side by side?  HIP maps streams onto a few hardware queues (four by default); two streams that share one
+// execute in issue order, and a launch that waits in the kernel for a launch queued BEHIND it on the same hardware queue waits
+// for nothing.  Probe: a one-thread kernel on `stream_a` waits (up to 20 ms) for a flag that a one-thread kernel issued
+// afterwards on `stream_b` raises.  *yes = 1 when it saw the flag.  Synchronises both streams; call it once per pair of streams.
+int pdec_streams_run_side_by_side(void* stream_a, void* stream_b, int* yes) {
+  PDEC_REQUIRE(yes, "pdec_streams_run_side_by_side: null");
+  *yes = 0;
+  if (stream_a == stream_b) return PDEC_OK;
+  DevBuf buf;
+  PDEC_HIP(buf.alloc(2 * sizeof(long long)));
+  const long long zero[2] = {0, 0};
+  PDEC_HIP(hipMemcpy(buf.p, zero, sizeof(zero), hipMemcpyHostToDevice));
+  long long* f = buf.as<long long>();
+  hipLaunchKernelGGL(sync_probe_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_a, f, f + 1, 2000000ull);
+  hipLaunchKernelGGL(sync_probe_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_b, f);
+  PDEC_HIP(hipGetLastError());
+  PDEC_HIP(hipStreamSynchronize((hipStream_t)stream_a));
+  PDEC_HIP(hipStreamSynchronize((hipStream_t)stream_b));
+  long long h[2] = {0, 0};
+  PDEC_HIP(hipMemcpy(h, buf.p, sizeof(h), hipMemcpyDeviceToHost));
+  *yes = h[1] == 1 ? 1 : 0;
   return PDEC_OK;
 }
 

@@ -231,6 +231,8 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
         ok = C.c_int(0)
         _lib.check(lib.pdec_step_glue_served(pol.behavior_actor.model.handle, tr._h, _lib.dtype_code(env.dtype), 1, cols, cols,
                                              C.byref(ok)))
+        if ok.value:      # ... and the two streams must sit on different hardware queues (a 20-ms bounded probe, once per run)
+            _lib.check(lib.pdec_streams_run_side_by_side(C.c_void_p(s_env.cuda_stream), C.c_void_p(s_upd.cuda_stream), C.byref(ok)))
         if ok.value:
             with _on_stream(s_env):
                 sync = torch.zeros(2, dtype=torch.int64, device=env.device)

@@ -504,6 +504,11 @@ int pdec_stream_wait_event(void* hip_stream, pdec_handle ev);
  * stores done_value to *done_flag behind its last store (NULL: no signal).  Flags: device int64, zeroed by the caller, values
  * increasing.  One-shot: cleared by the launch.  PDEC_E_INVALID from a launch that cannot honour a pending one. */
 int pdec_set_launch_sync(pdec_handle handle, const int64_t* wait_flag, int64_t wait_value, int64_t* done_flag, int64_t done_value);
+/* Do launches on the two streams run side by side?  HIP maps streams onto a few hardware queues; two streams that share one run
+ * in issue order, and a pdec_set_launch_sync wait for a launch queued behind the waiter on the same hardware queue would wait for
+ * nothing.  A caller checks its pair of streams with this once (a 20-ms bounded probe; synchronises both) before it uses
+ * pdec_set_launch_sync across them.  *yes = 1: side by side. */
+int pdec_streams_run_side_by_side(void* stream_a, void* stream_b, int* yes);
 /* waits that gave up since the library was loaded (synchronous read) */
 int pdec_launch_sync_timeouts(int* n);
 

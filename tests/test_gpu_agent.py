@@ -617,16 +617,27 @@ def test_launch_sync_hand_over_refusal_and_timeout(pkg):
     """pdec_set_launch_sync (device-side hand-over between the glue launch and the fused fp64 KS step of one trajectory):
     (a) producer and consumer on two streams: the env step waits INSIDE the kernel for the flag the glue launch raises and
     raises its own; (b) a launch that cannot honour a pending sync refuses (PDEC_E_INVALID) instead of ignoring it; (c) a wait
-    whose hand-over never comes gives up after 0.3 s, counts a timeout, and the launch still completes."""
+    whose hand-over never comes gives up after 0.3 s, counts a timeout, and the launch still completes.  First of all the two
+    streams have to run side by side (pdec_streams_run_side_by_side, what run() asks before it uses the sync)."""
     import ctypes as C
     import time
     L = pkg._lib
+    lib = L.init(0)
+    # HIP maps streams onto a few hardware queues: take streams from torch's pool until the pair sits on two of them
+    s_env, s_upd, side, same = torch.cuda.Stream(), torch.cuda.Stream(), C.c_int(0), C.c_int(1)
+    for _ in range(8):
+        L.check(lib.pdec_streams_run_side_by_side(C.c_void_p(s_env.cuda_stream), C.c_void_p(s_upd.cuda_stream), C.byref(side)))
+        if side.value:
+            break
+        s_upd = torch.cuda.Stream()
+    assert side.value == 1
+    L.check(lib.pdec_streams_run_side_by_side(C.c_void_p(s_env.cuda_stream), C.c_void_p(s_env.cuda_stream), C.byref(same)))
+    assert same.value == 0
     setup = pkg.KSSetup.KS22()
     ns, A = setup.state_shape
-    s_env, s_upd = torch.cuda.Stream(), torch.cuda.Stream()
     env = pkg.PDEenv(setup, B=1, dtype=torch.float64, stream=s_env)
     agent = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=320, stream=s_upd)
-    pol, tr, lib = agent.policy, agent.trajectory, env.lib
+    pol, tr = agent.policy, agent.trajectory
     m = pol.behavior_actor.model
     flags = torch.zeros(2, dtype=torch.int64, device="cuda:0")
     torch.cuda.synchronize()
@@ -643,7 +654,10 @@ def test_launch_sync_hand_over_refusal_and_timeout(pkg):
         L.check(lib.pdec_set_launch_sync(env.handle, P(flags[0:1]), 1, P(flags[1:2]), 1))
         L.check(lib.pdec_env_step(env.handle, P(env.y), P(a_t), P(a_prev), P(env.state), P(y1), P(p1), P(st1), P(r1), P(done)))
     time.sleep(0.02)
-    assert int(flags[1].item()) == 0                      # still waiting (flags read on the null stream)
+    with torch.cuda.stream(s_upd):            # (read through the OTHER stream: the null stream may share s_env's hardware queue)
+        seen = flags.to("cpu", non_blocking=True)
+    s_upd.synchronize()
+    assert seen.tolist() == [0, 0]            # the env step is still waiting
     served = C.c_int(0)
     pol._noise_seed, pol._noise_off = 3, 0
     with torch.cuda.stream(s_upd):
