@@ -673,7 +673,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
 //     iterations; per iteration each wave issues about a third of what an update costs it above.
 // Bit-identical to ddpg_small2_kernel at rho == 1: every sum is taken over the same lanes in the same order (the actor wave sums
 // critic units r * 64 + lane by the wave tree and adds the rows r in order, which is what the cross-wave exchange above does), the
-// expressions are the ones above (test_split_small_update_is_bit_identical).  Needs nA <= 64 and nC <= 448; launched for the exact
+// expressions are the ones above (test_split_small_update_is_bit_identical).  Needs (KA + 2) nA + 1 <= 64 and nC <= 448; launched for the exact
 // KS instantiation only (see the launch code).
 // NWC: the number of critic waves, a compile-time constant (3 for the KS nets' 140 critic units): the row loop of the actor wave
 // unrolls and its 18 wave sums interleave
@@ -721,11 +721,11 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
   }
   // ---- this thread's unit (critic waves: critic unit tid; actor wave: actor unit lane)
   float cw1[KC], cw1m[KC], cw1v[KC], cw1t[KC], cb1 = 0, cb1m = 0, cb1v = 0, cb1t = 0, cw2 = 0, cw2m = 0, cw2v = 0, cw2t = 0;
-  float aw1[KA], aw1m[KA], aw1v[KA], aw1t[KA], ab1 = 0, ab1m = 0, ab1v = 0, ab1t = 0, aw2 = 0, aw2m = 0, aw2v = 0, aw2t = 0;
+  float aw1[KA], aw1t[KA], ab1 = 0, ab1t = 0, aw2 = 0, aw2t = 0;        // (the actor's moments: with their owner lanes, below)
   const int cob1 = nC * K0, cow2 = cob1 + nC, cob2 = cow2 + nC;
   const int aob1 = nA * ns, aow2 = aob1 + nA, aob2 = aow2 + nA;
   float cb2 = g.C.p[cob2], cb2m = g.C.m[cob2], cb2v = g.C.v[cob2], cb2t = g.C.pt[cob2];
-  float ab2 = g.A.p[aob2], ab2m = g.A.m[aob2], ab2v = g.A.v[aob2], ab2t = g.A.pt[aob2];
+  float ab2 = g.A.p[aob2], ab2t = g.A.pt[aob2];
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
     const bool ok = isC && k < K0;
@@ -739,13 +739,23 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
 #pragma unroll
   for (int k = 0; k < KA; ++k) {
     const bool ok = isA && k < ns;
-    aw1[k] = ok ? g.A.p[lane * ns + k] : 0.f; aw1m[k] = ok ? g.A.m[lane * ns + k] : 0.f;
-    aw1v[k] = ok ? g.A.v[lane * ns + k] : 0.f; aw1t[k] = ok ? g.A.pt[lane * ns + k] : 0.f;
+    aw1[k] = ok ? g.A.p[lane * ns + k] : 0.f;
+    aw1t[k] = ok ? g.A.pt[lane * ns + k] : 0.f;
   }
   if (isA) {
-    ab1 = g.A.p[aob1 + lane]; ab1m = g.A.m[aob1 + lane]; ab1v = g.A.v[aob1 + lane]; ab1t = g.A.pt[aob1 + lane];
-    aw2 = g.A.p[aow2 + lane]; aw2m = g.A.m[aow2 + lane]; aw2v = g.A.v[aow2 + lane]; aw2t = g.A.pt[aow2 + lane];
+    ab1 = g.A.p[aob1 + lane]; ab1t = g.A.pt[aob1 + lane];
+    aw2 = g.A.p[aow2 + lane]; aw2t = g.A.pt[aow2 + lane];
   }
+  // The actor's ADAM state lives ONE PARAMETER PER LANE of the actor wave: lane kind * nA + unit owns parameter `kind` (first-layer
+  // weights 0 .. KA-1, then b1, then w2) of unit `unit`, lane (KA + 2) nA owns b2 -- (KA + 2) nA + 1 <= 64 lanes, one ADAM chain per
+  // update instead of KA + 3 one after the other on nA lanes (the actor wave is the long pole of an iteration and ~45 % of its work
+  // was these chains).  Gradients reach their owner and the new weights their unit by ds_bpermute; same arithmetic per parameter.
+  constexpr int NP = KA + 2;
+  const int okind = actor_wave ? lane / nA : 0, ounit = lane - okind * nA;
+  const bool ownP = actor_wave && lane < NP * nA, ownB2 = actor_wave && lane == NP * nA;
+  const int oidx = ownB2 ? aob2 : (okind < KA ? ounit * ns + okind : (okind == KA ? aob1 + ounit : aow2 + ounit));
+  float op = 0.f, om = 0.f, ov = 0.f, opt_unused = 0.f;
+  if ((ownP && (okind >= KA || okind < ns)) || ownB2) { op = g.A.p[oidx]; om = g.A.m[oidx]; ov = g.A.v[oidx]; }
   double bpa0 = g.bpA.cur[0], bpa1 = g.bpA.cur[1], bpc0 = g.bpC.cur[0], bpc1 = g.bpC.cur[1];
   const float invB = 1.f / (float)Bu;
   float closs = 0.f, aloss = 0.f;
@@ -979,14 +989,34 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
             for (int k = 0; k < KA; ++k)
               if (k < ns) gw1[k] = fmaf(dz, bs[k * Bu + c], gw1[k]);
           }
-        if (isA) {
+        {
+          // gradients to their owner lanes (unit lanes hold gw1[k], gb1, gw2 of their unit; gb2 is the same in every lane)
+          auto pull = [&](float x, int from) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from * 4, __builtin_bit_cast(int, x)));
+          };
+          float gown = gb2;
 #pragma unroll
-          for (int k = 0; k < KA; ++k)
-            if (k < ns) s2_adam(aw1[k], aw1m[k], aw1v[k], aw1t[k], gw1[k], g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
-          s2_adam(ab1, ab1m, ab1v, ab1t, gb1, g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
-          s2_adam(aw2, aw2m, aw2v, aw2t, gw2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+          for (int k = 0; k < KA; ++k) {
+            const float t = pull(gw1[k], ounit);
+            if (ownP && okind == k) gown = t;
+          }
+          {
+            const float t1 = pull(gb1, ounit), t2 = pull(gw2, ounit);
+            if (ownP && okind == KA) gown = t1;
+            if (ownP && okind == KA + 1) gown = t2;
+          }
+          if ((ownP && (okind >= KA || okind < ns)) || ownB2)
+            s2_adam(op, om, ov, opt_unused, gown, g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
+          // the new weights back to their units
+#pragma unroll
+          for (int k = 0; k < KA; ++k) {
+            const float t = pull(op, lane + k * nA);
+            if (isA && k < ns) aw1[k] = t;
+          }
+          const float t1 = pull(op, lane + KA * nA), t2 = pull(op, lane + (KA + 1) * nA);
+          if (isA) { ab1 = t1; aw2 = t2; }
+          ab2 = pull(op, NP * nA);
         }
-        s2_adam(ab2, ab2m, ab2v, ab2t, gb2, g.eta_a, g.b1, g.b2, g.eps, o1, o2, 1.f, 0.f, true);
         bpa0 *= g.b1;
         bpa1 *= g.b2;
       }
@@ -1001,20 +1031,13 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
     g.C.p[cob1 + tid] = cb1; g.C.m[cob1 + tid] = cb1m; g.C.v[cob1 + tid] = cb1v;
     g.C.p[cow2 + tid] = cw2; g.C.m[cow2 + tid] = cw2m; g.C.v[cow2 + tid] = cw2v;
   }
-  if (isA) {
-#pragma unroll
-    for (int k = 0; k < KA; ++k)
-      if (k < ns) { g.A.p[lane * ns + k] = aw1[k]; g.A.m[lane * ns + k] = aw1m[k]; g.A.v[lane * ns + k] = aw1v[k]; }
-    g.A.p[aob1 + lane] = ab1; g.A.m[aob1 + lane] = ab1m; g.A.v[aob1 + lane] = ab1v;
-    g.A.p[aow2 + lane] = aw2; g.A.m[aow2 + lane] = aw2m; g.A.v[aow2 + lane] = aw2v;
-  }
+  if ((ownP && (okind >= KA || okind < ns)) || ownB2) { g.A.p[oidx] = op; g.A.m[oidx] = om; g.A.v[oidx] = ov; }
   if (tid == 0) {
     g.C.p[cob2] = cb2; g.C.m[cob2] = cb2m; g.C.v[cob2] = cb2v;
     if (g.losses) g.losses[0] = closs;
     g.bpC.next[0] = bpc0; g.bpC.next[1] = bpc1;
   }
   if (actor_wave && lane == 0) {
-    g.A.p[aob2] = ab2; g.A.m[aob2] = ab2m; g.A.v[aob2] = ab2v;
     if (g.losses) g.losses[1] = aloss;
     g.bpA.next[0] = bpa0; g.bpA.next[1] = bpa1;
   }
@@ -1123,7 +1146,7 @@ static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hA
     // instantiations differ in the last place of the actor's gradient (a product fused into one kernel's sum and not the other's).
     const char* nosplit = getenv("PDEC_SMALL_SPLIT");      // (read per launch: the identity test switches it)
     const int nwc = (a2.nC + 63) / 64;
-    if (a2.g.rho == 1.0f && Bu == 3 && ns == 1 && a2.nA <= 64 && nwc == 3 && !(nosplit && nosplit[0] == '0')) {
+    if (a2.g.rho == 1.0f && Bu == 3 && ns == 1 && 3 * a2.nA + 1 <= 64 && nwc == 3 && !(nosplit && nosplit[0] == '0')) {
       const int ntf = (nwc + 1) * 64, ncol = loops * Bu;
       const size_t ldsf = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * S2_NW * S2_ROW + (size_t)ncol * (2 + S2_NW) +
                           (size_t)2 * ((2 + 2) * nwc * 64 + 4);
