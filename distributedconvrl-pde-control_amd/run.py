@@ -312,6 +312,9 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                 flags = logs.done.cpu().numpy()                                # the one read-back (waits for the whole episode)
         finally:
             _lib.check(lib.pdec_set_episode_halt(tr._h, None))
+            if sync is not None:          # (an exception between a pdec_set_launch_sync and its launch must not leave it pending)
+                lib.pdec_set_launch_sync(pol.behavior_actor.model.handle, None, 0, None, 0)
+                lib.pdec_set_launch_sync(env.handle, None, 0, None, 0)
         if sync is not None:               # a hand-over that never came (0.3 s each) means the results are not the stage loop's
             nto = C.c_int(0)
             _lib.check(lib.pdec_launch_sync_timeouts(C.byref(nto)))
