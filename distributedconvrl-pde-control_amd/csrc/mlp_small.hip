@@ -396,7 +396,12 @@ __device__ __forceinline__ void s2_adam(float& p, float& m, float& v, float& pt,
 
 // EXACT: ns == KA and Bu == BUT are compile-time constants (the shipped experiments: (1,3) KS, (12,3) Keller-Segel,
 // (9,3) fluid), so every column / input-row guard folds away; otherwise KA / BUT are upper bounds checked at run time
-template <int KC, int KA, int BUT, bool EXACT>
+// OS > 0: the ADAM state of the actor's per-unit parameters lives ONE PARAMETER PER (lane, slot) of wave 0 -- flat parameter f in
+// lane f % 64, slot f / 64, OS slots -- instead of ns + 2 parameters per unit thread: the actor's update is then OS fp64 ADAM chains
+// per update (5 for the Keller-Segel actor's 280 parameters) where the 20 unit threads ran 14 one after the other while every other
+// wave waited.  Gradients reach their owners and the new weights (and targets) their units through LDS, inside the wave (LDS
+// operations of one wave execute in order: no barrier).  Same arithmetic per parameter.  Needs nA <= 64, (ns + 2) nA <= 64 OS.
+template <int KC, int KA, int BUT, bool EXACT, int OS = 0>
 __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   const SmallArgs& g = a_in.g;
   extern __shared__ __align__(16) float sm[];
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   const int bstride = (2 * ns + 3) * Bu;    // per loop: s' [ns][Bu], s [ns][Bu], a [Bu], r [Bu], t [Bu]
   float* batch = sm;
   float* red = batch + (size_t)g.loops * bstride;    // [2][S2_NW][S2_ROW]
+  float* xg = red + 2 * S2_NW * S2_ROW;              // OS > 0: [3][64 OS] gradients / new parameters / new targets by flat index
   // three exchanges per update, two buffers: the parity flips from one update to the next, so an exchange never reuses
   // the buffer of the exchange right before it (a fast wave cannot overwrite partials a slow wave is still summing)
   int rp = 0;
@@ -465,6 +471,17 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
   if (isA) {
     ab1 = g.A.p[aob1 + tid]; ab1m = g.A.m[aob1 + tid]; ab1v = g.A.v[aob1 + tid]; ab1t = g.A.pt[aob1 + tid];
     aw2 = g.A.p[aow2 + tid]; aw2m = g.A.m[aow2 + tid]; aw2v = g.A.v[aow2 + tid]; aw2t = g.A.pt[aow2 + tid];
+  }
+  constexpr int OSN = OS > 0 ? OS : 1;
+  float op[OSN], om[OSN], ov[OSN], opt[OSN];
+  const int nown = (ns + 2) * nA;                    // the actor's per-unit parameters = flat indices [0, nown)
+  if constexpr (OS > 0) {
+#pragma unroll
+    for (int j = 0; j < OS; ++j) {
+      const int f = j * 64 + tid;
+      const bool own = tid < 64 && f < nown;
+      op[j] = own ? g.A.p[f] : 0.f; om[j] = own ? g.A.m[f] : 0.f; ov[j] = own ? g.A.v[f] : 0.f; opt[j] = own ? g.A.pt[f] : 0.f;
+    }
   }
   double bpa0 = g.bpA.cur[0], bpa1 = g.bpA.cur[1], bpc0 = g.bpC.cur[0], bpc1 = g.bpC.cur[1];
   const float omr = 1.0f - g.rho, invB = 1.f / (float)Bu;
@@ -612,7 +629,39 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
           for (int k = 0; k < KA; ++k)
             if (k < ns) gw1[k] = fmaf(dz, bs[k * Bu + c], gw1[k]);
         }
-      if (isA) {
+      if constexpr (OS > 0) {
+        if (tid < 64) {                    // wave 0: units -> owners -> units through LDS, in program order
+          float* gA = xg;
+          float* pA = xg + 64 * OS;
+          float* ptA = pA + 64 * OS;
+          if (isA) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k)
+              if (k < ns) gA[tid * ns + k] = gw1[k];
+            gA[aob1 + tid] = gb1;
+            gA[aow2 + tid] = gw2;
+          }
+#pragma unroll
+          for (int j = 0; j < OS; ++j) {
+            const int f = j * 64 + tid;
+            if (f < nown) {
+              s2_adam(op[j], om[j], ov[j], opt[j], gA[f], g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
+              pA[f] = op[j];
+              if (!frz) ptA[f] = opt[j];
+            }
+          }
+          if (isA) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k)
+              if (k < ns) {
+                aw1[k] = pA[tid * ns + k];
+                if (!frz) aw1t[k] = ptA[tid * ns + k];
+              }
+            ab1 = pA[aob1 + tid]; aw2 = pA[aow2 + tid];
+            if (!frz) { ab1t = ptA[aob1 + tid]; aw2t = ptA[aow2 + tid]; }
+          }
+        }
+      } else if (isA) {
 #pragma unroll
         for (int k = 0; k < KA; ++k)
           if (k < ns) s2_adam(aw1[k], aw1m[k], aw1v[k], aw1t[k], gw1[k], g.eta_a, g.b1, g.b2, g.eps, o1, o2, g.rho, omr, frz);
@@ -637,7 +686,16 @@ __global__ __launch_bounds__(512) void ddpg_small2_kernel(Small2Args a_in) {
     g.C.p[cow2 + tid] = cw2; g.C.m[cow2 + tid] = cw2m; g.C.v[cow2 + tid] = cw2v;
     if (!frz) g.C.pt[cow2 + tid] = cw2t;
   }
-  if (isA) {
+  if constexpr (OS > 0) {
+#pragma unroll
+    for (int j = 0; j < OS; ++j) {
+      const int f = j * 64 + tid;
+      if (tid < 64 && f < nown) {
+        g.A.p[f] = op[j]; g.A.m[f] = om[j]; g.A.v[f] = ov[j];
+        if (!frz) g.A.pt[f] = opt[j];
+      }
+    }
+  } else if (isA) {
 #pragma unroll
     for (int k = 0; k < KA; ++k)
       if (k < ns) {
@@ -1136,7 +1194,15 @@ static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hA
     a2.g.lds_params = 0;
     a2.nC = C->dims[1]; a2.nA = A->dims[1];
     const int nt = (std::max(a2.nC, a2.nA) + 63) / 64 * 64;
-    const size_t lds2f = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * S2_NW * S2_ROW;   // + the two exchange buffers
+    // the actor's ADAM state one parameter per lane of wave 0 (template OS slots) for the shipped moving-target shapes
+    const char* noown = getenv("PDEC_SMALL_OWN");          // (read per launch: the identity test switches it)
+    const int nown = (ns + 2) * a2.nA;
+    int os = 0;
+    if (Bu == 3 && a2.nA <= 64 && !(noown && noown[0] == '0')) {
+      if (ns == 12 && nown <= 64 * 5) os = 5;             // Keller-Segel10_16: 14 x 20 parameters
+      else if (ns == 9 && nown <= 64 * 4) os = 4;         // Fluid: 11 x 18
+    }
+    const size_t lds2f = (size_t)loops * (2 * ns + 3) * Bu + (size_t)2 * S2_NW * S2_ROW + (size_t)3 * 64 * os;   // + exchange buffers (+ owner rows)
     a2.g.smp_lds = (int)lds2f;
     const size_t lds2 = (lds2f + tab_floats) * 4;
     ProfScope ps(C, "ddpg_small");
@@ -1162,6 +1228,8 @@ static int ddpg_update_small_impl(pdec_handle hA, pdec_handle hC, pdec_handle hA
     }
 #define S2_LAUNCH(KC, KA, BUT, EX) hipLaunchKernelGGL((ddpg_small2_kernel<KC, KA, BUT, EX>), dim3(1), dim3(nt), lds2, C->stream, a2)
     if (Bu == 3 && ns == 1) S2_LAUNCH(2, 1, 3, true);            // KS22 / KS200 / KS500
+    else if (Bu == 3 && ns == 12 && os == 5) hipLaunchKernelGGL((ddpg_small2_kernel<13, 12, 3, true, 5>), dim3(1), dim3(nt), lds2, C->stream, a2);
+    else if (Bu == 3 && ns == 9 && os == 4) hipLaunchKernelGGL((ddpg_small2_kernel<10, 9, 3, true, 4>), dim3(1), dim3(nt), lds2, C->stream, a2);
     else if (Bu == 3 && ns == 12) S2_LAUNCH(13, 12, 3, true);    // Keller-Segel10_16
     else if (Bu == 3 && ns == 9) S2_LAUNCH(10, 9, 3, true);      // Fluid
     else if (ns <= 3) S2_LAUNCH(4, 3, S2_BU, false);

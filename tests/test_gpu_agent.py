@@ -552,6 +552,46 @@ def test_split_small_update_is_bit_identical(pkg, which, monkeypatch):
     assert not np.array_equal(fresh.behavior_critic.model.params()[0], p0.behavior_critic.model.params()[0])
 
 
+@pytest.mark.parametrize("which", ["keller_segel", "fluid"])
+def test_owner_lane_adam_is_bit_identical(pkg, which, monkeypatch):
+    """Moving targets (the Keller-Segel / fluid experiments' regime), the 20 x 3 update in one launch: the actor's ADAM state one
+    parameter per lane of wave 0 (gradients and new weights / targets through LDS; 5 ADAM chains per update for the Keller-Segel
+    actor's 280 per-unit parameters instead of 14 on 20 unit threads) == the per-unit form (PDEC_SMALL_OWN=0), bit for bit:
+    parameters, targets, ADAM moments, beta powers, losses after three launches on a wrapped buffer."""
+    from importlib import import_module
+    ck = import_module(pkg.__name__ + ".checkpoint")
+    setup = pkg.KellerSegelSetup() if which == "keller_segel" else pkg.FluidSetup(nx=128)
+    ns, A = setup.state_shape
+    agents = [pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=40 * A) for _ in range(2)]
+    g = torch.Generator()
+    for ag in agents:
+        tr = ag.trajectory
+        g.manual_seed(3)
+        for step in range(55):
+            tr.push_sa(torch.randn(A, ns, generator=g).cuda(), (torch.rand(A, 1, generator=g) * 2 - 1).cuda())
+            tr.push_rt(-torch.rand(A, generator=g).cuda(), (torch.rand(A, generator=g) < 0.1).float().cuda())
+        tr.push_sa(torch.randn(A, ns, generator=g).cuda(), None)
+    for ag, own in zip(agents, ("1", "0")):
+        monkeypatch.setenv("PDEC_SMALL_OWN", own)
+        pol = ag.policy
+        assert pol.small_update_ok() and pol.rho_effective < 1.0
+        pol._sample_seed, pol._sample_off = 4242, 17
+        for _ in range(3):
+            pol.update_small_rng(ag.trajectory)
+        torch.cuda.synchronize()
+    p0, p1 = agents[0].policy, agents[1].policy
+    for n in ("behavior_actor", "behavior_critic", "target_actor", "target_critic"):
+        m0, m1 = getattr(p0, n).model, getattr(p1, n).model
+        for x, y in zip(m0.params(), m1.params()):
+            assert np.array_equal(x, y), n
+        if n.startswith("behavior"):
+            for x, y in zip(ck._adam_state(m0), ck._adam_state(m1)):
+                assert np.array_equal(x, y), n
+    assert p0.losses() == p1.losses()
+    fresh = pkg.create_agent(setup=setup, B=1, rng=np.random.default_rng(5), trajectory_length=40 * A).policy
+    assert not np.array_equal(fresh.target_actor.model.params()[0], p0.target_actor.model.params()[0])
+
+
 @pytest.mark.parametrize("case", ["mid_episode", "zero_policy", "episode_ends_here", "episode_ended_before"])
 def test_step_glue_equals_the_three_launches(pkg, case):
     """pdec_step_glue (POST_ACT push of step t - 1 + agent(env) + PRE_ACT push of step t in ONE launch) == the three calls the
