@@ -340,6 +340,16 @@ __device__ __forceinline__ float s2_wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// the four in-row steps of s2_wave_sum alone: every lane then holds the total of ITS row of 16 lanes (lane 16 r + 15 in exactly
+// the order s2_wave_sum's row totals are formed in), for callers that sum four independent things per DPP chain, one per row
+__device__ __forceinline__ float s2_row_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane^1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane^2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  return v;
+}
+
 // Cross-wave exchange buffers: [2][S2_NW][S2_ROW] floats of LDS -- a row per wave, padded to 32 bytes, always eight rows (a
 // workgroup has at most 512 threads) so that the combining reads below are unconditional vector reads issued together: one LDS
 // round trip per exchange.  (Round 5 form: a loop over the waves with one load and one wait per partial, and the buffer picked
@@ -822,7 +832,41 @@ __global__ __launch_bounds__(512) void ddpg_small2f_kernel(Small2Args a_in) {
   // Columns go four at a time: their wave sums are independent dependency chains (six DPP adds with hazard waits each) that
   // the scheduler interleaves inside one block -- one column per trip cost 15 us of the launch, a quarter of it.
   constexpr int PG = 4;
-  if (actor_wave) {
+  if (actor_wave && nA <= 16) {
+    // The actor's units fit one ROW of 16 lanes: a DPP chain then sums FOUR columns, one per row (unit lane & 15 of column ... + row;
+    // the row totals at lanes 15 / 31 / 47 / 63 are formed exactly like the single row total of s2_wave_sum, whose two broadcast
+    // steps only add the zeros of the empty rows) -- 16 columns per trip of four chains.
+    const int ru = lane & 15, rr = lane >> 4;
+    const bool isAr = ru < nA;
+    float rw1[KA], rb1 = isAr ? g.A.pt[aob1 + ru] : 0.f, rw2 = isAr ? g.A.pt[aow2 + ru] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KA; ++k) rw1[k] = (isAr && k < ns) ? g.A.pt[ru * ns + k] : 0.f;
+    for (int col0 = 0; col0 < ncol; col0 += 64) {
+      float mine = 0.f;
+      const int nc = min(64, ncol - col0);
+      for (int cc0 = 0; cc0 < nc; cc0 += 4 * PG) {
+        float S[PG];
+#pragma unroll
+        for (int u = 0; u < PG; ++u) {
+          const int col = min(col0 + cc0 + 4 * u + rr, ncol - 1), it = col / Bu, c = col - it * Bu;
+          const float* bsn = batch + it * bstride;
+          float zt = rb1;
+#pragma unroll
+          for (int k = 0; k < KA; ++k)
+            if (k < ns) zt += rw1[k] * bsn[k * Bu + c];
+          S[u] = s2_row_sum(isAr ? rw2 * fmaxf(zt, 0.f) : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < PG; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float T = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S[u]), 16 * r + 15));
+            if (lane == cc0 + 4 * u + r) mine = T;
+          }
+      }
+      if (lane < nc) tan_[col0 + lane] = tanhf((0.f + mine) + ab2t);
+    }
+  } else if (actor_wave) {
     for (int col0 = 0; col0 < ncol; col0 += 64) {
       float mine = 0.f;
       const int nc = min(64, ncol - col0);
