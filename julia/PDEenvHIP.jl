@@ -301,6 +301,81 @@ end
 env_set_part_streams(env::UInt64, streams::Vector{Ptr{Cvoid}}) =
     check(ccall((:pdec_env_set_part_streams, LIB), Cint, (UInt64, Ptr{Ptr{Cvoid}}, Cint), env, streams, length(streams)))
 
+# ---- the reference-shaped training loop (one trajectory, `update_loops` x `batch_size` updates per step) with the trajectory on
+# the device: what src/PDEagent.jl:237-361 does on host arrays, as launches.  A `DeviceTrajectory` holds the four circular traces
+# (fp32, as RL.jl keeps them) and the two entry counters; RL.jl's stages map to
+#   PRE_ACT   (:254-274)  push_sa!        POST_ACT (:276-289)  push_rt!       update!(policy) (:342-361)  update_small!
+# and, where the library serves it (`step_glue!` returns true), the POST_ACT push of step t - 1, `agent(env)` and the PRE_ACT push
+# of step t are ONE launch.  With the environment and the agent on two streams that run side by side (`streams_run_side_by_side`)
+# the two hand-overs of a step can happen inside the kernels (`set_launch_sync!` on the actor's and the environment's handle
+# before the glue launch / the env step): see run.py `_run_device_episodes` for the protocol, incl. the episode halt flag
+# (`set_episode_halt!`) that lets a whole episode be enqueued without reading `is_terminated(env)` back per step.
+mutable struct DeviceTrajectory
+    h::UInt64                       # any handle on the stream the pushes run on (the actor's)
+    state::Ptr{Cvoid}; action::Ptr{Cvoid}; reward::Ptr{Cvoid}; terminal::Ptr{Cvoid}
+    capacity::Int64; stride::Int64; ns::Cint; na::Cint
+    n_sa::Int64; n_rt::Int64
+end
+function push_sa!(t::DeviceTrajectory, s_dev::Ptr{Cvoid}, a_dev::Ptr{Cvoid}, n::Integer, dtype::Cint)
+    cap1 = t.capacity + t.stride
+    check(ccall((:pdec_replay_push_sa, LIB), Cint,
+                (UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint),
+                t.h, t.state, t.action, cap1, t.ns, t.na, t.n_sa % cap1, s_dev, a_dev, n, dtype))
+    t.n_sa += n
+end
+function push_rt!(t::DeviceTrajectory, r_dev::Ptr{Cvoid}, done_dev::Ptr{Int32}, cols_per_traj::Integer, timeout::Bool, n::Integer, dtype::Cint)
+    check(ccall((:pdec_replay_push_rt, LIB), Cint,
+                (UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Int32}, Cint, Cint, Int64, Cint),
+                t.h, t.reward, t.terminal, t.capacity, t.n_rt % t.capacity, r_dev, done_dev, cols_per_traj, timeout ? 1 : 0, n, dtype))
+    t.n_rt += n
+end
+# update!(policy, trajectory) for batch_size <= 16: all `loops` minibatch updates in one launch, slots drawn on the device from
+# the Philox stream (seed, offset); returns the offset for the next call
+function update_small!(policy, t::DeviceTrajectory, loops::Integer, Bu::Integer, seed::UInt64, offset::UInt64, losses_dev::Ptr{Cvoid})
+    rho = FROZEN_TARGETS[] ? 1.0 : Float64(policy.p)
+    check(ccall((:pdec_ddpg_update_small_rng, LIB), Cint,
+                (UInt64, UInt64, UInt64, UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, UInt64, UInt64,
+                 Int64, Int64, Int64, Cint, Cdouble, Cdouble, Cint, Cdouble, Cdouble, Ptr{Cvoid}),
+                policy.behavior_actor.model.h, policy.behavior_critic.model.h, policy.target_actor.model.h,
+                policy.target_critic.model.h, t.state, t.action, t.reward, t.terminal, loops, Bu, seed, offset,
+                min(t.n_rt, t.capacity), t.n_rt, t.capacity, t.stride, policy.y, rho, 1,
+                policy.behavior_actor.optimizer.eta, policy.behavior_critic.optimizer.eta, losses_dev))
+    offset + UInt64((loops * Bu + 3) ÷ 4)
+end
+# POST_ACT push of the step that ran (r_dev / done_dev, n_rt values; n_rt = 0: none) + agent(env) on state_dev [cols][ns]
+# (act_mode 1: the actor with exploration noise, 2: the start policy's zero action) + PRE_ACT push of (state, action): one launch.
+# false: not served (nothing enqueued, no counter moved): make the three calls.
+function step_glue!(actor::HipMLP, t::DeviceTrajectory, dtype::Cint, r_dev::Ptr{Cvoid}, done_dev::Ptr{Int32}, cols_per_traj::Integer,
+                    n_rt::Integer, act_mode::Integer, state_dev::Ptr{Cvoid}, cols::Integer, act_noise::Real, act_limit::Real,
+                    seed::UInt64, offset::UInt64, actions_out::Ptr{Cvoid}, done_event::UInt64 = UInt64(0))
+    served = Ref{Cint}(0)
+    cap1 = t.capacity + t.stride
+    check(ccall((:pdec_step_glue, LIB), Cint,
+                (UInt64, UInt64, Cint, Ptr{Cvoid}, Ptr{Int32}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint,
+                 Ptr{Cvoid}, Cint, Cdouble, Cdouble, UInt64, UInt64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64,
+                 UInt64, Ref{Cint}),
+                actor.h, t.h, dtype, r_dev, done_dev, cols_per_traj, 0, t.reward, t.terminal, t.capacity, t.n_rt % t.capacity, n_rt,
+                act_mode, state_dev, cols, act_noise, act_limit, seed, offset, actions_out, t.state, t.action, cap1,
+                t.n_sa % cap1, cols, done_event, served))
+    served[] == 1 || return false
+    t.n_rt += n_rt
+    t.n_sa += cols
+    true
+end
+set_episode_halt!(h::UInt64, flag_dev::Ptr{Int32}) = check(ccall((:pdec_set_episode_halt, LIB), Cint, (UInt64, Ptr{Int32}), h, flag_dev))
+set_launch_sync!(h::UInt64, wait_flag::Ptr{Int64}, wait_value::Integer, done_flag::Ptr{Int64}, done_value::Integer) =
+    check(ccall((:pdec_set_launch_sync, LIB), Cint, (UInt64, Ptr{Int64}, Int64, Ptr{Int64}, Int64), h, wait_flag, wait_value, done_flag, done_value))
+function streams_run_side_by_side(a::Ptr{Cvoid}, b::Ptr{Cvoid})
+    yes = Ref{Cint}(0)
+    check(ccall((:pdec_streams_run_side_by_side, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cint}), a, b, yes))
+    yes[] == 1
+end
+function launch_sync_timeouts()
+    n = Ref{Cint}(0)
+    check(ccall((:pdec_launch_sync_timeouts, LIB), Cint, (Ref{Cint},), n))
+    Int(n[])
+end
+
 # ---- multi-GPU (one Julia process per GPU; the reference itself is single-process) -----------------------------------
 function comm_unique_id()
     id = zeros(UInt8, 128)
