@@ -196,6 +196,76 @@ def _step_glue(lib, pol, tr, env, logs, t, cols, A, acting, pending_rt, done_eve
     return True
 
 
+def _fast_issue(lib, pol, tr, env, agent, logs, T, cols, A, sync, seq):
+    """The step loop of _run_device_episodes for the case where every hand-over is inside the kernels (glue launch served, fused
+    fp64 KS step, small-batch update with device-side sampling): the SAME library calls with the SAME arguments as the general
+    loop below, issued through the raw C functions from addresses computed once -- the general loop spends ~45 us of host time per
+    step (25 pointer look-ups, five wrapped calls) where the GPU needs 57.  Returns issue(marks) or None when the case is not
+    this one."""
+    import ctypes as C
+
+    from . import _lib
+    if not (pol.small_update_ok() and pol.sampling == "device" and getattr(tr, "_h", None) is not None):
+        return None
+    raw = lib._c
+    f_glue, f_sync, f_upd, f_env = raw.pdec_step_glue, raw.pdec_set_launch_sync, raw.pdec_ddpg_update_small_rng, raw.pdec_env_step
+    check = _lib.check
+    Am, Cm, Atm, Ctm = (pol.behavior_actor.model, pol.behavior_critic.model, pol.target_actor.model, pol.target_critic.model)
+    hA, hC, hAt, hCt, henv, htr = Am.handle, Cm.handle, Atm.handle, Ctm.handle, env.handle, tr._h
+    na = Am.dims[-1]
+    dcode = _lib.dtype_code(env.dtype)
+
+    def base(tns):                 # address of slot 0 and bytes per slot of a [slots, ...] log
+        return tns.data_ptr(), tns[0].numel() * tns.element_size()
+    (aS, sS), (aA, sA), (aY, sY), (aP, sP), (aR, sR) = base(logs.state), base(logs.action), base(logs.y), base(logs.p), base(logs.reward)
+    aD = logs.done.data_ptr()
+    pTS, pTA, pTR, pTT = tr.state.data_ptr(), tr.action.data_ptr(), tr.reward.data_ptr(), tr.terminal.data_ptr()
+    cap, cap1, stride = tr.capacity, tr.capacity + tr.stride, tr.stride
+    f0, f1 = sync.data_ptr(), sync.data_ptr() + 8
+    noise, limit = float(pol.act_noise), float(pol.act_limit)
+    loops, Bu = int(pol.update_loops), int(pol.batch_size)
+    gamma, rho, quirk = float(pol.y), pol.rho_effective, int(pol.quirk)
+    eta_a, eta_c = float(pol.behavior_actor.optimizer.eta), float(pol.behavior_critic.optimizer.eta)
+    pL = pol._losses.data_ptr()
+    d_noise, d_sample = (cols * na + 3) // 4, (loops * Bu + 3) // 4
+    served = C.c_int(0)
+    pserved = C.byref(served)
+    after, freq, start_steps = pol.update_after * stride, pol.update_freq, pol.start_steps
+
+    def issue(marks):
+        n_sa, n_rt, ustep, noff, soff, q = tr.n_sa, tr.n_rt, pol.update_step, pol._noise_off, pol._sample_off, seq[0]
+        seed_n, seed_s = pol._noise_seed, pol._sample_seed
+        for t in range(T):
+            ustep += 1
+            q += 1
+            acting = ustep > start_steps
+            pend = t > 0
+            rc = f_sync(hA, f1 if pend else None, q - 1, f0, q)
+            rc = rc or f_glue(hA, htr, dcode, (aR + (t - 1) * sR) if pend else None, (aD + (t - 1) * 4) if pend else None, A, 0,
+                              pTR, pTT, cap, n_rt % cap, cols if pend else 0, 1 if acting else 2, aS + t * sS, cols, noise, limit,
+                              seed_n, noff, aA + (t + 1) * sA, pTS, pTA, cap1, n_sa % cap1, cols, 0, pserved)
+            if rc or not served.value:
+                check(rc)
+                raise RuntimeError("run(device_episodes): pdec_step_glue stopped serving the loop it served at its start")
+            if pend:
+                n_rt += cols
+            n_sa += cols
+            if acting:
+                noff += d_noise
+            if min(n_rt, cap) > after and ustep % freq == 0:                   # Agent._maybe_update, src/PDEagent.jl:354-355
+                rc = f_upd(hA, hC, hAt, hCt, pTS, pTA, pTR, pTT, loops, Bu, seed_s, soff, min(n_rt, cap), n_rt, cap, stride, gamma,
+                           rho, quirk, eta_a, eta_c, pL)
+                soff += d_sample
+            rc = rc or f_sync(henv, f0, q, f1, q)
+            rc = rc or f_env(henv, aY + t * sY, aA + (t + 1) * sA, aA + t * sA, aS + t * sS, aY + (t + 1) * sY, aP + t * sP,
+                             aS + (t + 1) * sS, aR + t * sR, aD + t * 4)
+            if rc:
+                check(rc)
+            marks.append((noff, soff))
+        tr.n_sa, tr.n_rt, pol.update_step, pol._noise_off, pol._sample_off, seq[0] = n_sa, n_rt, ustep, noff, soff, q
+    return issue
+
+
 def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
     """RL.jl's run loop with every episode issued in one go (module docstring of run / device_episodes_ok).  Stream protocol of
     the overlapped loop: acting kernel, PRE_ACT push and the update on the networks' stream, the env step on the environment's
@@ -241,6 +311,8 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
             timeouts0 = [nto.value]
     np_dt = np.float64 if env.dtype == torch.float64 else np.float32
 
+    fast = _fast_issue(lib, pol, tr, env, agent, logs, T, cols, A, sync, seq) if sync is not None else None
+
     def join():
         if two:
             s_upd.wait_stream(s_env)
@@ -267,7 +339,9 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
         try:
             with _on_stream(s_upd):
                 pending_rt = False           # the POST_ACT push of step t - 1 rides on step t's glue launch
-                for t in range(T):
+                if fast is not None:         # the same launches with the same arguments, issued from precomputed addresses
+                    fast(marks)
+                for t in (range(T) if fast is None else ()):
                     pol.update_step += 1
                     a_t = logs.action[t + 1]
                     acting = pol.update_step > pol.start_steps
@@ -305,6 +379,9 @@ def _run_device_episodes(agent, env, stop_condition, hook, s_env, s_upd):
                         ev_env.wait(s_upd)
                     pending_rt = True
                     marks.append((pol._noise_off, pol._sample_off))
+                if fast is not None:
+                    ev_env.record(s_env)
+                    ev_env.wait(s_upd)
                 tr.push_rt_flags(logs.reward[T - 1].view(-1), logs.done[T - 1:T], A, True)      # the last step's: a time-out
                 join()
                 # the per-step episode reward of PDEhook (src/PDEhook.jl:51-63): mean over the actuators, summed over the steps
